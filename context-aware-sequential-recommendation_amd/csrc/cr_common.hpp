@@ -1,0 +1,74 @@
+// Shared device/host helpers for libcastrec (gfx950 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "castrec.h"
+
+int cr_set_error(int code, const char* fmt, ...);
+int cr_check_launch(const char* what);
+
+#define CR_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return cr_set_error(CR_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t cr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------
+// f32-in / f32-accumulate MFMA, v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+// Lane l (li = l & 15, lg = l >> 4):  A[i = li][k = lg],  B[k = lg][j = li],
+// accumulator register r holds D[row = 4*lg + r][col = li].
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#define CR_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// counter-based dropout generator (restated in numpy by tests/dropout_ref.py)
+// ---------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t cr_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t cr_site_key(uint32_t seed, uint32_t step, uint32_t site) {
+    return cr_fmix32(seed ^ cr_fmix32(step * 0x9E3779B9u + site * 0x85EBCA77u + 0x165667B1u));
+}
+__host__ __device__ __forceinline__ bool cr_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
+    return cr_fmix32(idx * 0x9E3779B1u + key) >= thresh;
+}
+
+// device-side view of cr_rng, resolved once per kernel
+struct DropCtx {
+    uint32_t key, thresh;
+    float scale;
+    bool on;
+};
+__device__ __forceinline__ DropCtx drop_ctx(const cr_rng& r) {
+    DropCtx c;
+    c.on = r.rate > 0.0f;
+    c.key = 0; c.thresh = 0; c.scale = 1.0f;
+    if (c.on) {
+        c.key = cr_site_key(r.seed, *r.step, r.site);
+        double t = (double)r.rate * 4294967296.0;
+        c.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+        c.scale = 1.0f / (1.0f - r.rate);
+    }
+    return c;
+}
+__device__ __forceinline__ float drop_apply(const DropCtx& c, uint32_t idx, float v) {
+    return c.on ? (cr_keep(c.key, idx, c.thresh) ? v * c.scale : 0.0f) : v;
+}
+
+static inline int cr_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,117 @@
+// Embedding gather (+ scale, positional row, addend, dropout, row mask) and its backward.
+// Reference: modules.py:83-164 `embedding`; input composition sasrec.py:27-62, cast_1.py:86-91.
+// HBM-bound op: one wavefront per row, lanes sweep the row's columns (coalesced 256-B segments).
+#include "cr_common.hpp"
+
+__global__ __launch_bounds__(256) void k_embed_fwd(cr_embed_desc d) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= d.M) return;
+    const int id = d.ids[m];
+    const bool zero = (d.zero_pad && id == 0);
+    const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
+    const DropCtx dc = drop_ctx(d.drop);
+    const int t = m % d.T;
+    const float* row = d.table + (size_t)id * d.D;
+    for (int c = lane; c < d.D; c += 64) {
+        float v = zero ? 0.0f : row[c] * d.scale;
+        if (d.pos_table) v += d.pos_table[(size_t)t * d.D + c];
+        if (d.addend) v += d.addend[(size_t)m * d.ld_add + c];
+        v = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, v);
+        d.out[(size_t)m * d.ld_out + d.col_off + c] = v * keep_row;
+    }
+}
+
+extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
+    CR_REQUIRE(d && d->ids && d->table && d->out, "cr_embed_fwd: NULL pointer");
+    CR_REQUIRE(d->M > 0 && d->T > 0 && d->D > 0 && d->V > 0 && d->M % d->T == 0, "cr_embed_fwd: bad shape M=%d T=%d D=%d", d->M, d->T, d->D);
+    CR_REQUIRE(d->ld_out >= d->col_off + d->D, "cr_embed_fwd: ld_out too small");
+    hipLaunchKernelGGL(k_embed_fwd, dim3(cr_ceil_div(d->M, 4)), dim3(256), 0, cr_stream(stream), *d);
+    return cr_check_launch("cr_embed_fwd");
+}
+
+// Backward: one workgroup per position t sweeps the batch; the positional-table gradient
+// (sum over the batch) is reduced in registers + LDS (no atomics), the item rows are
+// scatter-added with one 4*D-byte contiguous float-atomic burst per row.
+#define EMB_MAXC 8   // columns per lane: D <= 512
+__global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
+    const cr_embed_desc& d = bd.f;
+    __shared__ float red[4][64 * EMB_MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
+    const int B = d.M / d.T;
+    const DropCtx dc = drop_ctx(d.drop);
+    float acc[EMB_MAXC];
+#pragma unroll
+    for (int i = 0; i < EMB_MAXC; ++i) acc[i] = 0.0f;
+    for (int b = wave; b < B; b += 4) {
+        const int m = b * d.T + t;
+        const int id = d.ids[m];
+        const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
+        const bool skip_table = (d.zero_pad && id == 0) || bd.table_grad == nullptr;
+#pragma unroll
+        for (int i = 0; i < EMB_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d.D) {
+                float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
+                g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
+                acc[i] += g;
+                if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
+                if (!skip_table) atomicAdd(bd.table_grad + (size_t)id * d.D + c, g * d.scale);
+            }
+        }
+    }
+    if (bd.pos_grad) {
+#pragma unroll
+        for (int i = 0; i < EMB_MAXC; ++i) red[wave][lane + 64 * i] = acc[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < d.D; c += 256)
+            bd.pos_grad[(size_t)t * d.D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+
+// Small-table mode (context tables: 8 / 25 / max_bins+1 rows): thousands of rows scatter into a
+// handful of table rows, so global float atomics would serialise on hot rows.  Each workgroup
+// reduces its share of the rows into an LDS image of the table and writes it out as one slab.
+#define EMB_SMALL_MAX 12288   // floats of LDS (48 KiB)
+__global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
+    const cr_embed_desc& d = bd.f;
+    __shared__ float tab[EMB_SMALL_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = d.V * d.D;
+    for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.0f;
+    __syncthreads();
+    const DropCtx dc = drop_ctx(d.drop);
+    const int rps = (d.M + gridDim.x - 1) / gridDim.x;
+    const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
+    for (int m = m0 + wave; m < m1; m += 4) {
+        const int id = d.ids[m];
+        const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
+        const bool skip_table = (d.zero_pad && id == 0);
+        for (int c = lane; c < d.D; c += 64) {
+            float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
+            g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
+            if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
+            if (!skip_table) atomicAdd(&tab[id * d.D + c], g * d.scale);
+        }
+    }
+    __syncthreads();
+    float* slab = bd.table_grad + (size_t)blockIdx.x * bd.slab_stride;
+    for (int i = threadIdx.x; i < n; i += 256) slab[i] = tab[i];
+}
+
+extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
+    CR_REQUIRE(bd && bd->f.ids && bd->f.out, "cr_embed_bwd: NULL pointer");
+    const cr_embed_desc* d = &bd->f;
+    CR_REQUIRE(d->M > 0 && d->T > 0 && d->D > 0 && d->M % d->T == 0, "cr_embed_bwd: bad shape");
+    if (bd->n_slabs > 0) {
+        CR_REQUIRE(bd->table_grad != nullptr && bd->pos_grad == nullptr, "cr_embed_bwd: small-table mode needs table_grad and no pos_grad");
+        if ((long long)d->V * d->D > EMB_SMALL_MAX)
+            return cr_set_error(CR_ERR_UNSUPPORTED, "cr_embed_bwd: small-table mode needs V*D <= %d (got %d*%d)", EMB_SMALL_MAX, d->V, d->D);
+        hipLaunchKernelGGL(k_embed_bwd_small, dim3(bd->n_slabs), dim3(256), 0, cr_stream(stream), *bd);
+        return cr_check_launch("cr_embed_bwd(small)");
+    }
+    if (d->D > 64 * EMB_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_embed_bwd: D=%d > %d", d->D, 64 * EMB_MAXC);
+    hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(256), 0, cr_stream(stream), *bd);
+    return cr_check_launch("cr_embed_bwd");
+}

@@ -1,0 +1,99 @@
+// Prediction head (sasrec.py:87-115): pos/neg item gathers, row dot products, masked BCE + AUC sums,
+// and -- fused in the same pass -- the gradients wrt the sequence embedding and the item table.
+// Gradients are UN-normalised (scaled by n_target); cr_adam_step divides by n_target, which is only
+// known after the whole batch (all ranks) has been reduced (sasrec.py:104-108).
+#include <math.h>
+
+#include "cr_common.hpp"
+
+#define HEAD_MAXC 8
+
+__global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
+    __shared__ float red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss_acc = 0.0f, auc_acc = 0.0f, n_acc = 0.0f;
+    for (int m = blockIdx.x * 4 + wave; m < d.M; m += gridDim.x * 4) {
+        const int p = d.pos[m], ng = d.neg[m];
+        float s[HEAD_MAXC], ep[HEAD_MAXC], en[HEAD_MAXC];
+        float pl = 0.0f, nl = 0.0f;
+#pragma unroll
+        for (int i = 0; i < HEAD_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < d.D;
+            s[i] = ok ? d.seq_emb[(size_t)m * d.ld + c] : 0.0f;
+            ep[i] = (ok && p != 0) ? d.table[(size_t)p * d.D + c] : 0.0f;      // row 0 == zeros (modules.py:154-156)
+            en[i] = (ok && ng != 0) ? d.table[(size_t)ng * d.D + c] : 0.0f;
+            pl += ep[i] * s[i];
+            nl += en[i] * s[i];
+        }
+        pl = wave_sum(pl);                                                     // sasrec.py:100
+        nl = wave_sum(nl);                                                     // sasrec.py:101
+        const float ist = (p != 0) ? 1.0f : 0.0f;                              // sasrec.py:104
+        const float sp = 1.0f / (1.0f + expf(-pl)), sn = 1.0f / (1.0f + expf(-nl));
+        if (lane == 0) {
+            loss_acc += ist * (-logf(sp + 1e-24f) - logf(1.0f - sn + 1e-24f)); // sasrec.py:105-108
+            const float dlt = pl - nl;
+            const float sg = (dlt > 0.0f) ? 1.0f : ((dlt < 0.0f) ? -1.0f : 0.0f);
+            auc_acc += ist * (sg + 1.0f) * 0.5f;                               // sasrec.py:113-115
+            n_acc += ist;
+            if (d.pos_logits) d.pos_logits[m] = pl;
+            if (d.neg_logits) d.neg_logits[m] = nl;
+        }
+        if (d.d_seq_emb || d.table_grad) {
+            // d/dpl [-log(sig(pl)+e)] = -sig(1-sig)/(sig+e);  d/dnl [-log(1-sig(nl)+e)] = sig(1-sig)/(1-sig+e)
+            const float dpl = -ist * sp * (1.0f - sp) / (sp + 1e-24f);
+            const float dnl = ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f);
+#pragma unroll
+            for (int i = 0; i < HEAD_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < d.D) {
+                    if (d.d_seq_emb) d.d_seq_emb[(size_t)m * d.ldd + c] = dpl * ep[i] + dnl * en[i];
+                    if (d.table_grad && ist != 0.0f) {
+                        if (p != 0) atomicAdd(d.table_grad + (size_t)p * d.D + c, dpl * s[i]);
+                        if (ng != 0) atomicAdd(d.table_grad + (size_t)ng * d.D + c, dnl * s[i]);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { red[0][wave] = loss_acc; red[1][wave] = auc_acc; red[2][wave] = n_acc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (v != 0.0f) atomicAdd(d.state + threadIdx.x, v);
+    }
+}
+
+extern "C" int cr_head_fwd_bwd(const cr_head_desc* d, void* stream) {
+    CR_REQUIRE(d && d->seq_emb && d->table && d->pos && d->neg && d->state, "cr_head_fwd_bwd: NULL pointer");
+    CR_REQUIRE(d->M > 0 && d->D > 0 && d->V > 0 && d->ld >= d->D, "cr_head_fwd_bwd: bad shape");
+    if (d->D > 64 * HEAD_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd: D=%d > %d", d->D, 64 * HEAD_MAXC);
+    int grid = cr_ceil_div(d->M, 4);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_head, dim3(grid), dim3(256), 0, cr_stream(stream), *d);
+    return cr_check_launch("cr_head_fwd_bwd");
+}
+
+// test_logits (sasrec.py:93-97): last position of every sequence against its candidate items.
+__global__ __launch_bounds__(256) void k_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
+                                                     int B, int T, int D, int n_cand, float* logits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const float* s = seq_emb + (size_t)(b * T + T - 1) * ld;
+    for (int j = wave; j < n_cand; j += 4) {
+        const int id = cand[(size_t)b * n_cand + j];
+        float acc = 0.0f;
+        if (id != 0)
+            for (int c = lane; c < D; c += 64) acc += s[c] * table[(size_t)id * D + c];
+        acc = wave_sum(acc);
+        if (lane == 0) logits[(size_t)b * n_cand + j] = acc;
+    }
+}
+
+extern "C" int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand, int B, int T, int D,
+                              int V, int n_cand, float* logits, void* stream) {
+    CR_REQUIRE(seq_emb && table && cand && logits, "cr_test_logits: NULL pointer");
+    CR_REQUIRE(B > 0 && T > 0 && D > 0 && V > 0 && n_cand > 0 && ld >= D, "cr_test_logits: bad shape");
+    hipLaunchKernelGGL(k_test_logits, dim3(B), dim3(256), 0, cr_stream(stream), seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+    return cr_check_launch("cr_test_logits");
+}

@@ -1,0 +1,137 @@
+"""ctypes binding of libcastrec.so (the C ABI of include/castrec.h).
+
+No fallback: if the library has not been built (``python -m castrec_amd.build``) importing this
+module raises.  The structures below mirror include/castrec.h field by field."""
+import ctypes as C
+import os
+
+from . import PKG_DIR
+
+LIB_PATH = os.path.join(PKG_DIR, "libcastrec.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError("castrec_amd: native library %s not found -- build it with "
+                      "`python -m castrec_amd.build` (needs hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+c_f = C.c_float
+c_i = C.c_int
+c_u32 = C.c_uint32
+c_p = C.c_void_p
+
+CR_MAX_BATCH = 4
+CR_STATE_FLOATS = 8
+ELT_COPY, ELT_ADD, ELT_DROPOUT, ELT_RELU_BWD, ELT_ROWMASK = 0, 1, 2, 3, 4
+
+
+class Rng(C.Structure):
+    _fields_ = [("rate", c_f), ("site", c_u32), ("seed", c_u32), ("step", c_p), ("row_offset", c_u32)]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("ids", c_p), ("table", c_p), ("M", c_i), ("T", c_i), ("D", c_i), ("V", c_i),
+                ("zero_pad", c_i), ("scale", c_f), ("pos_table", c_p), ("addend", c_p), ("ld_add", c_i),
+                ("drop", Rng), ("mask_ids", c_p), ("out", c_p), ("ld_out", c_i), ("col_off", c_i)]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [("f", EmbedDesc), ("table_grad", c_p), ("pos_grad", c_p), ("d_addend", c_p),
+                ("slab_stride", c_i), ("n_slabs", c_i)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i), ("gamma", c_p), ("beta", c_p), ("y", c_p), ("ldy", c_i),
+                ("M", c_i), ("D", c_i), ("eps", c_f), ("x_nonzero", c_p), ("y_nonzero", c_p)]
+
+
+class LnBwdDesc(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i), ("gamma", c_p), ("dy", c_p), ("lddy", c_i), ("dx", c_p), ("lddx", c_i),
+                ("accumulate", c_i), ("dgamma", c_p), ("dbeta", c_p), ("slab_stride", c_i), ("n_slabs", c_i),
+                ("M", c_i), ("D", c_i), ("eps", c_f)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", c_p), ("lda", c_i), ("B", c_p), ("ldb", c_i), ("bias", c_p), ("C", c_p), ("ldc", c_i),
+                ("M", c_i), ("N", c_i), ("K", c_i), ("trans_b", c_i), ("relu", c_i), ("drop", Rng),
+                ("residual", c_p), ("ldr", c_i), ("mask_ids", c_p), ("accumulate", c_i)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("A", c_p), ("lda", c_i), ("G", c_p), ("ldg", c_i), ("dW", c_p), ("db", c_p),
+                ("M", c_i), ("N", c_i), ("K", c_i)]
+
+
+class EltDesc(C.Structure):
+    _fields_ = [("op", c_i), ("x", c_p), ("ldx", c_i), ("aux", c_p), ("ldaux", c_i), ("y", c_p), ("ldy", c_i),
+                ("M", c_i), ("N", c_i), ("drop", Rng), ("mask_ids", c_p), ("accumulate", c_i)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", c_p), ("K", c_p), ("V", c_p), ("ld", c_i), ("k_valid", c_p), ("q_valid", c_p),
+                ("residual", c_p), ("ldr", c_i), ("dead_ids", c_p), ("out", c_p), ("ldo", c_i),
+                ("attn_weights", c_p), ("B", c_i), ("T", c_i), ("H", c_i), ("d", c_i), ("drop", Rng),
+                ("batch_global", c_i)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("f", AttnDesc), ("dout", c_p), ("lddo", c_i), ("dQ", c_p), ("dK", c_p), ("dV", c_p),
+                ("ldg", c_i), ("stats", c_p)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("seq_emb", c_p), ("ld", c_i), ("table", c_p), ("pos", c_p), ("neg", c_p),
+                ("M", c_i), ("D", c_i), ("V", c_i), ("state", c_p), ("d_seq_emb", c_p), ("ldd", c_i),
+                ("table_grad", c_p), ("pos_logits", c_p), ("neg_logits", c_p)]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
+                ("n_table", c_i), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
+                ("beta2", c_f), ("eps", c_f), ("state", c_p)]
+
+
+def _sig(name, restype, argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+# every symbol include/castrec.h declares (tests/test_abi.py checks this list against the header)
+_sig("cr_version", c_i, [])
+_sig("cr_last_error", C.c_char_p, [])
+_sig("cr_step_begin", c_i, [c_p, c_p])
+_sig("cr_embed_fwd", c_i, [C.POINTER(EmbedDesc), c_p])
+_sig("cr_embed_bwd", c_i, [C.POINTER(EmbedBwdDesc), c_p])
+_sig("cr_layernorm_fwd", c_i, [C.POINTER(LnDesc), c_p])
+_sig("cr_layernorm_bwd", c_i, [C.POINTER(LnBwdDesc), c_p])
+_sig("cr_gemm_rows", c_i, [C.POINTER(GemmDesc), c_i, c_p])
+_sig("cr_gemm_wgrad", c_i, [C.POINTER(WgradDesc), c_i, c_i, c_i, c_p])
+_sig("cr_eltwise", c_i, [C.POINTER(EltDesc), c_p])
+_sig("cr_attn_fwd", c_i, [C.POINTER(AttnDesc), c_p])
+_sig("cr_attn_bwd", c_i, [C.POINTER(AttnBwdDesc), c_p])
+_sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
+_sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
+_sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
+_sig("cr_graph_begin", c_i, [c_p])
+_sig("cr_graph_end", c_i, [c_p, C.POINTER(c_p)])
+_sig("cr_graph_launch", c_i, [c_p, c_p])
+_sig("cr_graph_destroy", c_i, [c_p])
+_sig("cr_sampler_create", c_p, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_u32, c_i])
+_sig("cr_sampler_next", c_i, [c_p] + [c_p] * 8)
+_sig("cr_sampler_destroy", None, [c_p])
+
+EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
+           "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
+           "cr_head_fwd_bwd", "cr_test_logits", "cr_adam_step", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
+           "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]
+
+lib = _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("castrec %s failed (%d): %s" % (what, rc, _lib.cr_last_error().decode()))
+
+
+def call(name, *args):
+    check(getattr(_lib, name)(*args), name)

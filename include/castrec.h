@@ -1,0 +1,252 @@
+/* castrec.h -- C ABI of libcastrec.so, the MI355X (gfx950) native hot path for
+ * SASRec / CAST training (drop-in for the hot path of
+ * Spijkervet/Context-Aware-Sequential-Recommendation).
+ *
+ * The reference has no FFI: its "operator interface" is the set of Python free
+ * functions in modules.py plus the graph code in models/<model>.py that TensorFlow
+ * executes.  Each entry point below replaces one of those (file:line cited); the
+ * Python mirror of the reference interface (castrec_amd/models, castrec_amd/sampler)
+ * binds them through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain C: pointers, ints, floats.  No torch / HIP types in signatures
+ *    (`stream` is a hipStream_t passed as void*; NULL = default stream).
+ *  - every device buffer is allocated and owned by the caller; the library
+ *    allocates nothing on the device and keeps no pointer after return.
+ *  - all kernels are asynchronous on `stream`; no entry point synchronises.
+ *  - activations are fp32 row-major matrices [M, ld] with M = B*T rows
+ *    (row b*T + t), `ld` = leading dimension in floats.
+ *  - return value: 0 on success, <0 on error (CR_ERR_*); cr_last_error() gives a
+ *    thread-local message.  The Python side raises RuntimeError.
+ *  - dropout uses a counter-based generator (cr_rng): keep(e) is a pure function
+ *    of (seed, *step, site, element index) so backward regenerates the forward
+ *    mask and results are independent of how a batch is sharded over GPUs.
+ */
+#ifndef CASTREC_H
+#define CASTREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CR_OK 0
+#define CR_ERR_INVALID (-1)     /* bad argument / shape */
+#define CR_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define CR_ERR_HIP (-3)         /* HIP runtime error (launch failure ...) */
+
+#define CR_MAX_BATCH 4          /* problems per batched GEMM launch */
+#define CR_STATE_FLOATS 8       /* device state block, see cr_step_begin */
+
+int cr_version(void);
+const char* cr_last_error(void);
+/* number of device slabs a dense-gradient producer writes (= grid of the reducing
+ * kernels); the caller sizes the slab buffer as n_slabs * n_dense floats. */
+
+/* ---- dropout generator -------------------------------------------------------- */
+typedef struct {
+    float rate;            /* 0 = no dropout (is_training False) */
+    uint32_t site;         /* distinct id per dropout call site in the graph */
+    uint32_t seed;
+    const uint32_t* step;  /* device pointer: step counter (state[4] as uint32) */
+    uint32_t row_offset;   /* global row index of local row 0 (data-parallel shards) */
+} cr_rng;
+
+/* ---- per-step device state ---------------------------------------------------- */
+/* state (device, CR_STATE_FLOATS floats):
+ *   [0] loss_sum  [1] auc_sum  [2] n_target  (accumulated by cr_head_fwd_bwd)
+ *   [3] reserved  [4] step counter (uint32 bits)  [5] loss  [6] auc (written by cr_adam_step)
+ * cr_step_begin zeroes [0..3] and increments [4]; call it first in every step. */
+int cr_step_begin(float* state, void* stream);
+
+/* ---- embedding gather (modules.py:83-164 `embedding`, sasrec.py:27-62, cast_1.py:86-91) */
+typedef struct {
+    const int32_t* ids;     /* [M] */
+    const float* table;     /* [V, D] */
+    int M, T, D, V;
+    int zero_pad;           /* modules.py:154-156: id 0 reads as a zero row */
+    float scale;            /* modules.py:159-160: sqrt(D) or 1 */
+    const float* pos_table; /* optional [T, D]: learned dec_pos (sasrec.py:40-50) or the static
+                               sinusoid (modules.py:27-37); row t = m % T is added */
+    const float* addend;    /* optional [M, ld_add]: e.g. the context sequence (cast_1.py:87) */
+    int ld_add;
+    cr_rng drop;            /* sasrec.py:59-61 */
+    const int32_t* mask_ids;/* optional [M]: out *= (mask_ids[m] != 0)  (sasrec.py:62) */
+    float* out;             /* [M, ld_out], written at columns [col_off, col_off + D) */
+    int ld_out, col_off;
+} cr_embed_desc;
+int cr_embed_fwd(const cr_embed_desc* d, void* stream);
+
+/* backward of cr_embed_fwd: g = dout (*mask)(*dropout); table_grad[id] += scale*g (atomics,
+ * row 0 skipped when zero_pad); pos_grad[t] = sum_b g (written, not accumulated);
+ * d_addend = g (written).  Unused outputs may be NULL. */
+typedef struct {
+    cr_embed_desc f;        /* same description as the forward call (out = dout here) */
+    float* table_grad;      /* [V, D] accumulated (n_slabs == 0), or slab 0 of a small table */
+    float* pos_grad;        /* [T, D] or NULL (large-table mode only) */
+    float* d_addend;        /* [M, ld_add] or NULL */
+    int slab_stride, n_slabs; /* n_slabs > 0: small-table mode (V*D*4 <= 48 KiB, context tables with
+                               8..201 rows): each of n_slabs workgroups reduces its rows in LDS and
+                               WRITES slab s (no hot-row global atomics) */
+} cr_embed_bwd_desc;
+int cr_embed_bwd(const cr_embed_bwd_desc* d, void* stream);
+
+/* ---- layer normalisation (modules.py:53-80 `normalize`) ------------------------- */
+typedef struct {
+    const float* x; int ldx;
+    const float* gamma; const float* beta;
+    float* y; int ldy;
+    int M, D;
+    float eps;              /* 1e-8, inside the sqrt (modules.py:77) */
+    float* x_nonzero;       /* optional [M]: (sum_c x[m,c] != 0)  -> key mask   (modules.py:222) */
+    float* y_nonzero;       /* optional [M]: (sum_c y[m,c] != 0)  -> query mask (modules.py:248-249) */
+} cr_ln_desc;
+int cr_layernorm_fwd(const cr_ln_desc* d, void* stream);
+
+typedef struct {
+    const float* x; int ldx;     /* forward input */
+    const float* gamma;
+    const float* dy; int lddy;
+    float* dx; int lddx;
+    int accumulate;              /* dx += ... instead of dx = ... */
+    float* dgamma; float* dbeta; /* slab 0; slab s at + s*slab_stride; every slab is written */
+    int slab_stride, n_slabs;
+    int M, D;
+    float eps;
+} cr_ln_bwd_desc;
+int cr_layernorm_bwd(const cr_ln_bwd_desc* d, void* stream);
+
+/* ---- row GEMM with fused epilogue -------------------------------------------------
+ * C[M,N] = epilogue(A[M,K] @ op(B) + bias)
+ *   tf.layers.dense (modules.py:203-205,333-334), conv1d k=1 (modules.py:300-310),
+ *   and their data gradients (trans_b = 1).
+ * epilogue order: +bias -> relu -> dropout -> +residual -> *row mask -> (accumulate) */
+typedef struct {
+    const float* A; int lda;
+    const float* B; int ldb;   /* trans_b=0: B is [K,N]; trans_b=1: B is [N,K] (C = A @ B^T) */
+    const float* bias;         /* [N] or NULL */
+    float* C; int ldc;
+    int M, N, K;
+    int trans_b;
+    int relu;
+    cr_rng drop;               /* element index = m*N + n */
+    const float* residual; int ldr;
+    const int32_t* mask_ids;   /* [M] or NULL */
+    int accumulate;            /* C += value */
+} cr_gemm_desc;
+int cr_gemm_rows(const cr_gemm_desc* d, int n_problems, void* stream);
+
+/* weight gradient: dW[K,N] = A[M,K]^T @ G[M,N], db[N] = colsum(G); reduction over M is split
+ * over n_slabs workgroups, each writing its own slab (no atomics, bitwise reproducible). */
+typedef struct {
+    const float* A; int lda;
+    const float* G; int ldg;
+    float* dW;                 /* slab 0, row-major [K,N] */
+    float* db;                 /* slab 0 or NULL */
+    int M, N, K;
+} cr_wgrad_desc;
+int cr_gemm_wgrad(const cr_wgrad_desc* d, int n_problems, int slab_stride, int n_slabs, void* stream);
+
+/* ---- element-wise helpers (dropout on concats, ReLU/dropout gradients, adds, copies) --- */
+#define CR_ELT_COPY 0        /* y = x                                   (concat / split)        */
+#define CR_ELT_ADD 1         /* y = x + aux                                                      */
+#define CR_ELT_DROPOUT 2     /* y = x * keep * 1/(1-rate) (* row mask)  (fwd and bwd are equal)  */
+#define CR_ELT_RELU_BWD 3    /* y = x * (aux > 0)                       (modules.py:300,333-334) */
+#define CR_ELT_ROWMASK 4     /* y = x * (mask_ids[m] != 0)                                       */
+typedef struct {
+    int op;
+    const float* x; int ldx;
+    const float* aux; int ldaux;
+    float* y; int ldy;
+    int M, N;
+    cr_rng drop;             /* CR_ELT_DROPOUT: element index = m*N + n */
+    const int32_t* mask_ids; /* optional */
+    int accumulate;          /* y += value */
+} cr_elt_desc;
+int cr_eltwise(const cr_elt_desc* d, void* stream);
+
+/* ---- causal multi-head self-attention core (modules.py:208-269) ---------------------
+ * Per head j (columns [j*d, (j+1)*d) of Q/K/V, d = D/H):
+ *   S = Q K^T / sqrt(d); masked (key invalid or key > query) -> -2^32+1; softmax over all T keys
+ *   (a row with no valid key is uniform 1/T over ALL keys, modules.py:227-244);
+ *   A = softmax * q_valid; dropout; out = A V + residual.
+ * q_valid / k_valid are the data-dependent masks sign(|sum_c .|) computed by cr_layernorm_fwd. */
+typedef struct {
+    const float* Q; const float* K; const float* V; int ld;   /* [M, ld], M = B*T */
+    const float* k_valid;      /* [M] */
+    const float* q_valid;      /* [M] */
+    const float* residual; int ldr;  /* queries (modules.py:269) */
+    const int32_t* dead_ids;   /* optional [M]: rows with id 0 are known-dead downstream
+                                  (every block ends with `*= mask`, sasrec.py:83): computed as A = 0 */
+    float* out; int ldo;
+    float* attn_weights;       /* optional [H*B, T, T] (modules.py:259), head j of sample n at row j*B+n */
+    int B, T, H, d;
+    cr_rng drop;               /* element index = ((j*Bglobal + n)*T + q)*T + k, see batch_global */
+    int batch_global;          /* Bglobal (>= B) for shard-invariant dropout indices */
+} cr_attn_desc;
+int cr_attn_fwd(const cr_attn_desc* d, void* stream);
+
+typedef struct {
+    cr_attn_desc f;            /* forward description (out / attn_weights unused) */
+    const float* dout; int lddo;   /* gradient of `out` (the residual branch is handled by the caller) */
+    float* dQ; float* dK; float* dV; int ldg;
+    float* stats;              /* workspace [H*B*T*4] floats */
+} cr_attn_bwd_desc;
+int cr_attn_bwd(const cr_attn_bwd_desc* d, void* stream);
+
+/* ---- prediction head: pos/neg dot-product BCE (sasrec.py:87-115), forward + backward ---- */
+typedef struct {
+    const float* seq_emb; int ld;   /* [M, D] */
+    const float* table;             /* item table [V, D]; row 0 reads as zeros (modules.py:154-156) */
+    const int32_t* pos; const int32_t* neg;   /* [M] */
+    int M, D, V;
+    float* state;                   /* [0] += loss_sum, [1] += auc_sum, [2] += n_target */
+    float* d_seq_emb; int ldd;      /* optional: UN-normalised gradient (times n_target) */
+    float* table_grad;              /* optional [V, D]: accumulated, un-normalised */
+    float* pos_logits; float* neg_logits;     /* optional [M] */
+} cr_head_desc;
+int cr_head_fwd_bwd(const cr_head_desc* d, void* stream);
+
+/* test_logits (sasrec.py:93-97): logits[b, j] = seq_emb[b*T + T-1, :] . table'[cand[b, j], :] */
+int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
+                   int B, int T, int D, int V, int n_cand, float* logits, void* stream);
+
+/* ---- Adam, TensorFlow formulation (sasrec.py:120) ------------------------------------
+ * g = grad * (1 / n_target); table part: grad = table_grad[i] (zeroed after use);
+ * dense part: grad = sum_s dense_slabs[s*n_dense + i].  lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+ * p -= lr_t*m/(sqrt(v)+eps), t = step counter in state[4].  Also writes state[5] = loss,
+ * state[6] = auc. */
+typedef struct {
+    float* p; float* m; float* v;     /* flat [n_table + n_dense] */
+    float* table_grad;                /* [n_table] */
+    const float* dense_slabs;         /* [n_slabs, n_dense] */
+    int n_table, n_dense, n_slabs;
+    float lr, beta1, beta2, eps;
+    float* state;
+} cr_adam_desc;
+int cr_adam_step(const cr_adam_desc* d, void* stream);
+
+/* ---- HIP graph capture of a whole step (launch-bound inner loop) ---------------------- */
+int cr_graph_begin(void* stream);
+int cr_graph_end(void* stream, void** graph_exec_out);
+int cr_graph_launch(void* graph_exec, void* stream);
+int cr_graph_destroy(void* graph_exec);
+
+/* ---- native batch sampler (sampler.py:9-136), host side, bit-exact ---------------------
+ * The corpus is CSR: events of user u are [offsets[u], offsets[u+1]) (row 0 empty). */
+typedef struct cr_sampler cr_sampler;
+cr_sampler* cr_sampler_create(const int64_t* offsets, const int32_t* items, const float* ratings,
+                              const int64_t* ts, int usernum, int itemnum, int batch_size, int maxlen,
+                              int bin_in_hours, int max_bins, int log_scale, double min_timedelta,
+                              double max_timedelta, uint32_t seed, int queue_depth);
+/* blocks until the next batch is ready; arrays are [B] / [B, maxlen] int32 */
+int cr_sampler_next(cr_sampler* s, int32_t* user, int32_t* seq, int32_t* pos, int32_t* neg,
+                    int32_t* timeseq, int32_t* ratings, int32_t* hours, int32_t* days);
+void cr_sampler_destroy(cr_sampler* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASTREC_H */
