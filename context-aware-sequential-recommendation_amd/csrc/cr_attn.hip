@@ -411,10 +411,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(cr_attn_bwd_desc bd, AttnGe
 static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
     CR_REQUIRE(d->Q && d->K && d->V && d->k_valid && d->q_valid, "%s: NULL pointer", who);
     CR_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->d > 0, "%s: bad shape B=%d T=%d H=%d d=%d", who, d->B, d->T, d->H, d->d);
-    CR_REQUIRE(d->ld >= d->H * d->d, "%s: ld too small", who);
-    CR_REQUIRE(d->batch_global >= d->B, "%s: batch_global < B", who);
     if (d->d > 64) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: head dim %d > 64", who, d->d);
     if (d->T > 256) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: T=%d > 256 (LDS-resident K/V design)", who, d->T);
+    CR_REQUIRE(d->ld >= d->H * d->d, "%s: ld too small", who);
+    CR_REQUIRE(d->batch_global >= d->B, "%s: batch_global < B", who);
     g->T16 = (d->T + 15) / 16 * 16;
     g->nkt = g->T16 / 16;
     g->dp = (d->d + 3) / 4 * 4;
