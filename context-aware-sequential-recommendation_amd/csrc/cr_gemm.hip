@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(WgradBatch batch) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int krow = k0 + 16 * wave + 4 * lg + r;
-            if (krow < d.K && col < d.N) dW[(size_t)krow * d.N + col] = acc[j][r];
+            if (krow < d.K && col < d.N) dW[(size_t)krow * d.ldw + col] = acc[j][r];
         }
     }
     if (d.db && k0 == 0 && tid < 64 && n0 + tid < d.N) d.db[(size_t)s * batch.slab_stride + n0 + tid] = bsum;
@@ -190,7 +190,7 @@ extern "C" int cr_gemm_wgrad(const cr_wgrad_desc* d, int n, int slab_stride, int
     for (int i = 0; i < n; ++i) {
         CR_REQUIRE(d[i].A && d[i].G && d[i].dW, "cr_gemm_wgrad[%d]: NULL pointer", i);
         CR_REQUIRE(d[i].M > 0 && d[i].N > 0 && d[i].K > 0, "cr_gemm_wgrad[%d]: bad shape", i);
-        CR_REQUIRE(d[i].lda >= d[i].K && d[i].ldg >= d[i].N, "cr_gemm_wgrad[%d]: leading dimension too small", i);
+        CR_REQUIRE(d[i].lda >= d[i].K && d[i].ldg >= d[i].N && d[i].ldw >= d[i].N, "cr_gemm_wgrad[%d]: leading dimension too small", i);
         b.p[i] = d[i];
         tiles += cr_ceil_div(d[i].K, 64) * cr_ceil_div(d[i].N, 64);
     }

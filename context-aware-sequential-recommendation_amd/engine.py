@@ -1,0 +1,651 @@
+"""Static forward/backward programs of the SASRec / CAST graphs, composed of libcastrec kernels.
+
+The reference builds a TensorFlow graph once (models/sasrec.py, models/cast_N.py) and runs it with
+``sess.run``; here the graph of a model is compiled ONCE into two flat lists of pre-built C-ABI
+launches (forward, backward) over persistent device buffers, which makes the whole step capturable
+as a HIP graph (launch-bound problem sizes).  Gradients are hand-derived per op; there is no autograd
+and no CPU fallback.
+
+Memory layout (all fp32, resident in HBM for the life of the engine):
+  P / M / V   flat parameter, Adam-m, Adam-v vectors: [table section | dense section]
+  Gt          table-gradient accumulator (float atomics), zeroed by cr_adam_step after use
+  Gs          dense-gradient slabs [n_slabs, n_dense]: every reducing kernel writes slab s from its
+              workgroup s (no atomics, bitwise reproducible); cr_adam_step sums the slabs
+  activations one [B*T, ld] buffer per tensor of the graph (row = b*T + t)
+"""
+import ctypes as C
+import math
+import zlib
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops as O
+
+MODELS = ["cast_1", "cast_2", "cast_3", "cast_4", "cast_5", "cast_6", "cast_7", "cast_8", "cast_9",
+          "sasrec", "sasrec_static"]          # main.py:28
+
+
+def site_id(name):
+    """Stable 24-bit id of a dropout call site (names follow the graph: 'emb', 'trunk.0.attn', ...)."""
+    return zlib.crc32(name.encode()) & 0xFFFFFF
+
+
+def positional_encoding(dim, length):
+    """modules.py:27-37 (sin on even FLAT indices, cos on odd ones; exponent 2*i/dim)."""
+    v = np.array([pos / np.power(10000, 2 * i / dim) for pos in range(length) for i in range(dim)])
+    v[::2] = np.sin(v[::2])
+    v[1::2] = np.cos(v[1::2])
+    return v.reshape(length, dim).astype(np.float32)
+
+
+class Hyper:
+    """The fields of the reference's argparse namespace the graphs read (main.py:45-82)."""
+
+    def __init__(self, args=None, **kw):
+        d = dict(maxlen=50, hidden_units=50, num_blocks=2, num_heads=1, dropout_rate=0.5, l2_emb=0.0, lr=1e-3,
+                 max_bins=200, num_context_blocks=2, seed=42)
+        for k in d:
+            if args is not None and hasattr(args, k):
+                d[k] = getattr(args, k)
+        d.update(kw)
+        self.__dict__.update(d)
+        if self.l2_emb != 0.0:
+            raise NotImplementedError("l2_emb != 0 is not implemented (every reference run uses 0.0, params.txt)")
+        if self.hidden_units % self.num_heads != 0:
+            raise ValueError("hidden_units must be divisible by num_heads (tf.split, modules.py:208)")
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter layout
+# ---------------------------------------------------------------------------------------------------
+def _stack_entries(prefix, L_, D):
+    out = []
+    for i in range(L_):
+        p = "%s.%d." % (prefix, i)
+        out += [(p + "ln1.gamma", (D,), "ones"), (p + "ln1.beta", (D,), "zeros"),
+                (p + "wqkv", (D, 3 * D), "glorot3"), (p + "bqkv", (3 * D,), "zeros"),
+                (p + "ln2.gamma", (D,), "ones"), (p + "ln2.beta", (D,), "zeros"),
+                (p + "w1", (D, D), "glorot"), (p + "b1", (D,), "zeros"),
+                (p + "w2", (D, D), "glorot"), (p + "b2", (D,), "zeros")]
+    out += [(prefix + ".lnf.gamma", (D,), "ones"), (prefix + ".lnf.beta", (D,), "zeros")]
+    return out
+
+
+def model_structure(model, hp):
+    """Which pieces a graph has: context stacks, small tables, mlp width (SURVEY 8a variant table)."""
+    L_, Lc = hp.num_blocks, hp.num_context_blocks
+    s = dict(ctx={}, small=[], mlp=0, learned_pos=model in ("sasrec", "cast_9"))
+    if model in ("cast_1", "cast_2", "cast_3", "cast_4", "cast_5", "cast_6"):
+        s["ctx"]["ctx_time"] = L_
+    if model == "cast_8":
+        s["ctx"].update(ctx_hours=L_, ctx_days=L_)
+    if model == "cast_9":
+        s["ctx"].update(ctx_hours=Lc, ctx_days=Lc, ctx_time=Lc)
+    if "ctx_time" in s["ctx"]:
+        s["small"].append(("time_emb", hp.max_bins + 1))
+    if model in ("cast_3", "cast_4", "cast_5", "cast_6", "cast_7", "cast_8", "cast_9"):
+        s["small"] += [("hours_emb", 25), ("days_emb", 8)]
+    s["mlp"] = {"cast_2": 2, "cast_3": 3, "cast_4": 4, "cast_5": 3, "cast_6": 4, "cast_7": 3, "cast_8": 3, "cast_9": 4}.get(model, 0)
+    return s
+
+
+class ParamLayout:
+    def __init__(self, model, usernum, itemnum, hp):
+        D, T = hp.hidden_units, hp.maxlen
+        st = model_structure(model, hp)
+        table = [("item_emb", (itemnum + 1, D), "glorot")]
+        if st["learned_pos"]:
+            table.append(("pos_emb", (T, D), "glorot"))
+        dense = [(n, (v, D), "glorot") for n, v in st["small"]]
+        for pfx, Lc in st["ctx"].items():
+            dense += _stack_entries(pfx, Lc, D)
+        if st["mlp"]:
+            k = st["mlp"]
+            dense += [("mlp.w1", (k * D, k * D), "glorot"), ("mlp.b1", (k * D,), "zeros"),
+                      ("mlp.w2", (k * D, D), "glorot"), ("mlp.b2", (D,), "zeros")]
+        dense += _stack_entries("trunk", hp.num_blocks, D)
+        self.entries, off = {}, 0
+        for (n, shape, init) in table:
+            self.entries[n] = (off, shape, init, "table"); off += int(np.prod(shape))
+        self.n_table = off
+        for (n, shape, init) in dense:
+            self.entries[n] = (off, shape, init, "dense"); off += int(np.prod(shape))
+        self.n_total, self.n_dense, self.D = off, off - self.n_table, D
+
+    def logical_names(self):
+        """Names as the oracle / reference variables see them (wq, wk, wv instead of the fused wqkv)."""
+        out = []
+        for n in self.entries:
+            if n.endswith("wqkv"):
+                out += [n[:-4] + x for x in ("wq", "wk", "wv")]
+            elif n.endswith("bqkv"):
+                out += [n[:-4] + x for x in ("bq", "bk", "bv")]
+            else:
+                out.append(n)
+        return out
+
+    def view(self, flat, name):
+        """torch view of a (logical) parameter inside a flat [n_total] tensor."""
+        D = self.D
+        for j, x in enumerate(("q", "k", "v")):
+            if name.endswith(".w" + x):
+                off, shape, _, _ = self.entries[name[:-2] + "wqkv"]
+                return flat[off:off + D * 3 * D].view(D, 3 * D)[:, j * D:(j + 1) * D]
+            if name.endswith(".b" + x):
+                off, shape, _, _ = self.entries[name[:-2] + "bqkv"]
+                return flat[off + j * D:off + (j + 1) * D]
+        off, shape, _, _ = self.entries[name]
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+    def init_host(self, seed):
+        """glorot-uniform kernels/tables (TF default of get_variable, tf.layers.dense/conv1d), zero biases,
+        LayerNorm gamma=1 / beta=0 (modules.py:75-76)."""
+        rs = np.random.RandomState(seed)
+        flat = np.zeros(self.n_total, np.float32)
+        for n, (off, shape, init, _) in self.entries.items():
+            size = int(np.prod(shape))
+            if init == "glorot":
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                flat[off:off + size] = rs.uniform(-lim, lim, size)
+            elif init == "glorot3":       # three independent [D,D] dense kernels side by side
+                D = shape[0]
+                lim = math.sqrt(6.0 / (D + D))
+                flat[off:off + size] = rs.uniform(-lim, lim, size)
+            elif init == "ones":
+                flat[off:off + size] = 1.0
+        return flat
+
+
+# ---------------------------------------------------------------------------------------------------
+class Engine:
+    def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=64,
+                 share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda"):
+        if model not in MODELS:
+            raise ValueError("model must be one of %s" % MODELS)
+        if not torch.cuda.is_available():
+            raise RuntimeError("castrec_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.model, self.hp, self.B, self.T, self.D = model, hp, batch_size, hp.maxlen, hp.hidden_units
+        self.H = hp.num_heads
+        self.M = self.B * self.T
+        self.usernum, self.itemnum = usernum, itemnum
+        self.training = training
+        self.dev = torch.device(device)
+        self.seed = hp.seed if seed is None else seed
+        self.layout = share.layout if share is not None else ParamLayout(model, usernum, itemnum, hp)
+        lay = self.layout
+        self.n_slabs = n_slabs
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        if share is not None:
+            self.P = share.P
+        else:
+            self.P = torch.from_numpy(lay.init_host(self.seed)).to(self.dev)
+        self.state = torch.zeros(L.CR_STATE_FLOATS, **f32)
+        if training:
+            self.Mom = torch.zeros(lay.n_total, **f32)
+            self.Vel = torch.zeros(lay.n_total, **f32)
+            self.Gt = torch.zeros(lay.n_table, **f32)
+            self.Gs = torch.zeros(n_slabs, max(lay.n_dense, 1), **f32)
+        self.drop = O.Drop(hp.dropout_rate if training else 0.0, self.seed, self.state, row_offset)
+        self.batch_global = self.B if batch_global is None else batch_global
+        self.want_attn = want_attn
+        self.attn_weights = None
+        self._bufs, self._keep = {}, []
+        self.fwd, self.bwd = [], []
+        self._bwd_factories = []
+        self._grad_written = set()
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.ids = {k: torch.zeros(self.M, **i32) for k in ("seq", "pos", "neg", "time", "hours", "days")}
+        self.static_pe = torch.from_numpy(positional_encoding(self.D, self.T)).to(self.dev)
+        self._build()
+        self._finalize()
+        self.graph = None
+
+    # ---- small helpers -------------------------------------------------------------------------
+    def buf(self, name, cols, rows=None):
+        if name not in self._bufs:
+            self._bufs[name] = torch.zeros(self.M if rows is None else rows, cols, dtype=torch.float32, device=self.dev)
+        return self._bufs[name]
+
+    def vec(self, name, n=None):
+        if name not in self._bufs:
+            self._bufs[name] = torch.zeros(self.M if n is None else n, dtype=torch.float32, device=self.dev)
+        return self._bufs[name]
+
+    def p(self, name):
+        return self.layout.view(self.P, name)
+
+    def _pptr(self, name):
+        off = self.layout.entries[name][0]
+        return self.P.data_ptr() + 4 * off
+
+    def _gptr(self, name):
+        """slab-0 pointer of a dense parameter's gradient / pointer into Gt for a table parameter."""
+        off, _, _, kind = self.layout.entries[name]
+        if kind == "table":
+            return self.Gt.data_ptr() + 4 * off
+        return self.Gs.data_ptr() + 4 * (off - self.layout.n_table)
+
+    def _acc(self, key):
+        """Backward-time accumulate flag of a gradient buffer: False for its first writer."""
+        first = key not in self._grad_written
+        self._grad_written.add(key)
+        return 0 if first else 1
+
+    def _call(self, lst, name, *args):
+        fn = getattr(L.lib, name)
+        self._keep.append(args)
+        lst.append((name, fn, args))
+
+    def rng(self, site_name, enabled=True):
+        return self.drop.rng(site_id(site_name), enabled and self.training)
+
+    # ---- graph pieces --------------------------------------------------------------------------
+    def op_embed(self, ids_key, table, out, ld_out, col_off, scale, pos=None, addend=None, drop_site=None,
+                 mask=False, small=False):
+        """modules.py:83-164 + the input composition of each graph. `addend` = (buffer, gradbuffer)."""
+        V, D = self.layout.entries[table][1]
+        pos_ptr = None
+        if pos == "static":
+            pos_ptr = self.static_pe.data_ptr()
+        elif pos == "learned":
+            pos_ptr = self._pptr("pos_emb")
+        add_buf = addend[0] if addend else None
+        d = L.EmbedDesc(self.ids[ids_key].data_ptr(), self._pptr(table), self.M, self.T, D, V, 1, float(scale), pos_ptr,
+                        add_buf.data_ptr() if addend else None, add_buf.shape[1] if addend else 0,
+                        self.rng(drop_site) if drop_site else O.NO_DROP,
+                        self.ids["seq"].data_ptr() if mask else None, out.data_ptr(), ld_out, col_off)
+        self._call(self.fwd, "cr_embed_fwd", C.byref(d))
+        if not self.training:
+            return
+
+        def factory(dname=out, d=d):
+            f = L.EmbedDesc.from_buffer_copy(d)
+            f.out = self._grad_of(out).data_ptr()
+            dadd = None
+            if addend:
+                assert self._acc(id(addend[1])) == 0, "addend gradient must be first-written here"
+                dadd = addend[1].data_ptr()
+            bd = L.EmbedBwdDesc(f, self._gptr(table), self._gptr("pos_emb") if pos == "learned" else None, dadd,
+                                self.Gs.shape[1] if small else 0, self.n_slabs if small else 0)
+            lst = []
+            self._call(lst, "cr_embed_bwd", C.byref(bd))
+            return lst
+        self._bwd_factories.append(factory)
+
+    def _grad_of(self, t):
+        """gradient buffer paired with activation buffer t (same shape), created on demand."""
+        key = "d@%d" % t.data_ptr()
+        if key not in self._bufs:
+            self._bufs[key] = torch.zeros_like(t)
+        return self._bufs[key]
+
+    def op_layernorm(self, x, y, y_ld, y_col, pname, flags=None):
+        """modules.py:53-80.  y may be a column block of a wider (concat) buffer."""
+        M, D = self.M, self.D
+        yptr = y.data_ptr() + 4 * y_col
+        d = L.LnDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), self._pptr(pname + ".beta"), yptr, y_ld, M, D, 1e-8,
+                     flags[0].data_ptr() if flags else None, flags[1].data_ptr() if flags else None)
+        self._call(self.fwd, "cr_layernorm_fwd", C.byref(d))
+        if not self.training:
+            return
+
+        def factory():
+            dy = self._grad_of(y)
+            dx = self._grad_of(x)
+            bd = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), dy.data_ptr() + 4 * y_col, y_ld,
+                             dx.data_ptr(), D, self._acc(id(dx)), self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"),
+                             self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+            lst = []
+            self._call(lst, "cr_layernorm_bwd", C.byref(bd))
+            return lst
+        self._bwd_factories.append(factory)
+
+    def op_dropout_inplace(self, c, ncols, site):
+        """tf.layers.dropout on the first `ncols` columns of concat buffer c (cast_2.py:90-92, cast_4.py:115-124)."""
+        ld = c.shape[1]
+        d = L.EltDesc(L.ELT_DROPOUT, c.data_ptr(), ld, None, 0, c.data_ptr(), ld, self.M, ncols, self.rng(site), None, 0)
+        self._call(self.fwd, "cr_eltwise", C.byref(d))
+        if not self.training:
+            return
+
+        def factory():
+            g = self._grad_of(c)
+            bd = L.EltDesc(L.ELT_DROPOUT, g.data_ptr(), ld, None, 0, g.data_ptr(), ld, self.M, ncols, self.rng(site), None, 0)
+            lst = []
+            self._call(lst, "cr_eltwise", C.byref(bd))
+            return lst
+        self._bwd_factories.append(factory)
+
+    def op_mlp(self, c, out, k, mask_out=False):
+        """modules.py:321-335: relu(dense(relu(dense(c)))), widths kD -> kD -> D."""
+        M, D = self.M, self.D
+        K = k * D
+        h = self.buf("mlp.h", K)
+        d1 = O.gemm_desc(c, K, None, K, h, K, M, K, K, relu=True)
+        d1.B, d1.bias = self._pptr("mlp.w1"), self._pptr("mlp.b1")
+        d2 = O.gemm_desc(h, K, None, D, out, out.shape[1], M, D, K, relu=True,
+                         mask_ids=self.ids["seq"] if mask_out else None)
+        d2.B, d2.bias = self._pptr("mlp.w2"), self._pptr("mlp.b2")
+        for d in (d1, d2):
+            arr = (L.GemmDesc * 1)(d)
+            self._call(self.fwd, "cr_gemm_rows", arr, 1)
+        if not self.training:
+            return
+
+        def factory():
+            lst = []
+            dout, dh, dc = self._grad_of(out), self._grad_of(h), self._grad_of(c)
+            g2 = self.buf("mlp.g2", D)
+            e = L.EltDesc(L.ELT_GRADPREP, dout.data_ptr(), out.shape[1], out.data_ptr(), out.shape[1], g2.data_ptr(), D, M, D,
+                          O.NO_DROP, self.ids["seq"].data_ptr() if mask_out else None, 0)
+            self._call(lst, "cr_eltwise", C.byref(e))
+            b = O.gemm_desc(g2, D, None, D, dh, K, M, K, D, trans_b=True, accumulate=bool(self._acc(id(dh))))
+            b.B = self._pptr("mlp.w2")
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 1)(b), 1)
+            e2 = L.EltDesc(L.ELT_GRADPREP, dh.data_ptr(), K, h.data_ptr(), K, dh.data_ptr(), K, M, K, O.NO_DROP, None, 0)
+            self._call(lst, "cr_eltwise", C.byref(e2))
+            w = (L.WgradDesc * 2)(L.WgradDesc(h.data_ptr(), K, g2.data_ptr(), D, self._gptr("mlp.w2"), D, self._gptr("mlp.b2"), M, D, K),
+                                  L.WgradDesc(c.data_ptr(), K, dh.data_ptr(), K, self._gptr("mlp.w1"), K, self._gptr("mlp.b1"), M, K, K))
+            self._call(lst, "cr_gemm_wgrad", w, 2, self.Gs.shape[1], self.n_slabs)
+            b1 = O.gemm_desc(dh, K, None, K, dc, K, M, K, K, trans_b=True, accumulate=bool(self._acc(id(dc))))
+            b1.B = self._pptr("mlp.w1")
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 1)(b1), 1)
+            return lst
+        self._bwd_factories.append(factory)
+
+    def op_block(self, x, y, pfx, attn_out=None):
+        """One transformer block (sasrec.py:65-83): y = mask * FFN(LN2(MHA(LN1(x), x)))."""
+        M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
+        d_head = D // H
+        q_in, o, f_in, hid = (self.buf(pfx + n, D) for n in ("q_in", "o", "f_in", "hid"))
+        qkv = self.buf(pfx + "qkv", 3 * D)
+        kvalid, qvalid = self.vec(pfx + "kvalid"), self.vec(pfx + "qvalid")
+        ids = self.ids["seq"]
+        wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
+        # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
+        ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
+                       1e-8, kvalid.data_ptr(), qvalid.data_ptr())
+        self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln1))
+        # Q = LN1(x) Wq + bq ; [K|V] = x [Wk|Wv] + [bk|bv]   (modules.py:203-205), one batched launch
+        gq = O.gemm_desc(q_in, D, None, 3 * D, qkv, 3 * D, M, D, D)
+        gq.B, gq.bias = wqkv, bqkv
+        gkv = O.gemm_desc(x, D, None, 3 * D, None, 3 * D, M, 2 * D, D)
+        gkv.B, gkv.bias, gkv.C = wqkv + 4 * D, bqkv + 4 * D, qkv.data_ptr() + 4 * D
+        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 2)(gq, gkv), 2)
+        # attention core (modules.py:208-269), residual = queries
+        ad = O.attn_desc(qkv, None, None, 3 * D, kvalid, qvalid, q_in, D, o, D, B, T, H, d_head,
+                         rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
+                         dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
+        ad.K, ad.V = qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
+        self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
+        # LN2 + FFN (modules.py:280-318), residual = LN2 output, then * mask (sasrec.py:83)
+        ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
+                       1e-8, None, None)
+        self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln2))
+        f1 = O.gemm_desc(f_in, D, None, D, hid, D, M, D, D, relu=True, rng=self.rng(pfx[:-1] + ".ffn1"))
+        f1.B, f1.bias = self._pptr(pfx + "w1"), self._pptr(pfx + "b1")
+        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f1), 1)
+        f2 = O.gemm_desc(hid, D, None, D, y, D, M, D, D, rng=self.rng(pfx[:-1] + ".ffn2"), residual=f_in, ldr=D, mask_ids=ids)
+        f2.B, f2.bias = self._pptr(pfx + "w2"), self._pptr(pfx + "b2")
+        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f2), 1)
+        if not self.training:
+            return
+
+        def factory():
+            lst = []
+            dy, dx = self._grad_of(y), self._grad_of(x)
+            g2, g1, df, do, dq_in = (self.buf(pfx + n, D) for n in ("g2", "g1", "df", "do", "dq_in"))
+            dqkv = self.buf(pfx + "dqkv", 3 * D)
+            stats = self.vec(pfx + "stats", H * B * T * 4)
+            S = self.Gs.shape[1]
+            # (a) gradient wrt FFN2 pre-dropout output: dy * mask * keep/(1-rate)
+            e = L.EltDesc(L.ELT_GRADPREP, dy.data_ptr(), D, None, 0, g2.data_ptr(), D, M, D, self.rng(pfx[:-1] + ".ffn2"), ids.data_ptr(), 0)
+            self._call(lst, "cr_eltwise", C.byref(e))
+            # (b) dhid = g2 W2^T ; (c) gate by the stored post-dropout ReLU output
+            b = O.gemm_desc(g2, D, None, D, g1, D, M, D, D, trans_b=True)
+            b.B = self._pptr(pfx + "w2")
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 1)(b), 1)
+            e1 = L.EltDesc(L.ELT_GRADPREP, g1.data_ptr(), D, hid.data_ptr(), D, g1.data_ptr(), D, M, D, self.rng(pfx[:-1] + ".ffn1"), None, 0)
+            self._call(lst, "cr_eltwise", C.byref(e1))
+            # (d) dW2, db2, dW1, db1
+            w = (L.WgradDesc * 2)(L.WgradDesc(hid.data_ptr(), D, g2.data_ptr(), D, self._gptr(pfx + "w2"), D, self._gptr(pfx + "b2"), M, D, D),
+                                  L.WgradDesc(f_in.data_ptr(), D, g1.data_ptr(), D, self._gptr(pfx + "w1"), D, self._gptr(pfx + "b1"), M, D, D))
+            self._call(lst, "cr_gemm_wgrad", w, 2, S, self.n_slabs)
+            # (e) df_in = (g1 W1^T + dy) * mask     (residual branch of modules.py:313)
+            b1 = O.gemm_desc(g1, D, None, D, df, D, M, D, D, trans_b=True, residual=dy, ldr=D, mask_ids=ids)
+            b1.B = self._pptr(pfx + "w1")
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 1)(b1), 1)
+            # (f) LN2 backward -> do
+            l2 = L.LnBwdDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), df.data_ptr(), D, do.data_ptr(), D, 0,
+                             self._gptr(pfx + "ln2.gamma"), self._gptr(pfx + "ln2.beta"), S, self.n_slabs, M, D, 1e-8)
+            self._call(lst, "cr_layernorm_bwd", C.byref(l2))
+            # (g) attention backward -> dQ | dK | dV
+            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + 4 * D,
+                                dqkv.data_ptr() + 8 * D, 3 * D, stats.data_ptr())
+            self._call(lst, "cr_attn_bwd", C.byref(abd))
+            # (h) dWq, dbq ; [dWk|dWv], [dbk|dbv]
+            gw = self._gptr(pfx + "wqkv"); gb = self._gptr(pfx + "bqkv")
+            w2 = (L.WgradDesc * 2)(L.WgradDesc(q_in.data_ptr(), D, dqkv.data_ptr(), 3 * D, gw, 3 * D, gb, M, D, D),
+                                   L.WgradDesc(x.data_ptr(), D, dqkv.data_ptr() + 4 * D, 3 * D, gw + 4 * D, 3 * D, gb + 4 * D, M, 2 * D, D))
+            self._call(lst, "cr_gemm_wgrad", w2, 2, S, self.n_slabs)
+            # (i) dq_in = dQ Wq^T + do (residual, modules.py:269) ; dx (+)= [dK|dV] [Wk|Wv]^T
+            bq = O.gemm_desc(dqkv, 3 * D, None, 3 * D, dq_in, D, M, D, D, trans_b=True, residual=do, ldr=D)
+            bq.B = wqkv
+            bkv = O.gemm_desc(None, 3 * D, None, 3 * D, dx, D, M, D, 2 * D, trans_b=True, accumulate=bool(self._acc(id(dx))))
+            bkv.A, bkv.B = dqkv.data_ptr() + 4 * D, wqkv + 4 * D
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 2)(bq, bkv), 2)
+            # (j) LN1 backward accumulates into dx
+            l1 = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), dq_in.data_ptr(), D, dx.data_ptr(), D, 1,
+                             self._gptr(pfx + "ln1.gamma"), self._gptr(pfx + "ln1.beta"), S, self.n_slabs, M, D, 1e-8)
+            self._call(lst, "cr_layernorm_bwd", C.byref(l1))
+            return lst
+        self._bwd_factories.append(factory)
+
+    def op_stack(self, x, prefix, nblocks, out, out_ld, out_col, want_attn=False):
+        """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns."""
+        cur = x
+        for i in range(nblocks):
+            nxt = self.buf("%s.%d.y" % (prefix, i), self.D)
+            aw = None
+            if want_attn and i == nblocks - 1:
+                self.attn_weights = torch.zeros(self.H * self.B, self.T, self.T, dtype=torch.float32, device=self.dev)
+                aw = self.attn_weights
+            self.op_block(cur, nxt, "%s.%d." % (prefix, i), attn_out=aw)
+            cur = nxt
+        self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf")
+
+    def op_head(self, seq_emb):
+        """sasrec.py:87-115 (+ unnormalised gradients) / test_logits sasrec.py:93-97."""
+        M, D = self.M, self.D
+        self.seq_emb = seq_emb
+        if not self.training:
+            return
+        ds = self._grad_of(seq_emb)
+        self._grad_written.add(id(ds))
+        d = L.HeadDesc(seq_emb.data_ptr(), seq_emb.shape[1], self._pptr("item_emb"), self.ids["pos"].data_ptr(),
+                       self.ids["neg"].data_ptr(), M, D, self.itemnum + 1, self.state.data_ptr(), ds.data_ptr(), ds.shape[1],
+                       self._gptr("item_emb"), None, None)
+        self._call(self.fwd, "cr_head_fwd_bwd", C.byref(d))
+
+    # ---- the eleven graphs -----------------------------------------------------------------------
+    def _build(self):
+        m, D, T, L_ = self.model, self.D, self.T, self.hp.num_blocks
+        sq = math.sqrt(D)    # modules.py:159-160 (num_units ** 0.5)
+        st = model_structure(m, self.hp)
+        wa_ctx = self.want_attn and m in ("cast_1", "cast_2", "cast_3", "cast_4", "cast_5", "cast_6")
+        wa_trunk = self.want_attn and not wa_ctx
+
+        def ctx_stack(table, ids_key, prefix, out, out_ld, out_col, want=False):
+            e = self.buf(prefix + ".emb", D)
+            self.op_embed(ids_key, table, e, D, 0, sq, small=True)                         # cast_1.py:30-38
+            self.op_stack(e, prefix, st["ctx"][prefix], out, out_ld, out_col, want_attn=want)   # cast_1.py:42-60
+
+        if m in ("sasrec", "sasrec_static"):
+            x = self.buf("x0", D)
+            self.op_embed("seq", "item_emb", x, D, 0, sq, pos="learned" if m == "sasrec" else "static",
+                          drop_site="emb", mask=True)                                       # sasrec.py:27-62
+            s = self.buf("seq_emb", D)
+            self.op_stack(x, "trunk", L_, s, D, 0, want_attn=wa_trunk)
+        elif m == "cast_1":
+            tseq = self.buf("tseq", D)
+            ctx_stack("time_emb", "time", "ctx_time", tseq, D, 0, want=wa_ctx)
+            x = self.buf("x0", D)
+            self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)),
+                          drop_site="emb", mask=True)                                       # cast_1.py:86-91
+            s = self.buf("seq_emb", D)
+            self.op_stack(x, "trunk", L_, s, D, 0)
+        elif m in ("cast_2", "cast_3", "cast_4", "cast_7", "cast_8", "cast_9"):
+            k = st["mlp"]
+            c = self.buf("concat", k * D)
+            if m == "cast_2":
+                ctx_stack("time_emb", "time", "ctx_time", c, k * D, D, want=wa_ctx)
+                self.op_embed("seq", "item_emb", c, k * D, 0, sq, pos="static", mask=True)   # cast_2.py:85-86
+                self.op_dropout_inplace(c, 2 * D, "concat1")                                # cast_2.py:89-92
+            elif m == "cast_3":
+                tseq = self.buf("tseq", D)
+                ctx_stack("time_emb", "time", "ctx_time", tseq, D, 0, want=wa_ctx)
+                self.op_embed("hours", "hours_emb", c, k * D, D, sq, small=True)            # cast_3.py:32-41
+                self.op_embed("days", "days_emb", c, k * D, 2 * D, sq, small=True)          # cast_3.py:43-52
+                self.op_embed("seq", "item_emb", c, k * D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)),
+                              mask=True)                                                    # cast_3.py:112-114
+                self.op_dropout_inplace(c, 3 * D, "concat1")                                # cast_3.py:117-120
+            elif m == "cast_4":
+                ctx_stack("time_emb", "time", "ctx_time", c, k * D, D, want=wa_ctx)
+                self.op_embed("seq", "item_emb", c, k * D, 0, sq, pos="static", mask=True)   # cast_4.py:111-112
+                self.op_dropout_inplace(c, 2 * D, "concat1")                                # cast_4.py:115-118
+                self.op_embed("hours", "hours_emb", c, k * D, 2 * D, sq, small=True)
+                self.op_embed("days", "days_emb", c, k * D, 3 * D, sq, small=True)
+                self.op_dropout_inplace(c, 4 * D, "concat2")                                # cast_4.py:121-124
+            elif m in ("cast_7", "cast_8"):
+                if m == "cast_7":
+                    self.op_embed("hours", "hours_emb", c, k * D, D, sq, small=True)        # cast_7.py:30-51
+                    self.op_embed("days", "days_emb", c, k * D, 2 * D, sq, small=True)
+                else:
+                    ctx_stack("hours_emb", "hours", "ctx_hours", c, k * D, D)              # cast_8.py:56-74
+                    ctx_stack("days_emb", "days", "ctx_days", c, k * D, 2 * D)             # cast_8.py:78-95
+                self.op_embed("seq", "item_emb", c, k * D, 0, sq, pos="static", mask=True)   # cast_7.py:77-78
+                self.op_dropout_inplace(c, 3 * D, "concat1")                                # cast_7.py:81-84
+            else:  # cast_9
+                ctx_stack("hours_emb", "hours", "ctx_hours", c, k * D, 2 * D)              # cast_9.py:56-74
+                ctx_stack("days_emb", "days", "ctx_days", c, k * D, 3 * D)                 # cast_9.py:78-95
+                ctx_stack("time_emb", "time", "ctx_time", c, k * D, D)                     # cast_9.py:101-129
+                self.op_embed("seq", "item_emb", c, k * D, 0, sq, pos="learned")            # cast_9.py:149-160
+                self.op_dropout_inplace(c, 4 * D, "concat1")                                # cast_9.py:163-168
+            x = self.buf("x0", D)
+            self.op_mlp(c, x, k, mask_out=(m == "cast_9"))                                  # cast_2.py:95 / cast_9.py:171-174
+            s = self.buf("seq_emb", D)
+            self.op_stack(x, "trunk", L_, s, D, 0, want_attn=wa_trunk)
+        elif m in ("cast_5", "cast_6"):
+            k = st["mlp"]
+            c = self.buf("concat", k * D)
+            x = self.buf("x0", D)
+            if m == "cast_5":
+                tseq = self.buf("tseq", D)
+                ctx_stack("time_emb", "time", "ctx_time", tseq, D, 0, want=wa_ctx)
+                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)))  # cast_5.py:113-114
+                self.op_stack(x, "trunk", L_, c, k * D, 0)                                  # cast_5.py:118-139
+                self.op_embed("hours", "hours_emb", c, k * D, D, sq, small=True)
+                self.op_embed("days", "days_emb", c, k * D, 2 * D, sq, small=True)
+                self.op_dropout_inplace(c, 3 * D, "concat1")                                # cast_5.py:143-146
+            else:
+                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static")                 # cast_6.py:113
+                self.op_stack(x, "trunk", L_, c, k * D, 0)                                  # cast_6.py:117-138
+                ctx_stack("time_emb", "time", "ctx_time", c, k * D, D, want=wa_ctx)
+                self.op_dropout_inplace(c, 2 * D, "concat1")                                # cast_6.py:142-145
+                self.op_embed("hours", "hours_emb", c, k * D, 2 * D, sq, small=True)
+                self.op_embed("days", "days_emb", c, k * D, 3 * D, sq, small=True)
+                self.op_dropout_inplace(c, 4 * D, "concat2")                                # cast_6.py:148-151
+            s = self.buf("seq_emb", D)
+            self.op_mlp(c, s, k)                                                            # cast_5.py:149
+        self.op_head(s)
+
+    def _finalize(self):
+        if self.training:
+            for fac in reversed(self._bwd_factories):
+                self.bwd += fac()
+            lay = self.layout
+            ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
+                            lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr())
+            self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
+            self._keep.append(ad)
+
+    # ---- running ---------------------------------------------------------------------------------
+    def set_batch(self, seq, pos=None, neg=None, time=None, hours=None, days=None):
+        """Copies one batch ([B,T] int arrays, host or device) into the static input buffers."""
+        for k, a in (("seq", seq), ("pos", pos), ("neg", neg), ("time", time), ("hours", hours), ("days", days)):
+            if a is None:
+                continue
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32))
+            self.ids[k].copy_(t.reshape(-1).to(torch.int32), non_blocking=True)
+
+    def _run(self, lst, stream):
+        for name, fn, args in lst:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise RuntimeError("castrec %s failed (%d): %s" % (name, rc, L.lib.cr_last_error().decode()))
+
+    def launch_step(self, apply=True, between=None):
+        """step_begin -> forward -> backward -> [between()] -> Adam, on the current stream."""
+        s = torch.cuda.current_stream().cuda_stream
+        L.check(L.lib.cr_step_begin(self.state.data_ptr(), s), "cr_step_begin")
+        self._run(self.fwd, s)
+        if self.training:
+            self._run(self.bwd, s)
+            if between is not None:
+                between()
+            if apply:
+                self._run([self._adam], s)
+
+    def capture(self):
+        """Captures launch_step() into a HIP graph (inputs are read from the static id buffers)."""
+        g = O.Graph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g.begin()
+            self.launch_step()
+            g.end()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph, self._graph_stream = g, side
+        return g
+
+    def train_step(self, seq, pos, neg, time=None, hours=None, days=None):
+        self.set_batch(seq, pos, neg, time, hours, days)
+        if self.graph is not None:
+            self.graph.launch()
+        else:
+            self.launch_step()
+
+    def loss_auc(self):
+        s = self.state.cpu()
+        return float(s[5]), float(s[6])
+
+    def forward_eval(self, seq, time=None, hours=None, days=None):
+        assert not self.training
+        self.set_batch(seq, None, None, time, hours, days)
+        self.launch_step()
+
+    def test_logits(self, cand):
+        """[B, n_cand] logits of the last position (sasrec.py:93-97); cand int32 device tensor [B, n_cand]."""
+        out = torch.empty(self.B, cand.shape[1], dtype=torch.float32, device=self.dev)
+        O.test_logits(self.seq_emb, self.seq_emb.shape[1], self.p("item_emb"), cand, self.B, self.T, self.D, out)
+        return out
+
+    # ---- parameter / gradient access (tests, checkpoints) ----------------------------------------
+    def get_params(self):
+        return {n: self.layout.view(self.P, n).detach().clone() for n in self.layout.logical_names()}
+
+    def load_params(self, d):
+        for n in self.layout.logical_names():
+            self.layout.view(self.P, n).copy_(torch.as_tensor(np.asarray(d[n]), dtype=torch.float32).to(self.dev))
+
+    def grads(self):
+        """Normalised gradients by logical name, valid after launch_step(apply=False)."""
+        n = float(self.state[2])
+        flat = torch.cat([self.Gt, self.Gs.sum(0)[:self.layout.n_dense]]) / max(n, 1.0)
+        return {k: self.layout.view(flat, k).clone() for k in self.layout.logical_names()}
+
+    def n_launches(self):
+        return 1 + len(self.fwd) + len(self.bwd) + (1 if self.training else 0)

@@ -20,7 +20,7 @@ c_p = C.c_void_p
 
 CR_MAX_BATCH = 4
 CR_STATE_FLOATS = 8
-ELT_COPY, ELT_ADD, ELT_DROPOUT, ELT_RELU_BWD, ELT_ROWMASK = 0, 1, 2, 3, 4
+ELT_COPY, ELT_ADD, ELT_DROPOUT, ELT_RELU_BWD, ELT_ROWMASK, ELT_GRADPREP = 0, 1, 2, 3, 4, 5
 
 
 class Rng(C.Structure):
@@ -56,7 +56,7 @@ class GemmDesc(C.Structure):
 
 
 class WgradDesc(C.Structure):
-    _fields_ = [("A", c_p), ("lda", c_i), ("G", c_p), ("ldg", c_i), ("dW", c_p), ("db", c_p),
+    _fields_ = [("A", c_p), ("lda", c_i), ("G", c_p), ("ldg", c_i), ("dW", c_p), ("ldw", c_i), ("db", c_p),
                 ("M", c_i), ("N", c_i), ("K", c_i)]
 
 

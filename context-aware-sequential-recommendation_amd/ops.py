@@ -83,8 +83,8 @@ def gemm_rows(descs):
     L.call("cr_gemm_rows", arr, len(descs), _stream())
 
 
-def wgrad_desc(A, lda, G, ldg, dW, db, M, N, K):
-    return L.WgradDesc(_p(A), lda, _p(G), ldg, _p(dW), _p(db), M, N, K)
+def wgrad_desc(A, lda, G, ldg, dW, db, M, N, K, ldw=None):
+    return L.WgradDesc(_p(A), lda, _p(G), ldg, _p(dW), N if ldw is None else ldw, _p(db), M, N, K)
 
 
 def gemm_wgrad(descs, slab_stride, n_slabs):

@@ -143,7 +143,8 @@ int cr_gemm_rows(const cr_gemm_desc* d, int n_problems, void* stream);
 typedef struct {
     const float* A; int lda;
     const float* G; int ldg;
-    float* dW;                 /* slab 0, row-major [K,N] */
+    float* dW; int ldw;        /* slab 0, row-major [K,N] with row pitch ldw (>= N): column blocks of a
+                                  fused [D,3D] QKV weight are addressed this way */
     float* db;                 /* slab 0 or NULL */
     int M, N, K;
 } cr_wgrad_desc;
@@ -155,6 +156,11 @@ int cr_gemm_wgrad(const cr_wgrad_desc* d, int n_problems, int slab_stride, int n
 #define CR_ELT_DROPOUT 2     /* y = x * keep * 1/(1-rate) (* row mask)  (fwd and bwd are equal)  */
 #define CR_ELT_RELU_BWD 3    /* y = x * (aux > 0)                       (modules.py:300,333-334) */
 #define CR_ELT_ROWMASK 4     /* y = x * (mask_ids[m] != 0)                                       */
+#define CR_ELT_GRADPREP 5    /* gradient wrt a layer's pre-activation from the gradient of its output:
+                                aux != NULL: y = (aux > 0) ? x/(1-rate) : 0   (ReLU [+dropout] gate read from the
+                                             stored output: kept & positive  <=>  output > 0)
+                                aux == NULL: y = x * keep/(1-rate)            (regenerated dropout mask)
+                                then * row mask */
 typedef struct {
     int op;
     const float* x; int ldx;

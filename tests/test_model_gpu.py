@@ -1,0 +1,174 @@
+"""End-to-end parity of the HIP training path (engine = C-ABI kernels) against the fp64 oracle on
+identical inputs and parameters: loss, AUC, EVERY parameter gradient, Adam-updated parameters, test
+logits -- for all eleven graphs, with and without dropout (the oracle is fed the exact masks of the
+counter-based generator).  Tolerance: 1e-3 is the north-star bound for fp32 forward logits; the
+kernels are exact-fp32 MFMA so the observed error is ~1e-6 and the tests assert 2e-4 (relative)."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import dropout_ref as dr
+from oracle import fpmodel as fm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine
+    return engine
+
+
+def make_batch(rs, B, T, itemnum, max_bins, all_zero_time_rows=True):
+    seq = rs.randint(1, itemnum + 1, (B, T)); pos = rs.randint(1, itemnum + 1, (B, T)); neg = rs.randint(1, itemnum + 1, (B, T))
+    for b in range(B):
+        n = rs.randint(0, T - 2)
+        seq[b, :n] = 0; pos[b, :n] = 0; neg[b, :n] = 0
+    seq[0, :] = 0; pos[0, :] = 0; neg[0, :] = 0                  # an all-padding sequence
+    seq[0, -1] = 3; pos[0, -1] = 4; neg[0, -1] = 5               # ... with a single real position
+    time = rs.randint(0, max_bins + 1, (B, T)) * (seq != 0)
+    time[:, -1] = 0                                              # most recent item is always bin 0 (sampler.py:61-64)
+    if all_zero_time_rows and B > 2:
+        time[2, :] = 0                                           # all interactions in one bin: no valid context key
+    hours = rs.randint(1, 25, (B, T)) * (seq != 0); days = rs.randint(1, 8, (B, T)) * (seq != 0)
+    return seq, pos, neg, time, hours, days
+
+
+def oracle_drop(eng_mod, seed, step, rate, B, T, H):
+    def drop(site, shape):
+        sid = eng_mod.site_id(site)
+        if site.endswith(".attn"):
+            return torch.tensor(dr.attn_mask(seed, step, sid, rate, H, B, T))
+        ncol = shape[-1]
+        return torch.tensor(dr.rows_mask(seed, step, sid, rate, B * T, ncol).reshape(shape))
+    return drop
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+CASES = [(m, 0.0) for m in fm.MODELS] + [("sasrec", 0.3), ("cast_1", 0.3), ("cast_4", 0.25), ("cast_9", 0.2)]
+
+
+@pytest.mark.parametrize("model,rate", CASES)
+def test_model_grads_and_adam_match_oracle(E, model, rate):
+    rs = np.random.RandomState(abs(hash(model)) % 1000 + int(rate * 100))
+    B, T, D, H, itemnum, max_bins = 5, 24, 20, 2, 37, 12
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=rate, max_bins=max_bins,
+                 num_context_blocks=1, lr=1e-3, seed=7)
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=rate, max_bins=max_bins,
+                   num_context_blocks=1, lr=1e-3)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=7)
+    # oracle parameters: perturbed init so LN gains / biases are off their defaults
+    P = fm.init_params(model, 9, itemnum, ohp, seed=3)
+    P = {k: v + 0.1 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
+    assert sorted(P) == sorted(eng.layout.logical_names())
+    eng.load_params(P)
+    P = {k: v.double() for k, v in eng.get_params().items()}        # the fp32-rounded values the GPU holds
+    P = {k: v.cpu() for k, v in P.items()}
+    seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, max_bins)
+    batch = fm.to_batch(seq, pos, neg, time, hours, days)
+    opt = fm.AdamTF(P, lr=1e-3)
+    for step in (1, 2):
+        drop = oracle_drop(E, 7, step, rate, B, T, H) if rate > 0 else None
+        out, G = fm.loss_and_grads(model, P, ohp, batch, drop)
+        eng.set_batch(seq, pos, neg, time, hours, days)
+        eng.launch_step(apply=False)
+        torch.cuda.synchronize()
+        st = eng.state.cpu().numpy()
+        n = st[2]
+        assert n == float(out["istarget"].sum())
+        assert st[0] / n == pytest.approx(float(out["loss"]), rel=2e-5)
+        assert st[1] / n == pytest.approx(float(out["auc"]), abs=1e-6)
+        got = eng.grads()
+        # d loss / d bk == 0 identically (adding a per-query constant to all scores leaves softmax unchanged),
+        # so both sides hold rounding noise there: errors are measured against the global gradient scale.
+        gmax = max(float(G[k].abs().max()) for k in G)
+        def gerr(k):
+            a = got[k].cpu().double().numpy(); b = G[k].numpy()
+            return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3 * gmax))
+        worst = max((gerr(k), k) for k in G)
+        assert worst[0] < 2e-4, worst
+        for k in G:
+            if k.endswith(".bk"):
+                assert float(got[k].abs().max()) < 1e-5 * gmax and float(G[k].abs().max()) < 1e-9 * gmax
+        assert rel(eng.seq_emb, out["seq_emb"].reshape(B * T, -1)) < 2e-5
+        # now apply Adam on both sides (engine: re-run the step with the update; grads are recomputed)
+        eng.Gt.zero_()
+        eng.state[4:5].view(torch.int32)[0] = step - 1
+        eng.launch_step(apply=True)
+        torch.cuda.synchronize()
+        P = opt.step(P, G)
+        now = eng.get_params()
+        # Adam divides by sqrt(v): on the zero-gradient bk it amplifies rounding noise to O(lr) moves on
+        # BOTH sides (in TensorFlow too), so bk is re-synchronised instead of compared.
+        worst = max((float((now[k].cpu().double() - P[k]).abs().max()), k) for k in P if not k.endswith(".bk"))
+        # one Adam step moves a weight by ~lr = 1e-3; m/(sqrt(v)+eps) is ill-conditioned where |g| ~ eps, so the
+        # bound is 5% of a step (the Adam kernel itself is checked to 1e-6 in test_ops_gpu.py)
+        assert worst[0] < 5e-5, worst
+        for k in P:
+            if k.endswith(".bk"):
+                P[k] = now[k].cpu().double()
+                opt.m[k].zero_(); opt.v[k].zero_()
+        off = eng.layout
+        for k in P:
+            if k.endswith(".bk"):
+                eng.layout.view(eng.Mom, k).zero_(); eng.layout.view(eng.Vel, k).zero_()
+        loss, auc = eng.loss_auc()
+        assert loss == pytest.approx(float(out["loss"]), rel=2e-5)
+        P = {k: v.detach() for k, v in P.items()}
+
+
+@pytest.mark.parametrize("model", ["sasrec", "cast_1", "cast_5", "cast_8"])
+def test_eval_logits_and_attention_weights(E, model):
+    rs = np.random.RandomState(5)
+    B, T, D, H, itemnum, max_bins = 4, 16, 10, 1, 30, 8
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.4, max_bins=max_bins, seed=1)
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.4, max_bins=max_bins)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=False, want_attn=True)
+    P = fm.init_params(model, 9, itemnum, ohp, seed=4)
+    P = {k: v + 0.1 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
+    eng.load_params(P)
+    P = {k: v.double().cpu() for k, v in eng.get_params().items()}
+    seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, max_bins)
+    cand = rs.randint(1, itemnum + 1, 101)
+    batch = fm.to_batch(seq, pos, neg, time, hours, days, test_item=cand)
+    out = fm.forward(model, P, ohp, batch, drop=None)              # is_training False
+    eng.forward_eval(seq, time, hours, days)
+    cd = torch.tensor(np.tile(cand, (B, 1)).astype(np.int32)).cuda()
+    lg = eng.test_logits(cd)
+    torch.cuda.synchronize()
+    assert rel(lg, out["test_logits"]) < 1e-4                      # north-star bound: 1e-3
+    assert rel(eng.attn_weights, out["attention_weights"]) < 1e-4
+
+
+def test_graph_replay_equals_eager(E):
+    rs = np.random.RandomState(6)
+    B, T, D, itemnum = 8, 32, 50, 100
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=20, seed=3)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b.P.copy_(a.P)
+    b.capture()
+    batch = make_batch(rs, B, T, itemnum, 20)
+    a.train_step(*batch)
+    b.train_step(*batch)
+    torch.cuda.synchronize()
+    nt = a.layout.n_table
+    assert torch.equal(a.P[nt:], b.P[nt:])                         # dense part: slab reduction, bit-identical
+    assert torch.allclose(a.P[:nt], b.P[:nt], rtol=0, atol=1e-6)   # item table: float atomics may reorder
+    assert a.loss_auc() == pytest.approx(b.loss_auc(), rel=1e-6)   # loss sums use float atomics across workgroups
+    for _ in range(3):                                             # replay keeps tracking eager training
+        batch = make_batch(rs, B, T, itemnum, 20)
+        a.train_step(*batch)
+        b.train_step(*batch)
+    torch.cuda.synchronize()
+    la, lb = a.loss_auc(), b.loss_auc()
+    assert la[0] == pytest.approx(lb[0], rel=1e-3) and int(b.state[4:5].view(torch.int32)[0]) == 4
