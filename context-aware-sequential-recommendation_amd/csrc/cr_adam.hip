@@ -49,3 +49,23 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, cr_stream(stream), *d);
     return cr_check_launch("cr_adam_step");
 }
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* slabs, int n_slabs, int n_dense, float* out,
+                                                      const float* state, float* stats_out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_dense; i += gridDim.x * 256) {
+        float g = 0.0f;
+        for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * n_dense + i];
+        out[i] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3 && stats_out) stats_out[threadIdx.x] = state[threadIdx.x];
+}
+
+extern "C" int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dense, float* out, const float* state,
+                               float* stats_out, void* stream) {
+    CR_REQUIRE(dense_slabs && out && n_slabs > 0 && n_dense > 0, "cr_reduce_slabs: bad arguments");
+    CR_REQUIRE(stats_out == nullptr || state != nullptr, "cr_reduce_slabs: state is NULL");
+    int grid = cr_ceil_div(n_dense, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid), dim3(256), 0, cr_stream(stream), dense_slabs, n_slabs, n_dense, out, state, stats_out);
+    return cr_check_launch("cr_reduce_slabs");
+}

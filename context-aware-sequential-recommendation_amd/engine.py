@@ -185,7 +185,10 @@ class Engine:
         if training:
             self.Mom = torch.zeros(lay.n_total, **f32)
             self.Vel = torch.zeros(lay.n_total, **f32)
-            self.Gt = torch.zeros(lay.n_table, **f32)
+            # flat gradient bucket [table | dense | loss stats(3) + pad]: the table part receives float atomics
+            # directly; the dense part is written by cr_reduce_slabs (data-parallel path only)
+            self.Gflat = torch.zeros(lay.n_total + 4, **f32)
+            self.Gt = self.Gflat[:lay.n_table]
             self.Gs = torch.zeros(n_slabs, max(lay.n_dense, 1), **f32)
         self.drop = O.Drop(hp.dropout_rate if training else 0.0, self.seed, self.state, row_offset)
         self.batch_global = self.B if batch_global is None else batch_global
@@ -196,7 +199,10 @@ class Engine:
         self._bwd_factories = []
         self._grad_written = set()
         i32 = dict(dtype=torch.int32, device=self.dev)
-        self.ids = {k: torch.zeros(self.M, **i32) for k in ("seq", "pos", "neg", "time", "hours", "days")}
+        # the six id inputs of one batch live in ONE [6, M] buffer so a staged batch is a single D2D copy
+        self.ID_KEYS = ("seq", "pos", "neg", "time", "hours", "days")
+        self.ids_all = torch.zeros(6, self.M, **i32)
+        self.ids = {k: self.ids_all[i] for i, k in enumerate(self.ID_KEYS)}
         self.static_pe = torch.from_numpy(positional_encoding(self.D, self.T)).to(self.dev)
         self._build()
         self._finalize()
@@ -569,7 +575,14 @@ class Engine:
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
                             lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr())
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
-            self._keep.append(ad)
+            ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
+                             self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
+                             1e-8, self.state.data_ptr())
+            self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
+            self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
+                            (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,
+                             self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total))
+            self._keep += [ad, ad1]
 
     # ---- running ---------------------------------------------------------------------------------
     def set_batch(self, seq, pos=None, neg=None, time=None, hours=None, days=None):
@@ -598,14 +611,31 @@ class Engine:
             if apply:
                 self._run([self._adam], s)
 
-    def capture(self):
+    # ---- data-parallel pieces (castrec_amd.dist drives them around an RCCL all-reduce) ----------
+    def launch_backward_to_flat(self):
+        """step_begin -> forward -> backward -> slabs collapsed into Gflat (+ loss stats in its tail)."""
+        s = torch.cuda.current_stream().cuda_stream
+        L.check(L.lib.cr_step_begin(self.state.data_ptr(), s), "cr_step_begin")
+        self._run(self.fwd, s)
+        self._run(self.bwd, s)
+        self._run([self._reduce], s)
+
+    def launch_adam_from_flat(self):
+        """Adam on the (all-reduced) flat bucket; the global loss statistics come from its tail."""
+        self.state[:3].copy_(self.Gflat[self.layout.n_total:self.layout.n_total + 3])
+        self._run([self._adam_flat], torch.cuda.current_stream().cuda_stream)
+
+    def capture(self, dp=False):
         """Captures launch_step() into a HIP graph (inputs are read from the static id buffers)."""
         g = O.Graph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             g.begin()
-            self.launch_step()
+            if dp:
+                self.launch_backward_to_flat()
+            else:
+                self.launch_step()
             g.end()
         torch.cuda.current_stream().wait_stream(side)
         self.graph, self._graph_stream = g, side

@@ -5,6 +5,11 @@ module raises.  The structures below mirror include/castrec.h field by field."""
 import ctypes as C
 import os
 
+# torch first: it ships its own HIP runtime (libamdhip64).  Loading libcastrec.so before it would pull the
+# system ROCm copy into the process as a SECOND runtime, on which kernel launches fail with
+# "no ROCm-capable device is detected".  With torch loaded, the soname is already resolved and shared.
+import torch  # noqa: F401
+
 from . import PKG_DIR
 
 LIB_PATH = os.path.join(PKG_DIR, "libcastrec.so")
@@ -112,6 +117,7 @@ _sig("cr_attn_bwd", c_i, [C.POINTER(AttnBwdDesc), c_p])
 _sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
 _sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 _sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
+_sig("cr_reduce_slabs", c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p])
 _sig("cr_graph_begin", c_i, [c_p])
 _sig("cr_graph_end", c_i, [c_p, C.POINTER(c_p)])
 _sig("cr_graph_launch", c_i, [c_p, c_p])
@@ -122,7 +128,7 @@ _sig("cr_sampler_destroy", None, [c_p])
 
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
-           "cr_head_fwd_bwd", "cr_test_logits", "cr_adam_step", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
+           "cr_head_fwd_bwd", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]
 
 lib = _lib

@@ -234,6 +234,13 @@ typedef struct {
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 
+/* Data-parallel path: collapse the dense slabs into one flat vector that is all-reduced over RCCL
+ * together with the table gradient: out[i] = sum_s slabs[s*n_dense + i]; also copies the three loss
+ * statistics state[0..2] to stats_out (the tail of the all-reduce bucket).  cr_adam_step is then
+ * called with n_slabs = 1 on the reduced vector. */
+int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dense, float* out,
+                    const float* state, float* stats_out, void* stream);
+
 /* ---- HIP graph capture of a whole step (launch-bound inner loop) ---------------------- */
 int cr_graph_begin(void* stream);
 int cr_graph_end(void* stream, void** graph_exec_out);
