@@ -4,8 +4,10 @@
 // MFMA shape: v_mfma_f32_16x16x4_f32 (exact fp32).  Workgroup = 4 waves, 64x64 output tile, wave w
 // owns rows [16w,16w+16) x 64 columns (4 accumulators, the A fragment is reused by 4 MFMAs).
 // LDS pitches are chosen so the fragment reads (ds_read_b32, 32-lane groups) are conflict-free:
-//   A-pattern  (lanes vary ROW by li, k by lg):  pitch % 4 == 2           (34)
+//   A-pattern  (lanes vary ROW by li, k by lg):  pitch % 4 == 2           (66)
 //   B-pattern  (lanes vary COL by li, k by lg):  pitch % 32 == 16         (80)
+// A K-chunk is 64 deep (one pass for hidden sizes <= 64); the next chunk is prefetched into
+// registers while the MFMAs of the current one run.
 #include "cr_common.hpp"
 
 struct GemmBatch {
@@ -14,9 +16,10 @@ struct GemmBatch {
 
 #define G_BM 64
 #define G_BN 64
-#define G_KC 32
-#define G_PA 34
-#define G_PB 80
+#define G_KC 64
+#define G_PA 66      // A-pattern pitch (% 4 == 2)
+#define G_PB 80      // B-pattern pitch (% 32 == 16)
+#define G_NLD ((G_BM * G_KC) / 256)   // elements per thread per staged tile (16)
 
 __global__ __launch_bounds__(256) void k_gemm_rows(GemmBatch batch) {
     const cr_gemm_desc& d = batch.p[blockIdx.y];
@@ -25,46 +28,51 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmBatch batch) {
     if ((int)blockIdx.x >= ntiles * mtiles) return;
     const int m0 = ((int)blockIdx.x / ntiles) * G_BM, n0 = ((int)blockIdx.x % ntiles) * G_BN;
     __shared__ float As[G_BM * G_PA];
-    __shared__ float Bs[G_KC * G_PB];   // trans_b: used as Bt[64][G_PA] (64*34 = 2176 <= 2560)
+    __shared__ float Bs[G_KC * G_PB];   // trans_b: used as Bt[64][G_PA] (64*66 = 4224 <= 5120)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
+    const int tr = tid >> 6, tc = tid & 63;     // staging coordinates: 4 rows x 64 columns per pass
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ra[G_NLD], rb[G_NLD];
 
+    // global -> registers for the K-chunk starting at k0 (issued back to back: 32 loads in flight)
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < G_NLD; ++i) {
+            const int r = tr + 4 * i;           // tile row (A: m, B: k or n)
+            const int gm = m0 + r, gk = k0 + tc;
+            ra[i] = (gm < d.M && gk < d.K) ? d.A[(size_t)gm * d.lda + gk] : 0.0f;
+            if (!d.trans_b) {                   // B[k0 + r][n0 + tc]
+                const int bk = k0 + r, bn = n0 + tc;
+                rb[i] = (bk < d.K && bn < d.N) ? d.B[(size_t)bk * d.ldb + bn] : 0.0f;
+            } else {                            // B[n0 + r][k0 + tc]
+                const int bn = n0 + r, bk = k0 + tc;
+                rb[i] = (bk < d.K && bn < d.N) ? d.B[(size_t)bn * d.ldb + bk] : 0.0f;
+            }
+        }
+    };
+    load_chunk(0);
     for (int k0 = 0; k0 < d.K; k0 += G_KC) {
 #pragma unroll
-        for (int i = 0; i < (G_BM * G_KC) / 256; ++i) {
-            const int e = tid + 256 * i, r = e / G_KC, c = e % G_KC;
-            const int gm = m0 + r, gk = k0 + c;
-            As[r * G_PA + c] = (gm < d.M && gk < d.K) ? d.A[(size_t)gm * d.lda + gk] : 0.0f;
-        }
-        if (!d.trans_b) {
-#pragma unroll
-            for (int i = 0; i < (G_KC * G_BN) / 256; ++i) {
-                const int e = tid + 256 * i, kk = e / G_BN, nn = e % G_BN;
-                const int gk = k0 + kk, gn = n0 + nn;
-                Bs[kk * G_PB + nn] = (gk < d.K && gn < d.N) ? d.B[(size_t)gk * d.ldb + gn] : 0.0f;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < (G_KC * G_BN) / 256; ++i) {
-                const int e = tid + 256 * i, nn = e / G_KC, kk = e % G_KC;
-                const int gk = k0 + kk, gn = n0 + nn;
-                Bs[nn * G_PA + kk] = (gk < d.K && gn < d.N) ? d.B[(size_t)gn * d.ldb + gk] : 0.0f;
-            }
+        for (int i = 0; i < G_NLD; ++i) {
+            const int r = tr + 4 * i;
+            As[r * G_PA + tc] = ra[i];
+            if (!d.trans_b) Bs[r * G_PB + tc] = rb[i];
+            else Bs[r * G_PA + tc] = rb[i];
         }
         __syncthreads();
+        if (k0 + G_KC < d.K) load_chunk(k0 + G_KC);      // prefetch under the MFMAs
+        const int ksteps = min(G_KC, d.K - k0);
         if (!d.trans_b) {
-#pragma unroll
-            for (int kk = 0; kk < G_KC; kk += 4) {
+            for (int kk = 0; kk < ksteps; kk += 4) {
                 const float a = As[(16 * wave + li) * G_PA + kk + lg];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = mfma16(a, Bs[(kk + lg) * G_PB + 16 * j + li], acc[j]);
             }
         } else {
-#pragma unroll
-            for (int kk = 0; kk < G_KC; kk += 4) {
+            for (int kk = 0; kk < ksteps; kk += 4) {
                 const float a = As[(16 * wave + li) * G_PA + kk + lg];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = mfma16(a, Bs[(16 * j + li) * G_PA + kk + lg], acc[j]);
@@ -123,6 +131,7 @@ struct WgradBatch {
 };
 
 #define W_MC 32
+#define W_NLD ((W_MC * 64) / 256)     // 8 elements per thread per staged tile
 
 __global__ __launch_bounds__(256) void k_gemm_wgrad(WgradBatch batch) {
     int bx = blockIdx.x, pi = 0;
@@ -142,19 +151,29 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(WgradBatch batch) {
     __shared__ float Gs[W_MC * G_PB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
+    const int tr = tid >> 6, tc = tid & 63;
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
+    float ra[W_NLD], rg[W_NLD];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < W_NLD; ++i) {
+            const int gm = mc + tr + 4 * i;
+            ra[i] = (gm < me && k0 + tc < d.K) ? d.A[(size_t)gm * d.lda + k0 + tc] : 0.0f;
+            rg[i] = (gm < me && n0 + tc < d.N) ? d.G[(size_t)gm * d.ldg + n0 + tc] : 0.0f;
+        }
+    };
+    if (mb < me) load_chunk(mb);
     for (int mc = mb; mc < me; mc += W_MC) {
 #pragma unroll
-        for (int i = 0; i < (W_MC * 64) / 256; ++i) {
-            const int e = tid + 256 * i, mm = e / 64, cc = e % 64;
-            const int gm = mc + mm;
-            As[mm * G_PB + cc] = (gm < me && k0 + cc < d.K) ? d.A[(size_t)gm * d.lda + k0 + cc] : 0.0f;
-            Gs[mm * G_PB + cc] = (gm < me && n0 + cc < d.N) ? d.G[(size_t)gm * d.ldg + n0 + cc] : 0.0f;
+        for (int i = 0; i < W_NLD; ++i) {
+            As[(tr + 4 * i) * G_PB + tc] = ra[i];
+            Gs[(tr + 4 * i) * G_PB + tc] = rg[i];
         }
         __syncthreads();
+        if (mc + W_MC < me) load_chunk(mc + W_MC);       // prefetch under the MFMAs
 #pragma unroll
         for (int mm = 0; mm < W_MC; mm += 4) {
             const float a = As[(mm + lg) * G_PB + 16 * wave + li];

@@ -1,95 +1,117 @@
 // Layer normalisation (modules.py:53-80 `normalize`) forward / backward.
-// One wavefront per row; row statistics by 64-lane xor-shuffle reductions.
+// Rows are reduced by xor-shuffles.  For the small hidden sizes of this model family (D <= 64) a
+// 64-lane wave would idle on most lanes and serialise on the row's dependent reduction chain, so a
+// row gets LPR = 16 lanes and a wave works on 4 rows at once; D > 64 uses one wave per row.
 #include "cr_common.hpp"
 
-#define LN_MAXC 8   // columns per lane: D <= 512
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
+template <int LPR, int MAXC>
 __global__ __launch_bounds__(256) void k_ln_fwd(cr_ln_desc d) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= d.M) return;
-    float x[LN_MAXC];
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    const int m = (blockIdx.x * 4 + wave) * RPW + sub;
+    const bool act = m < d.M;
+    const int mm = act ? m : d.M - 1;
+    float x[MAXC];
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        const int c = lane + 64 * i;
-        x[i] = (c < d.D) ? d.x[(size_t)m * d.ldx + c] : 0.0f;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = l + LPR * i;
+        x[i] = (c < d.D) ? d.x[(size_t)mm * d.ldx + c] : 0.0f;
         s += x[i];
     }
-    s = wave_sum(s);
+    s = row_sum<LPR>(s);
     const float mean = s / (float)d.D;
     float v = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = l + LPR * i;
         const float dx = (c < d.D) ? (x[i] - mean) : 0.0f;
         v += dx * dx;
     }
-    v = wave_sum(v) / (float)d.D;
+    v = row_sum<LPR>(v) / (float)d.D;
     const float sd = sqrtf(v + d.eps);
     float ys = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = l + LPR * i;
         if (c < d.D) {
             const float y = d.gamma[c] * ((x[i] - mean) / sd) + d.beta[c];
-            d.y[(size_t)m * d.ldy + c] = y;
+            if (act) d.y[(size_t)m * d.ldy + c] = y;
             ys += y;
         }
     }
-    if (d.y_nonzero) {
-        ys = wave_sum(ys);
-        if (lane == 0) d.y_nonzero[m] = (ys != 0.0f) ? 1.0f : 0.0f;
+    ys = row_sum<LPR>(ys);
+    if (act && l == 0) {
+        if (d.y_nonzero) d.y_nonzero[m] = (ys != 0.0f) ? 1.0f : 0.0f;
+        if (d.x_nonzero) d.x_nonzero[m] = (s != 0.0f) ? 1.0f : 0.0f;
     }
-    if (d.x_nonzero && lane == 0) d.x_nonzero[m] = (s != 0.0f) ? 1.0f : 0.0f;
 }
 
 extern "C" int cr_layernorm_fwd(const cr_ln_desc* d, void* stream) {
     CR_REQUIRE(d && d->x && d->y && d->gamma && d->beta, "cr_layernorm_fwd: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->D > 0 && d->ldx >= d->D && d->ldy >= d->D, "cr_layernorm_fwd: bad shape");
-    if (d->D > 64 * LN_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_layernorm_fwd: D=%d > %d", d->D, 64 * LN_MAXC);
-    hipLaunchKernelGGL(k_ln_fwd, dim3(cr_ceil_div(d->M, 4)), dim3(256), 0, cr_stream(stream), *d);
+    if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_layernorm_fwd: D=%d > 512", d->D);
+    if (d->D <= 64)
+        hipLaunchKernelGGL((k_ln_fwd<16, 4>), dim3(cr_ceil_div(d->M, 16)), dim3(256), 0, cr_stream(stream), *d);
+    else
+        hipLaunchKernelGGL((k_ln_fwd<64, 8>), dim3(cr_ceil_div(d->M, 4)), dim3(256), 0, cr_stream(stream), *d);
     return cr_check_launch("cr_layernorm_fwd");
 }
 
-// Backward.  n_slabs persistent workgroups; workgroup s owns rows [s*rps, (s+1)*rps) and writes
-// its partial dgamma / dbeta into slab s (reduced later by cr_adam_step) -- no atomics.
-__global__ __launch_bounds__(256) void k_ln_bwd(cr_ln_bwd_desc d) {
-    __shared__ float red[2][4][64 * LN_MAXC];
+// Backward.  n_slabs workgroups of 16 waves; workgroup s owns rows [s*rps, (s+1)*rps) and writes its
+// partial dgamma / dbeta into slab s (summed later by cr_adam_step) -- no global atomics.
+template <int LPR, int MAXC>
+__global__ __launch_bounds__(1024) void k_ln_bwd(cr_ln_bwd_desc d) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float sg[512], sb[512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    for (int c = threadIdx.x; c < d.D; c += 1024) { sg[c] = 0.0f; sb[c] = 0.0f; }
+    __syncthreads();
     const int rps = (d.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
-    float g[LN_MAXC], ag[LN_MAXC], ab[LN_MAXC];
+    float g[MAXC], ag[MAXC], ab[MAXC];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = l + LPR * i;
         g[i] = (c < d.D) ? d.gamma[c] : 0.0f;
         ag[i] = 0.0f; ab[i] = 0.0f;
     }
     const float invD = 1.0f / (float)d.D;
-    for (int m = m0 + wave; m < m1; m += 4) {
-        float x[LN_MAXC], dy[LN_MAXC];
+    for (int mb = m0 + wave * RPW; mb < m1; mb += 16 * RPW) {
+        const int m = mb + sub;
+        const bool act = m < m1;
+        const int mm = act ? m : m0;
+        float x[MAXC], dy[MAXC];
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            x[i] = (c < d.D) ? d.x[(size_t)m * d.ldx + c] : 0.0f;
-            dy[i] = (c < d.D) ? d.dy[(size_t)m * d.lddy + c] : 0.0f;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
+            x[i] = (c < d.D) ? d.x[(size_t)mm * d.ldx + c] : 0.0f;
+            dy[i] = (c < d.D && act) ? d.dy[(size_t)mm * d.lddy + c] : 0.0f;
             s += x[i];
         }
-        const float mean = wave_sum(s) * invD;
+        const float mean = row_sum<LPR>(s) * invD;
         float v = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
             const float dx = (c < d.D) ? (x[i] - mean) : 0.0f;
             v += dx * dx;
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(v) * invD + d.eps);
+        const float rstd = 1.0f / sqrtf(row_sum<LPR>(v) * invD + d.eps);
         float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
             const float xh = (c < d.D) ? (x[i] - mean) * rstd : 0.0f;
             x[i] = xh;
             const float dg = dy[i] * g[i];
@@ -98,34 +120,48 @@ __global__ __launch_bounds__(256) void k_ln_bwd(cr_ln_bwd_desc d) {
             ag[i] += dy[i] * xh;
             ab[i] += dy[i];
         }
-        c1 = wave_sum(c1) * invD;
-        c2 = wave_sum(c2) * invD;
+        c1 = row_sum<LPR>(c1) * invD;
+        c2 = row_sum<LPR>(c2) * invD;
+        if (act) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d.D) {
-                const float dx = rstd * (dy[i] * g[i] - c1 - x[i] * c2);
-                float* p = d.dx + (size_t)m * d.lddx + c;
-                *p = d.accumulate ? (*p + dx) : dx;
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = l + LPR * i;
+                if (c < d.D) {
+                    const float dx = rstd * (dy[i] * g[i] - c1 - x[i] * c2);
+                    float* p = d.dx + (size_t)m * d.lddx + c;
+                    *p = d.accumulate ? (*p + dx) : dx;
+                }
             }
         }
     }
+    // fold the RPW row groups of the wave, then the 16 waves through LDS float atomics
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        red[0][wave][lane + 64 * i] = ag[i];
-        red[1][wave][lane + 64 * i] = ab[i];
+    for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            ag[i] += __shfl_xor(ag[i], o, 64);
+            ab[i] += __shfl_xor(ab[i], o, 64);
+        }
+        const int c = l + LPR * i;
+        if (sub == 0 && c < d.D) {
+            atomicAdd(&sg[c], ag[i]);
+            atomicAdd(&sb[c], ab[i]);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < d.D; c += 256) {
-        d.dgamma[(size_t)blockIdx.x * d.slab_stride + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        d.dbeta[(size_t)blockIdx.x * d.slab_stride + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    for (int c = threadIdx.x; c < d.D; c += 1024) {
+        d.dgamma[(size_t)blockIdx.x * d.slab_stride + c] = sg[c];
+        d.dbeta[(size_t)blockIdx.x * d.slab_stride + c] = sb[c];
     }
 }
 
 extern "C" int cr_layernorm_bwd(const cr_ln_bwd_desc* d, void* stream) {
     CR_REQUIRE(d && d->x && d->gamma && d->dy && d->dx && d->dgamma && d->dbeta, "cr_layernorm_bwd: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->D > 0 && d->n_slabs > 0, "cr_layernorm_bwd: bad shape");
-    if (d->D > 64 * LN_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_layernorm_bwd: D=%d > %d", d->D, 64 * LN_MAXC);
-    hipLaunchKernelGGL(k_ln_bwd, dim3(d->n_slabs), dim3(256), 0, cr_stream(stream), *d);
+    if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_layernorm_bwd: D=%d > 512", d->D);
+    if (d->D <= 64)
+        hipLaunchKernelGGL((k_ln_bwd<16, 4>), dim3(d->n_slabs), dim3(1024), 0, cr_stream(stream), *d);
+    else
+        hipLaunchKernelGGL((k_ln_bwd<64, 8>), dim3(d->n_slabs), dim3(1024), 0, cr_stream(stream), *d);
     return cr_check_launch("cr_layernorm_bwd");
 }

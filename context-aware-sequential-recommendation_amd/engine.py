@@ -160,7 +160,7 @@ class ParamLayout:
 
 # ---------------------------------------------------------------------------------------------------
 class Engine:
-    def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=64,
+    def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=256,
                  share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda"):
         if model not in MODELS:
             raise ValueError("model must be one of %s" % MODELS)
