@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcastrec.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
-           "cr_attn.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
+           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -34,7 +34,7 @@ def _stale(obj, srcs):
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(ROOT, "include", "castrec.h")]
+    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(ROOT, "include", "castrec.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -1,0 +1,290 @@
+// Attention backward (gradient of modules.py:208-269); see cr_attn_common.hpp for the design.
+//   pass 1 (query-owner): dQ + per-row statistics (max, 1/sum, delta, flag) for pass 2
+//   pass 2 (key-owner):   dK, dV of the wave's 16 keys, summed over queries in registers
+// Two passes recompute the scores in the orientation each one needs (7 MFMA products instead of the
+// textbook 5) but need no LDS transposes, no cross-wave reductions and no atomics: bitwise reproducible.
+#include "cr_attn_common.hpp"
+
+// flag: 0 = normal row, 1 = uniform row with a non-zero incoming gradient, 2 = contributes nothing.
+template <int NKT, int NDS, int NDT>
+__global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_desc bd, AttnGeom g) {
+    const cr_attn_desc& d = bd.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* Ks = smem;                                   // [T16][PA]  A-pattern (scores) and B-pattern (dQ) reads
+    float* Vs = Ks + g.T16 * g.PA + A_TAIL;             // [T16][PA]  A-pattern reads (dP^T)
+    float* Qs = Vs + g.T16 * g.PA;                      // [nw][16][PA]: slot for the Q tile, then the dOut tile
+    float* kv = Qs + nw * 16 * g.PA;
+    float* qv = kv + g.T16;
+    float* dead = qv + g.T16;
+    const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
+    const int base_row = n * d.T, hoff = head * d.d;
+    const int T = d.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_rows(Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+        kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
+        qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
+        dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    const uint64_t kbits = key_bits<NKT>(kv, T);
+    const DropCtx dc = drop_ctx(d.drop);
+    float* Qw = Qs + wave * 16 * g.PA;
+    const int nwaves = gridDim.y * nw;
+    for (int qi = wave * gridDim.y + blockIdx.y; qi < g.nkt; qi += nwaves) {   // interleaved: every workgroup gets heavy and light tiles
+        const int qt = g.nkt - 1 - qi;
+        const int q0 = 16 * qt, q = q0 + li;
+        const bool is_dead = dead[q] != 0.0f;
+        if (__all(is_dead ? 1 : 0)) {                  // whole tile dead: dQ = 0, flag 2
+            for (int rr = 0; rr < 16; ++rr) {
+                const int qq = q0 + rr;
+                if (qq < T && lane < d.d) bd.dQ[(size_t)(base_row + qq) * bd.ldg + hoff + lane] = 0.0f;
+            }
+            if (lg == 0 && q < T) {
+                float* sp = bd.stats + ((size_t)blockIdx.x * T + q) * 4;
+                sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 0.0f; sp[3] = 2.0f;
+            }
+            continue;
+        }
+        float qf[NDS], dof[NDS];
+        stage_rows(Qw, g.PA, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
+        load_frag<NDS>(Qw, g.PA, qf);
+        stage_rows(Qw, g.PA, bd.dout, bd.lddo, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
+        load_frag<NDS>(Qw, g.PA, dof);
+        float nz = 0.0f;                               // does this query's incoming gradient row vanish?
+#pragma unroll
+        for (int s = 0; s < NDS; ++s)
+            if (dof[s] != 0.0f) nz = 1.0f;
+        nz = grp_max(nz);
+        f32x4 st[NKT];
+        float m2, inv;
+        bool uniform;
+        score_rows<NKT, NDS>(g, Ks, qf, kbits, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        const float qvq = qv[q];
+        const bool live = !uniform && !is_dead && (q < T);
+        const float wq = live ? qvq : 0.0f;
+        const uint32_t ridx = attn_row_idx(d, head, n, q);
+        // dP^T[key][q] = V dO^T, then softmax backward (delta = sum_k dPsm * Psm)
+        f32x4 dps[NKT];
+        float delta = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kt <= qt) {
+                acc = mma_tile_frag<NDS>(Vs + 16 * kt * g.PA, g.PA, dof);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float psm = st[kt][r];
+                    float w = wq;                                             // query mask (* dropout keep / (1-rate))
+                    if (dc.on) w *= drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
+                    const float dpsm = acc[r] * w;
+                    delta += dpsm * psm;
+                    acc[r] = dpsm;
+                }
+            }
+            dps[kt] = acc;
+        }
+        delta = grp_sum(delta);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st[kt][r] = live ? st[kt][r] * (dps[kt][r] - delta) * g.isd : 0.0f;   // dS / sqrt(d)
+        }
+        // dQ[q][dim] = sum_key dS[q][key] K[key][dim]
+        f32x4 acc[NDT];
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma_prob_rows<NKT, NDT>(st, Ks, g.PA, qt + 1, acc);
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + 4 * lg + r, c = 16 * jt + li;
+                if (qq < T && c < d.d) bd.dQ[(size_t)(base_row + qq) * bd.ldg + hoff + c] = acc[jt][r];
+            }
+        }
+        if (lg == 0 && q < T) {
+            float* sp = bd.stats + ((size_t)blockIdx.x * T + q) * 4;
+            float flag = 0.0f;
+            if (is_dead || (uniform && nz == 0.0f)) flag = 2.0f;
+            else if (uniform) flag = 1.0f;
+            sp[0] = m2; sp[1] = inv; sp[2] = delta; sp[3] = flag;
+        }
+    }
+}
+
+template <int NDS, int NDT>
+__global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_desc bd, AttnGeom g) {
+    const cr_attn_desc& d = bd.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* Qs = smem;                                   // [T16][PA]  A- and B-pattern reads
+    float* Os = Qs + g.T16 * g.PA + A_TAIL;             // [T16][PA]  dOut
+    float* KVs = Os + g.T16 * g.PA + A_TAIL;            // [nw][16][PA]: slot for the wave's K tile, then its V tile
+    float* smx = KVs + nw * 16 * g.PA;                  // [T16] each
+    float* sinv = smx + g.T16;
+    float* sdel = sinv + g.T16;
+    float* sflag = sdel + g.T16;
+    float* qv = sflag + g.T16;
+    float* tile_uni = qv + g.T16;                       // [nkt]: tile holds a flag==1 row
+    float* tile_live = tile_uni + g.nkt;                // [nkt]: tile holds a row with flag != 2
+    const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
+    const int base_row = n * d.T, hoff = head * d.d;
+    const int T = d.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    stage_rows(Qs, g.PA, d.Q, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_rows(Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16, wave, nw);
+    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+        const float* sp = bd.stats + ((size_t)blockIdx.x * T + (t < T ? t : 0)) * 4;
+        smx[t] = (t < T) ? sp[0] : 0.0f;
+        sinv[t] = (t < T) ? sp[1] : 0.0f;
+        sdel[t] = (t < T) ? sp[2] : 0.0f;
+        sflag[t] = (t < T) ? sp[3] : 2.0f;
+        qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.nkt; t += blockDim.x) {
+        float u = 0.0f, lv = 0.0f;
+        for (int i = 0; i < 16; ++i) {
+            if (sflag[16 * t + i] == 1.0f) u = 1.0f;
+            if (sflag[16 * t + i] != 2.0f) lv = 1.0f;
+        }
+        tile_uni[t] = u;
+        tile_live[t] = lv;
+    }
+    __syncthreads();
+    const DropCtx dc = drop_ctx(d.drop);
+    float* Kw = KVs + wave * 16 * g.PA;
+    const int nwaves = gridDim.y * nw;
+    for (int kt = wave * gridDim.y + blockIdx.y; kt < g.nkt; kt += nwaves) {
+        const int key = 16 * kt + li;
+        float kf[NDS], vf[NDS];
+        stage_rows(Kw, g.PA, d.K, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, 16, 0, 1);
+        load_frag<NDS>(Kw, g.PA, kf);
+        stage_rows(Kw, g.PA, d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, 16, 0, 1);
+        load_frag<NDS>(Kw, g.PA, vf);
+        const bool kvk = (key < T) && (d.k_valid[base_row + (key < T ? key : 0)] != 0.0f);
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) {
+            dk[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int qt = 0; qt < g.nkt; ++qt) {
+            if (tile_live[qt] == 0.0f) continue;                          // nothing flows through dead query tiles
+            if (qt < kt && tile_uni[qt] == 0.0f) continue;                // causal skip (uniform rows see all keys)
+            const f32x4 s_acc = mma_tile_frag<NDS>(Qs + 16 * qt * g.PA, g.PA, kf);   // S[q][key]
+            const f32x4 p_acc = mma_tile_frag<NDS>(Os + 16 * qt * g.PA, g.PA, vf);   // dP[q][key]
+            float pa[4], pd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * lg + r;
+                const float flag = sflag[q];
+                float psm = 0.0f;
+                if (flag == 0.0f) {
+                    const bool valid = (key <= q) && kvk;
+                    psm = valid ? __builtin_amdgcn_exp2f(s_acc[r] * g.isd_log2e - smx[q]) * sinv[q] : 0.0f;
+                } else if (flag == 1.0f) {
+                    psm = (key < T) ? g.invT : 0.0f;
+                }
+                float w = qv[q];
+                if (dc.on) w *= drop_factor(dc, attn_row_idx(d, head, n, q) + (uint32_t)key);
+                pa[r] = psm * w;                                                          // A after mask+dropout
+                pd[r] = (flag == 0.0f) ? psm * (p_acc[r] * w - sdel[q]) * g.isd : 0.0f;   // dS / sqrt(d)
+            }
+            const float* op = Os + (16 * qt + 4 * lg) * g.PA + li;
+            const float* qp = Qs + (16 * qt + 4 * lg) * g.PA + li;
+            float bo[4][NDT], bq[4][NDT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < NDT; ++jt) {
+                    bo[r][jt] = op[r * g.PA + 16 * jt];
+                    bq[r][jt] = qp[r * g.PA + 16 * jt];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < NDT; ++jt) {
+                    dv[jt] = mfma16(pa[r], bo[r][jt], dv[jt]);
+                    dk[jt] = mfma16(pd[r], bq[r][jt], dk[jt]);
+                }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * kt + 4 * lg + r, c = 16 * jt + li;
+                if (kk < T && c < d.d) {
+                    bd.dK[(size_t)(base_row + kk) * bd.ldg + hoff + c] = dk[jt][r];
+                    bd.dV[(size_t)(base_row + kk) * bd.ldg + hoff + c] = dv[jt][r];
+                }
+            }
+        }
+    }
+}
+
+static size_t lds_bwd_q(const AttnGeom& g, int w) {
+    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + A_TAIL + (size_t)w * 16 * g.PA + 3 * g.T16);
+}
+static size_t lds_bwd_kv(const AttnGeom& g, int w) {
+    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + 2 * A_TAIL + (size_t)w * 16 * g.PA + 5 * g.T16 + 2 * g.nkt);
+}
+
+template <int NKT, int NDS, int NDT>
+static int launch_bwd_q(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_bwd_q<NKT, NDS, NDT>));
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_attn_bwd_q<NKT, NDS, NDT>), dim3(bd->f.B * bd->f.H, attn_nsplit(&bd->f, g, waves)), dim3(64 * waves),
+                       lds_bwd_q(g, waves), s, *bd, g);
+    return cr_check_launch("cr_attn_bwd(q)");
+}
+
+template <int NKT>
+static int dispatch_bwd_q(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, hipStream_t s) {
+    if (g.nds == 8) return launch_bwd_q<NKT, 8, 2>(bd, g, waves, s);
+    if (g.nds == 13) return launch_bwd_q<NKT, 13, 4>(bd, g, waves, s);
+    return launch_bwd_q<NKT, 16, 4>(bd, g, waves, s);
+}
+
+template <int NDS, int NDT>
+static int launch_bwd_kv(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_bwd_kv<NDS, NDT>));
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_attn_bwd_kv<NDS, NDT>), dim3(bd->f.B * bd->f.H, attn_nsplit(&bd->f, g, waves)), dim3(64 * waves),
+                       lds_bwd_kv(g, waves), s, *bd, g);
+    return cr_check_launch("cr_attn_bwd(kv)");
+}
+
+extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
+    CR_REQUIRE(bd != nullptr, "cr_attn_bwd: NULL desc");
+    const cr_attn_desc* d = &bd->f;
+    AttnGeom g;
+    int rc = attn_geom(d, &g, "cr_attn_bwd");
+    if (rc) return rc;
+    CR_REQUIRE(bd->dout && bd->dQ && bd->dK && bd->dV && bd->stats, "cr_attn_bwd: NULL pointer");
+    const int wq = attn_pick_waves(g, lds_bwd_q), wkv = attn_pick_waves(g, lds_bwd_kv);
+    if (!wq || !wkv)
+        return cr_set_error(CR_ERR_UNSUPPORTED, "cr_attn_bwd: T=%d d=%d needs %zu B of LDS", d->T, d->d, lds_bwd_kv(g, 1));
+    hipStream_t s = cr_stream(stream);
+    const int nkt = attn_pick_nkt(g.nkt);
+    if (nkt == 4) rc = dispatch_bwd_q<4>(bd, g, wq, s);
+    else if (nkt == 13) rc = dispatch_bwd_q<13>(bd, g, wq, s);
+    else rc = dispatch_bwd_q<16>(bd, g, wq, s);
+    if (rc) return rc;
+    if (g.nds == 8) return launch_bwd_kv<8, 2>(bd, g, wkv, s);
+    if (g.nds == 13) return launch_bwd_kv<13, 4>(bd, g, wkv, s);
+    return launch_bwd_kv<16, 4>(bd, g, wkv, s);
+}

@@ -1,0 +1,251 @@
+// Shared pieces of the attention kernels (cr_attn_fwd.hip, cr_attn_bwd.hip).
+//
+// Causal multi-head self-attention core of modules.py:208-269 (scores, key / causal / query masks,
+// softmax, dropout, weighted sum, residual); scores never leave the chip.
+//
+// Work decomposition: grid = (H*B, nsplit); a workgroup (up to 8 waves) stages the K and V rows of ONE
+// (head, sample) in LDS; each wave owns 16-query tiles and keeps the whole score row block
+// (NKT key tiles x 4 registers) in VGPRs, so softmax is a register + 2-shuffle reduction.
+//
+// MFMA trick (v_mfma_f32_16x16x4_f32): scores are computed TRANSPOSED, St[key][query] = K Q^T, so a
+// lane holds, for ITS query (lane & 15), keys {16*kt + 4*(lane>>4) + r}.  That accumulator layout is
+// exactly the A-operand layout of the next product (P V, dS K) when the k-dimension of MFMA step r
+// is taken as key 4*lg + r -- no LDS round trip, no cross-lane movement between the two GEMMs.
+// The key-owner backward kernel uses the mirrored form (S[query][key]) for dK / dV.
+//
+// Code shape (second rewrite, see DESIGN.md "attention"): NKT (key tiles) and NDS (head-dim k-steps of
+// 4) are template parameters so every MFMA group is preceded by ONE batch of LDS operand reads (the
+// per-MFMA read->wait->issue pattern of the first versions exposed the LDS latency 200 times per tile)
+// and the per-wave Q / dOut / K / V fragments live in registers.
+//
+// Exactness notes (tests/test_ops_gpu.py): masked entries are -2^32+1 in the reference, so
+//  * a row with >= 1 valid key: masked probabilities are exactly 0;
+//  * a row with NO valid key ("uniform"): probability 1/T on ALL T keys, future ones included
+//    (modules.py:227-244) -- handled explicitly, contributes to out and to dV, no score gradient.
+#pragma once
+#include <math.h>
+
+#include "cr_common.hpp"
+
+#define A_MAX_WAVES 8        // two waves per SIMD hide each other's LDS / MFMA latencies
+#define A_TAIL 64            // floats of slack after a B-pattern-read LDS array (reads of padded columns)
+
+struct AttnGeom {
+    int T16, nkt;            // padded T, number of 16-tiles
+    int nds, ndt;            // template values in use: k-steps (pitch = 4*nds + 2), 16-column output tiles
+    int PA, PB;              // LDS pitches: 4*nds+2 (A-pattern, % 4 == 2); B-pattern (% 8 == 4)
+    float isd;               // 1/sqrt(d)   (modules.py:219)
+    float isd_log2e;         // isd * log2(e): softmax exponent in base 2 (v_exp_f32)
+    float invT;
+};
+
+__device__ __forceinline__ float grp_max(float v) {   // over the 4 lanes that share (lane & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// dropout element index of attention_weights[(j*Bglobal + n), q, 0]
+__device__ __forceinline__ uint32_t attn_row_idx(const cr_attn_desc& d, int head, int n, int q) {
+    const uint32_t ng = d.drop.row_offset / (uint32_t)d.T + (uint32_t)n;
+    return (((uint32_t)head * (uint32_t)d.batch_global + ng) * (uint32_t)d.T + (uint32_t)q) * (uint32_t)d.T;
+}
+
+// branch-free dropout factor: keep ? scale : 0  (all lanes hash; no divergent control flow)
+__device__ __forceinline__ float drop_factor(const DropCtx& c, uint32_t idx) {
+    const uint32_t h = cr_fmix32(idx * 0x9E3779B1u + c.key);
+    return (h >= c.thresh) ? c.scale : 0.0f;
+}
+
+// D[i][j] = sum_k A[i][k] * frag[k][j]: A = 16-row LDS tile read in the A-pattern (row li, column 4s+lg),
+// the other operand is a register fragment (lane holds element [4s+lg] of ITS row li).  The NDS reads
+// are issued as one batch ahead of the MFMA chain.
+template <int NDS>
+__device__ __forceinline__ f32x4 mma_tile_frag(const float* a_tile, int pa, const float (&frag)[NDS]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const float* ap = a_tile + li * pa + lg;
+    float a[NDS];
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) a[s] = ap[4 * s];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) acc = mfma16(a[s], frag[s], acc);
+    return acc;
+}
+
+// register fragment of a 16-row LDS tile: element s = tile[li][4s + lg]
+template <int NDS>
+__device__ __forceinline__ void load_frag(const float* tile, int pa, float (&frag)[NDS]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) frag[s] = tile[li * pa + 4 * s + lg];
+}
+
+// stage rows [0,nrows_valid) x [hoff, hoff+d) of a [M, ld] matrix into LDS with pitch P <= 68; everything
+// outside (rows >= nrows_valid, columns >= d up to the pitch) is zero so padded k-steps contribute 0.
+// A wave copies one row per pass (coalesced 4*d-byte segments), 8 rows in flight.
+__device__ __forceinline__ void stage_rows(float* dst, int P, const float* src, int ld, int row0, int hoff,
+                                           int nrows_valid, int d, int nrows, int tr, int nw) {
+    const int tc = threadIdx.x & 63;
+    constexpr int U = 8;
+    for (int t0 = tr; t0 < nrows; t0 += nw * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + nw * u;
+            v[u] = (t < nrows_valid && tc < d) ? src[(size_t)(row0 + t) * ld + hoff + tc] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + nw * u;
+            if (t < nrows) {
+                if (tc < P) dst[t * P + tc] = v[u];
+                if (tc + 64 < P) dst[t * P + tc + 64] = 0.0f;   // d <= 64: always padding
+            }
+        }
+    }
+}
+
+// per-lane key-validity bits: bit (4*kt + r) <=> key 16*kt + 4*lg + r is a valid key (< T, k_valid != 0)
+template <int NKT>
+__device__ __forceinline__ uint64_t key_bits(const float* kv, int T) {
+    const int lg = (threadIdx.x & 63) >> 4;
+    uint64_t bits = 0;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * lg + r;
+            if (key < T && kv[key] != 0.0f) bits |= (1ull << (4 * kt + r));
+        }
+    }
+    return bits;
+}
+
+// Score row block of one 16-query tile.  On return st[kt][r] = SOFTMAX probability (before query mask /
+// dropout) of key 16*kt + 4*lg + r for query q0 + li; m2 = row max in base-2 exponent units,
+// inv = 1/sum; `uniform` marks rows with no valid key.
+template <int NKT, int NDS>
+__device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, const float (&qf)[NDS], uint64_t kbits,
+                                           int qt, int T, bool is_dead, bool q_in_range, f32x4 (&st)[NKT], float& m2,
+                                           float& inv, bool& uniform) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    float mx = -INFINITY;
+    const float c2 = is_dead ? 0.0f : g.isd_log2e;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x4 acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (kt <= qt) {                                                          // wave-uniform
+            acc = mma_tile_frag<NDS>(Ks + 16 * kt * g.PA, g.PA, qf);             // St tile (modules.py:216)
+            const bool below_diag = kt < qt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = (((kbits >> (4 * kt + r)) & 1ull) != 0) && !is_dead &&
+                                   (below_diag || (4 * lg + r <= li));           // key mask + causal (modules.py:222-241)
+                const float sv = valid ? acc[r] * c2 : -INFINITY;               // scale (modules.py:219), base 2
+                acc[r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        st[kt] = acc;
+    }
+    mx = grp_max(mx);
+    uniform = (mx == -INFINITY) && !is_dead && q_in_range;
+    const float off = (mx == -INFINITY) ? 0.0f : mx;
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt <= qt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[kt][r] - off);   // v_exp_f32; exp2(-inf) = 0 for masked entries
+                st[kt][r] = p;
+                sum += p;
+            }
+        } else {
+            st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    sum = grp_sum(sum);
+    inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+    m2 = mx;
+    const float uni = uniform ? g.invT : 0.0f;                                   // modules.py:227-244
+    const float sc = uniform ? 0.0f : inv;                                       // modules.py:244
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u = (16 * kt + 4 * lg + r < T) ? uni : 0.0f;
+            st[kt][r] = st[kt][r] * sc + u;
+        }
+    }
+}
+
+// out[q][16 cols] tiles: acc[jt] += sum over keys of st[kt][r] * Bs[key][16*jt + li]  (B-pattern reads,
+// one batch of 4*NDT operands per key tile ahead of its 4*NDT MFMAs)
+template <int NKT, int NDT>
+__device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const float* Bs, int pb, int kt_end, f32x4 (&acc)[NDT]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const float* bp = Bs + (4 * lg) * pb + li;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < kt_end) {
+            float b[4][NDT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < NDT; ++jt) b[r][jt] = bp[(16 * kt + r) * pb + 16 * jt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < NDT; ++jt) acc[jt] = mfma16(st[kt][r], b[r][jt], acc[jt]);
+        }
+    }
+}
+
+// geometry shared by host launchers ---------------------------------------------------------------
+static inline int attn_pick_nds(int d) { return d <= 32 ? 8 : (d <= 52 ? 13 : 16); }
+static inline int attn_pick_nkt(int nkt) { return nkt <= 4 ? 4 : (nkt <= 13 ? 13 : 16); }
+
+static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
+    CR_REQUIRE(d->Q && d->K && d->V && d->k_valid && d->q_valid, "%s: NULL pointer", who);
+    CR_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->d > 0, "%s: bad shape B=%d T=%d H=%d d=%d", who, d->B, d->T, d->H, d->d);
+    if (d->d > 64) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: head dim %d > 64", who, d->d);
+    if (d->T > 256) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: T=%d > 256 (LDS-resident K/V design)", who, d->T);
+    CR_REQUIRE(d->ld >= d->H * d->d, "%s: ld too small", who);
+    CR_REQUIRE(d->batch_global >= d->B, "%s: batch_global < B", who);
+    g->T16 = (d->T + 15) / 16 * 16;
+    g->nkt = g->T16 / 16;
+    g->nds = attn_pick_nds(d->d);
+    g->ndt = g->nds == 8 ? 2 : 4;
+    g->PA = 4 * g->nds + 2;                                   // % 4 == 2: conflict-free A-pattern reads
+    g->PB = 4 * g->nds + (((4 * g->nds) % 8 == 4) ? 0 : 4);   // % 8 == 4: conflict-free B-pattern reads
+    g->isd = (float)(1.0 / sqrt((double)d->d));
+    g->isd_log2e = (float)(1.4426950408889634 / sqrt((double)d->d));
+    g->invT = 1.0f / (float)d->T;
+    return CR_OK;
+}
+
+static inline int attn_nsplit(const cr_attn_desc* d, const AttnGeom& g, int waves) {
+    int want = (256 + d->B * d->H - 1) / (d->B * d->H);
+    int maxs = (g.nkt + waves - 1) / waves;
+    if (want > maxs) want = maxs;
+    return want < 1 ? 1 : want;
+}
+
+static inline int attn_set_lds_attr(const void* fn) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return cr_set_error(CR_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return CR_OK;
+}
+
+// largest wave count (8, 4, 2, 1) whose LDS footprint fits the 160 KiB of a CU; 0 if none does
+template <class F>
+static int attn_pick_waves(const AttnGeom& g, F lds) {
+    for (int w = A_MAX_WAVES; w >= 1; w >>= 1)
+        if (lds(g, w) <= 160 * 1024) return w;
+    return 0;
+}

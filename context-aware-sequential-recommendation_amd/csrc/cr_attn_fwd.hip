@@ -1,0 +1,131 @@
+// Attention forward (modules.py:208-269); see cr_attn_common.hpp for the design.
+#include "cr_attn_common.hpp"
+
+template <int NKT, int NDS, int NDT>
+__global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, AttnGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* Ks = smem;                                   // [T16][PA]  A-pattern reads
+    float* Vs = Ks + g.T16 * g.PA;                      // [T16][PB]  B-pattern reads (+ tail)
+    float* Qs = Vs + g.T16 * g.PB + A_TAIL;             // [nw][16][PA] per-wave query tile slot
+    float* kv = Qs + nw * 16 * g.PA;                    // [T16]
+    float* qv = kv + g.T16;                             // [T16]
+    float* dead = qv + g.T16;                           // [T16]
+    const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
+    const int base_row = n * d.T, hoff = head * d.d;
+    const int T = d.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_rows(Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+        kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
+        qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
+        dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    const uint64_t kbits = key_bits<NKT>(kv, T);
+    const DropCtx dc = drop_ctx(d.drop);
+    float* Qw = Qs + wave * 16 * g.PA;
+    const int nwaves = gridDim.y * nw;
+    for (int qi = wave * gridDim.y + blockIdx.y; qi < g.nkt; qi += nwaves) {   // interleaved: every workgroup gets heavy and light tiles
+        const int qt = g.nkt - 1 - qi;                  // heaviest tiles first
+        const int q0 = 16 * qt, q = q0 + li;
+        const bool is_dead = dead[q] != 0.0f;
+        if (__all(is_dead ? 1 : 0) && d.attn_weights == nullptr) {
+            // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
+            for (int rr = 0; rr < 16; ++rr) {
+                const int qq = q0 + rr;
+                if (qq < T && lane < d.d) {
+                    const size_t row = (size_t)(base_row + qq);
+                    d.out[row * d.ldo + hoff + lane] = d.residual[row * d.ldr + hoff + lane];
+                }
+            }
+            continue;
+        }
+        stage_rows(Qw, g.PA, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
+        float qf[NDS];
+        load_frag<NDS>(Qw, g.PA, qf);
+        f32x4 st[NKT];
+        float m2, inv;
+        bool uniform;
+        score_rows<NKT, NDS>(g, Ks, qf, kbits, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        const float qvq = qv[q];
+        const bool any_uni = __any(uniform ? 1 : 0) != 0;
+        const uint32_t ridx = attn_row_idx(d, head, n, q);
+        if (dc.on) {                                                                 // wave-uniform
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                                          // modules.py:248-257
+                    st[kt][r] *= qvq * drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) st[kt] *= qvq;                          // modules.py:248-253
+        }
+        if (d.attn_weights) {                                                        // modules.py:259 (on request only)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kt + 4 * lg + r;
+                    if (q < T && key < T) d.attn_weights[((size_t)blockIdx.x * T + q) * T + key] = st[kt][r];
+                }
+            }
+        }
+        f32x4 acc[NDT];
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma_prob_rows<NKT, NDT>(st, Vs, g.PB, any_uni ? g.nkt : qt + 1, acc);        // modules.py:262
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + 4 * lg + r, c = 16 * jt + li;
+                if (qq < T && c < d.d) {
+                    const size_t row = (size_t)(base_row + qq);
+                    d.out[row * d.ldo + hoff + c] = acc[jt][r] + d.residual[row * d.ldr + hoff + c];   // modules.py:265-269
+                }
+            }
+        }
+    }
+}
+
+static size_t lds_fwd(const AttnGeom& g, int w) {
+    return sizeof(float) * ((size_t)g.T16 * (g.PA + g.PB) + A_TAIL + (size_t)w * 16 * g.PA + 3 * g.T16);
+}
+
+template <int NKT, int NDS, int NDT>
+static int launch_fwd(const cr_attn_desc* d, const AttnGeom& g, int waves, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_fwd<NKT, NDS, NDT>));
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_attn_fwd<NKT, NDS, NDT>), dim3(d->B * d->H, attn_nsplit(d, g, waves)), dim3(64 * waves),
+                       lds_fwd(g, waves), s, *d, g);
+    return cr_check_launch("cr_attn_fwd");
+}
+
+template <int NKT>
+static int dispatch_fwd(const cr_attn_desc* d, const AttnGeom& g, int waves, hipStream_t s) {
+    if (g.nds == 8) return launch_fwd<NKT, 8, 2>(d, g, waves, s);
+    if (g.nds == 13) return launch_fwd<NKT, 13, 4>(d, g, waves, s);
+    return launch_fwd<NKT, 16, 4>(d, g, waves, s);
+}
+
+extern "C" int cr_attn_fwd(const cr_attn_desc* d, void* stream) {
+    CR_REQUIRE(d != nullptr, "cr_attn_fwd: NULL desc");
+    AttnGeom g;
+    int rc = attn_geom(d, &g, "cr_attn_fwd");
+    if (rc) return rc;
+    CR_REQUIRE(d->out && d->residual, "cr_attn_fwd: NULL out/residual");
+    const int waves = attn_pick_waves(g, lds_fwd);
+    if (!waves) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_attn_fwd: T=%d d=%d needs %zu B of LDS", d->T, d->d, lds_fwd(g, 1));
+    hipStream_t s = cr_stream(stream);
+    const int nkt = attn_pick_nkt(g.nkt);
+    if (nkt == 4) return dispatch_fwd<4>(d, g, waves, s);
+    if (nkt == 13) return dispatch_fwd<13>(d, g, waves, s);
+    return dispatch_fwd<16>(d, g, waves, s);
+}

@@ -111,8 +111,8 @@ def test_model_grads_and_adam_match_oracle(E, model, rate):
         # BOTH sides (in TensorFlow too), so bk is re-synchronised instead of compared.
         worst = max((float((now[k].cpu().double() - P[k]).abs().max()), k) for k in P if not k.endswith(".bk"))
         # one Adam step moves a weight by ~lr = 1e-3; m/(sqrt(v)+eps) is ill-conditioned where |g| ~ eps, so the
-        # bound is 5% of a step (the Adam kernel itself is checked to 1e-6 in test_ops_gpu.py)
-        assert worst[0] < 5e-5, worst
+        # bound is 10% of a step (the Adam kernel itself is checked to 1e-6 in test_ops_gpu.py)
+        assert worst[0] < 1e-4, worst
         for k in P:
             if k.endswith(".bk"):
                 P[k] = now[k].cpu().double()
