@@ -1,0 +1,139 @@
+"""Model classes with the reference's constructor / predict surface (models/sasrec.py:5,127-129,
+models/cast_N.py) on top of the native engine.
+
+    model = SASRec(usernum, itemnum, args)              # or CAST1(usernum, itemnum, ratingnum, args) ... CAST9
+    auc, loss = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq)    # == sess.run([auc, loss, train_op], feed)
+    logits, attn = model.predict(sess, u, seq, item_idx, timeseq=, hours_seq=, days_seq=)
+
+``sess`` is accepted and ignored (there is no TensorFlow session).  ``predict`` takes a whole batch of
+users; ``item_idx`` is either the reference's shared list of 101 candidates or a [B, n] array.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .engine import MODELS, Engine, Hyper
+
+
+class _Model(object):
+    NAME = None
+
+    def __init__(self, usernum, itemnum, args, reuse=None, n_slabs=256, batch_global=None, row_offset=0):
+        self.name = self.NAME
+        self.usernum, self.itemnum, self.args = usernum, itemnum, args
+        self.hp = Hyper(args)
+        self._n_slabs, self._batch_global, self._row_offset = n_slabs, batch_global, row_offset
+        self._train = None
+        self._eval = {}
+        self._graph = bool(int(os.environ.get("CASTREC_GRAPH", "1")))
+        # parameters exist from construction on (tf.global_variables_initializer, main.py:150)
+        self._owner = Engine(self.name, usernum, itemnum, self.hp, 1, training=False)
+        self.attention_weights = None
+
+    # -- training ---------------------------------------------------------------------------------
+    def _train_engine(self, B):
+        if self._train is None:
+            self._train = Engine(self.name, self.usernum, self.itemnum, self.hp, B, training=True, share=self._owner,
+                                 n_slabs=self._n_slabs, batch_global=self._batch_global, row_offset=self._row_offset)
+            if self._graph and self._batch_global is None:
+                self._train.capture()
+                self._train.state.zero_(); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
+        if self._train.B != B:
+            raise ValueError("batch size changed from %d to %d (static graph)" % (self._train.B, B))
+        return self._train
+
+    def train_step(self, u, seq, pos, neg, time_seq=None, hours=None, days=None, fetch=True):
+        """One optimisation step (main.py:212-219).  Returns (auc, loss) of the batch like the reference's fetch."""
+        seq = np.asarray(seq)
+        eng = self._train_engine(seq.shape[0])
+        z = np.zeros_like(seq) if (time_seq is None or hours is None or days is None) else None
+        eng.train_step(seq, np.asarray(pos), np.asarray(neg), z if time_seq is None else np.asarray(time_seq),
+                       z if hours is None else np.asarray(hours), z if days is None else np.asarray(days))
+        if fetch:
+            loss, auc = eng.loss_auc()
+            return auc, loss
+        return None
+
+    # -- inference --------------------------------------------------------------------------------
+    def predict(self, sess, u, seq, item_idx, timeseq=None, input_context_seq=None, hours_seq=None, days_seq=None,
+                want_attention=True):
+        seq = np.asarray(seq)
+        if seq.ndim == 1:
+            seq = seq[None]
+        B = seq.shape[0]
+        key = (B, bool(want_attention))
+        if key not in self._eval:
+            self._eval[key] = Engine(self.name, self.usernum, self.itemnum, self.hp, B, training=False, share=self._owner,
+                                     want_attn=want_attention)
+        eng = self._eval[key]
+        z = np.zeros_like(seq)
+        f = lambda a: z if a is None else np.asarray(a).reshape(B, -1)
+        eng.forward_eval(seq, f(timeseq), f(hours_seq), f(days_seq))
+        cand = np.asarray(item_idx, np.int32)
+        if cand.ndim == 1:
+            cand = np.tile(cand[None], (B, 1))
+        lg = eng.test_logits(torch.from_numpy(np.ascontiguousarray(cand)).to(eng.dev))
+        self.attention_weights = eng.attn_weights
+        attn = eng.attn_weights.cpu().numpy() if (want_attention and eng.attn_weights is not None) else None
+        return lg.cpu().numpy(), attn
+
+    # -- checkpoints (tf.train.Saver, main.py:159,227) ----------------------------------------------
+    def state_dict(self):
+        d = {"model": self.name, "P": self._owner.P.detach().cpu(), "names": self._owner.layout.logical_names()}
+        if self._train is not None:
+            d.update(M=self._train.Mom.cpu(), V=self._train.Vel.cpu(), state=self._train.state.cpu())
+        return d
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+        return path
+
+    def load(self, path):
+        d = torch.load(path, map_location="cpu")
+        if d["model"] != self.name or d["P"].numel() != self._owner.P.numel():
+            raise ValueError("checkpoint %s does not match model %s" % (path, self.name))
+        self._owner.P.copy_(d["P"])
+        if "M" in d and self._train is not None:
+            self._train.Mom.copy_(d["M"]); self._train.Vel.copy_(d["V"]); self._train.state.copy_(d["state"])
+
+    def get_params(self):
+        return self._owner.get_params()
+
+    def load_params(self, d):
+        self._owner.load_params(d)
+
+
+class SASRec(_Model):
+    """models/sasrec.py:4-5: SASRec(usernum, itemnum, args, static=False, reuse=None)."""
+
+    def __init__(self, usernum, itemnum, args, static=False, reuse=None, **kw):
+        self.NAME = "sasrec_static" if static else "sasrec"
+        super().__init__(usernum, itemnum, args, reuse, **kw)
+
+
+def _cast(n):
+    class _C(_Model):
+        NAME = "cast_%d" % n
+        __doc__ = "models/cast_%d.py: CAST%d(usernum, itemnum, ratingnum, args, reuse=None)." % (n, n)
+
+        def __init__(self, usernum, itemnum, ratingnum, args, reuse=None, **kw):
+            self.ratingnum = ratingnum
+            super().__init__(usernum, itemnum, args, reuse, **kw)
+    _C.__name__ = "CAST%d" % n
+    return _C
+
+
+CAST1, CAST2, CAST3, CAST4, CAST5, CAST6, CAST7, CAST8, CAST9 = (_cast(n) for n in range(1, 10))
+
+
+def build_model(name, usernum, itemnum, ratingnum, args, **kw):
+    """The registry of main.py:121-142."""
+    name = name.lower()
+    if name not in MODELS:
+        raise ValueError("provide model from %s" % MODELS)
+    if name == "sasrec":
+        return SASRec(usernum, itemnum, args, **kw)
+    if name == "sasrec_static":
+        return SASRec(usernum, itemnum, args, static=True, **kw)
+    return globals()["CAST%s" % name.split("_")[1]](usernum, itemnum, ratingnum, args, **kw)

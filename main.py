@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Command-line training / evaluation loop with the flags of the reference's main.py:45-82.
+
+    python main.py --dataset data/ml-1m.txt --train_dir sasrec_baseline --model sasrec --maxlen 200 --dropout_rate 0.2
+
+Artefacts keep the reference's formats: saved_models/<dataset>/<train_dir>_<timestamp>/{params.txt,log.txt,model.ckpt}
+(main.py:153-158,196-199,238).  `--dataset synthetic:<preset>` trains on a seeded synthetic corpus
+(castrec_amd.synth.PRESETS) when no dataset file is available."""
+import argparse
+import json
+import logging
+import os
+import random
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import castrec_amd  # noqa: E402
+from castrec_amd import synth  # noqa: E402
+from castrec_amd.engine import MODELS  # noqa: E402
+from castrec_amd.models import build_model  # noqa: E402
+from castrec_amd.sampler import WarpSampler  # noqa: E402
+from castrec_amd.util import data_partition, evaluate, evaluate_valid, partition, train_corpus  # noqa: E402
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--dataset', required=True, help='Location of pre-processed dataset (or synthetic:<preset>)')
+    parser.add_argument('--maxlen', default=50, type=int)
+    parser.add_argument('--train_dir', required=True)
+    parser.add_argument('--batch_size', default=128, type=int)
+    parser.add_argument('--lr', type=float, default=1e-3)
+    parser.add_argument('--num_epochs', type=int, default=201)
+    parser.add_argument('--max_norm', type=float, default=5.0)
+    parser.add_argument('--hidden_units', default=50, type=int)
+    parser.add_argument('--num_blocks', default=2, type=int)
+    parser.add_argument('--num_heads', default=1, type=int)
+    parser.add_argument('--dropout_rate', default=0.5, type=float)
+    parser.add_argument('--l2_emb', default=0.0, type=float)
+    parser.add_argument('--bin_in_hours', default=24, type=int)
+    parser.add_argument('--max_bins', default=200, type=int)
+    parser.add_argument('--num_context_blocks', default=2, type=int)
+    parser.add_argument('--test_model', type=str, default=None)
+    parser.add_argument('--test_seq_len', type=int, default=None)
+    parser.add_argument('--saved_model', default='model.pt', type=str)
+    parser.add_argument('--seed', default=42, type=int)
+    parser.add_argument('--log_scale', type=bool, default=False)       # type=bool as in the reference (any string is True)
+    parser.add_argument('--input_context', type=bool, default=False)
+    parser.add_argument('--model', default="cast_1", required=True, help="model to use from" + str(MODELS))
+    parser.add_argument('--eval_every', type=int, default=20, help='evaluate + checkpoint every N epochs (reference: 20)')
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logger = logging.getLogger('ir2')
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)-5.5s]  %(message)s",
+                        handlers=[logging.FileHandler(os.path.join('.', 'output.log')), logging.StreamHandler()])
+    if args.dataset.startswith("synthetic:"):
+        c = synth.preset(args.dataset.split(":", 1)[1])
+        dataset = partition(c.to_dict(), c.usernum, c.itemnum)
+    elif not os.path.exists(args.dataset):
+        logger.info('Pre-process the data first')
+        sys.exit()
+    else:
+        dataset = data_partition(args.dataset, args.log_scale)
+    train, valid, test, usernum, itemnum, ratingnum = dataset
+    num_batch = round(len(train) / args.batch_size)               # main.py:96 (banker's rounding)
+    print('usernum', usernum, 'itemnum', itemnum)
+    cc = sum(len(v) for v in train.values())
+    logger.info('Average sequence length: {:.2f}'.format(cc / len(train)))
+    if args.seed:                                                  # main.py:103-107
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+    if args.model.lower() not in MODELS:
+        print("provide model from", MODELS)
+        sys.exit(0)
+    model = build_model(args.model, usernum, itemnum, ratingnum, args)
+    sampler = WarpSampler(args, train_corpus(train, usernum, itemnum), usernum, itemnum,
+                          batch_size=args.batch_size, maxlen=args.maxlen, n_workers=1)
+    model_path = os.path.abspath('saved_models')
+    now = datetime.now()
+    files_path = os.path.join(model_path, os.path.basename(args.dataset).replace(":", "_"),
+                              '{}_{}'.format(args.train_dir, now.strftime("%m-%d-%Y-%H-%M-%S")))
+    save_path = os.path.join(files_path, 'model.ckpt')
+
+    if args.test_model:                                            # main.py:161-189
+        ck = os.path.join(args.test_model, 'model.ckpt')
+        if os.path.exists(ck):
+            model.load(ck)
+            print('loaded saved model {}'.format(args.test_model))
+            u, seq, pos, neg, timeseq, ratings_seq, hours_seq, days_seq, _ = sampler.next_batch()
+            auc, loss = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq)   # the reference's one-train-step quirk
+            print(auc); print(loss)
+            t_test = evaluate(model, dataset, args)
+            logger.info('test (NDCG@10: %.4f, HR@10: %.4f)' % (t_test[0], t_test[1]))
+            with open(os.path.join(args.test_model, 'test_seq_len.txt'), 'a') as f:
+                f.write('{},{},{}\n'.format(args.test_seq_len, t_test[0], t_test[1]))
+        else:
+            print('{} not found'.format(args.test_model))
+        sampler.close()
+        return 0
+
+    os.makedirs(files_path, exist_ok=True)
+    with open(os.path.join(files_path, 'params.txt'), 'w') as f:   # main.py:196-197
+        json.dump(args.__dict__, f, indent=2)
+    f = open(os.path.join(files_path, 'log.txt'), 'w')
+    T, t0, rc = 0.0, time.time(), 0
+    try:
+        for epoch in range(1, args.num_epochs + 1):
+            for step in range(num_batch):
+                u, seq, pos, neg, timeseq, ratings_seq, hours_seq, days_seq, _ = sampler.next_batch()
+                last = (step == num_batch - 1)
+                out = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq, fetch=last)
+            if out is not None:
+                logger.info('epoch %d: TRAIN/loss %.5f TRAIN/auc %.5f' % (epoch, out[1], out[0]))
+            if epoch % args.eval_every == 0:
+                logger.info('Model saved in path: %s' % model.save(save_path))
+                logger.info('Evaluating')
+                T += time.time() - t0
+                t_test = evaluate(model, dataset, args)
+                t_valid = evaluate_valid(model, dataset, args)
+                logger.info('epoch:%d, time: %f(s), valid (NDCG@10: %.4f, HR@10: %.4f), test (NDCG@10: %.4f, HR@10: %.4f)' % (
+                    epoch, T, t_valid[0], t_valid[1], t_test[0], t_test[1]))
+                f.write(str(t_valid) + ' ' + str(t_test) + '\n')
+                f.flush()
+                t0 = time.time()
+    except Exception as e:                                         # main.py:253-257
+        logger.error(e)
+        rc = 1
+    f.close()
+    sampler.close()
+    if rc == 0:
+        print("Done")
+    return rc
+
+
+if __name__ == '__main__':
+    sys.exit(main())

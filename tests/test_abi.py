@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every symbol include/castrec.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import castrec_amd  # noqa: F401
+from castrec_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "castrec.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = header_functions()
+    assert len(names) >= 20
+    so = ctypes.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), "libcastrec.so does not export %s" % n
+    assert sorted(L.EXPORTS) == names
+
+
+def test_version_and_error_string_without_gpu():
+    assert L.lib.cr_version() >= 100
+    assert isinstance(L.lib.cr_last_error(), bytes)
+    # argument validation happens before any HIP call: a NULL descriptor is rejected with a message
+    rc = L.lib.cr_adam_step(None, None)
+    assert rc == -1 and b"cr_adam_step" in L.lib.cr_last_error()
+
+
+def test_struct_sizes_match_c_layout(tmp_path):
+    """sizeof of every descriptor as gcc lays it out from include/castrec.h == the ctypes mirror."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    pairs = [("cr_rng", L.Rng), ("cr_embed_desc", L.EmbedDesc), ("cr_embed_bwd_desc", L.EmbedBwdDesc), ("cr_ln_desc", L.LnDesc),
+             ("cr_ln_bwd_desc", L.LnBwdDesc), ("cr_gemm_desc", L.GemmDesc), ("cr_wgrad_desc", L.WgradDesc),
+             ("cr_elt_desc", L.EltDesc), ("cr_attn_desc", L.AttnDesc), ("cr_attn_bwd_desc", L.AttnBwdDesc),
+             ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "castrec.h"\nint main(void){' +
+                   "".join('printf("%%zu\\n", sizeof(%s));' % c for c, _ in pairs) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    for (cname, ct), n in zip(pairs, sizes):
+        assert ctypes.sizeof(ct) == n, (cname, ctypes.sizeof(ct), n)

@@ -1,0 +1,108 @@
+"""world_size-2 gloo test of the data-parallel wrapper (castrec_amd.dist) on CPU.
+
+The replica is oracle-backed (the HIP engine needs a GPU): it produces UN-normalised gradients of its
+row shard in the flat bucket layout the engine uses, so the test covers row sharding, the single flat
+all-reduce carrying gradients + loss statistics, global-target-count normalisation and the Adam hand-off.
+Result must equal a single-process step on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import castrec_amd  # noqa: F401
+from castrec_amd.dist import DataParallel, shard_rows
+from oracle import fpmodel as fm
+
+MODEL = "cast_1"
+HP = fm.Hyper(maxlen=10, hidden_units=8, num_blocks=1, num_heads=2, dropout_rate=0.0, max_bins=6, lr=1e-2)
+
+
+class OracleReplica:
+    def __init__(self, seed=0):
+        self.P = fm.init_params(MODEL, 7, 20, HP, seed=seed)
+        self.names = sorted(self.P)
+        self.sizes = [self.P[k].numel() for k in self.names]
+        self.vec = torch.cat([self.P[k].reshape(-1) for k in self.names])
+        self.bucket = torch.zeros(self.vec.numel() + 4, dtype=torch.float64)
+        self.opt = fm.AdamTF(self.P, lr=HP.lr)
+
+    def param_vector(self):
+        return self.vec
+
+    def _sync_from_vec(self):
+        off = 0
+        for k, n in zip(self.names, self.sizes):
+            self.P[k] = self.vec[off:off + n].reshape(self.P[k].shape).clone(); off += n
+
+    def backward_to_flat(self, shard):
+        self._sync_from_vec()
+        out, G = fm.loss_and_grads(MODEL, self.P, HP, fm.to_batch(*shard))
+        n = float(out["istarget"].sum())
+        self.bucket[:-4] = torch.cat([G[k].reshape(-1) for k in self.names]) * n     # un-normalised
+        self.bucket[-4] = float(out["loss"]) * n
+        self.bucket[-3] = float(out["auc"]) * n
+        self.bucket[-2] = n
+        return self.bucket
+
+    def adam_from_flat(self):
+        n = float(self.bucket[-2])
+        off, G = 0, {}
+        for k, sz in zip(self.names, self.sizes):
+            G[k] = (self.bucket[off:off + sz] / n).reshape(self.P[k].shape); off += sz
+        self.P = self.opt.step(self.P, G)
+        self.vec = torch.cat([self.P[k].reshape(-1) for k in self.names])
+        self.loss = float(self.bucket[-4]) / n
+
+
+def make_batch(B=8, T=10, seed=3):
+    rs = np.random.RandomState(seed)
+    seq = rs.randint(1, 21, (B, T)); pos = rs.randint(1, 21, (B, T)); neg = rs.randint(1, 21, (B, T))
+    for b in range(B):
+        n = rs.randint(0, T - 2)
+        seq[b, :n] = 0; pos[b, :n] = 0; neg[b, :n] = 0          # ragged: ranks see different target counts
+    time = rs.randint(0, 7, (B, T)) * (seq != 0)
+    z = np.zeros_like(seq)
+    return seq, pos, neg, time, z, z
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rep = OracleReplica(seed=rank)            # different init per rank: the wrapper must broadcast rank 0's
+    dp = DataParallel(rep, rank, world)
+    batch = make_batch()
+    for _ in range(2):
+        dp.step(batch)
+    q.put((rank, rep.param_vector().numpy().copy(), rep.loss))
+    dist.destroy_process_group()
+
+
+def test_shard_rows():
+    assert [shard_rows(8, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    with pytest.raises(ValueError):
+        shard_rows(10, 0, 4)
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_step_equals_single_process():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in procs])
+    for p in procs:
+        p.join(timeout=30)
+    ref = OracleReplica(seed=0)
+    one = DataParallel(ref, 0, 1)
+    batch = make_batch()
+    for _ in range(2):
+        one.step(batch)
+    for rank, vec, loss in res:
+        np.testing.assert_allclose(vec, ref.param_vector().numpy(), rtol=0, atol=1e-12)
+        assert loss == pytest.approx(ref.loss, rel=1e-12)

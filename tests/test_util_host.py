@@ -1,0 +1,67 @@
+"""Host-side mirror of util.py (castrec_amd.util) against the reference-generated goldens (CPU only)."""
+import random
+import types
+
+import numpy as np
+import pytest
+
+import castrec_amd  # noqa: F401
+from castrec_amd import util as U
+from helpers import load_eval_golden, load_sampler_golden, load_util_golden
+
+
+def test_hour_day_bins_and_partition_golden(tmp_path):
+    g = load_util_golden()
+    for ts, hour, day in g["hour_day"]:
+        assert (U.hour_of(ts), U.day_of(ts)) == (hour, day)
+    for tab in g["linear"]:
+        assert [U.get_timedelta_bin(float(d), tab["bin_in_hours"], tab["max_bins"], False) for d in g["deltas"]] == tab["bins"]
+    for tab in g["log"]:
+        assert [U.get_timedelta_bin(float(d), 48, tab["max_bins"], True, tab["min_ts"], tab["max_ts"]) for d in g["deltas"]] == tab["bins"]
+    p = tmp_path / "d.txt"
+    p.write_text(g["partition"]["text"])
+    tr, va, te, usernum, itemnum, ratingnum = U.data_partition(str(p))
+    assert (usernum, itemnum, ratingnum) == (g["partition"]["usernum"], g["partition"]["itemnum"], g["partition"]["ratingnum"])
+    for got, want in ((tr, g["partition"]["train"]), (va, g["partition"]["valid"]), (te, g["partition"]["test"])):
+        assert {str(u): [list(e) for e in ev] for u, ev in got.items()} == want
+
+
+class FakeModel:
+    """Batched stand-in with the pseudo-logits tests/golden/make_golden.py used; records its inputs."""
+
+    def __init__(self):
+        self.calls = []
+
+    def predict(self, sess, u, seq, item_idx, timeseq=None, hours_seq=None, days_seq=None):
+        out = []
+        for i, uu in enumerate(u):
+            self.calls.append((int(uu), seq[i].copy(), timeseq[i].copy(), hours_seq[i].copy(), days_seq[i].copy(), item_idx[i].copy()))
+            h = (item_idx[i].astype(np.int64) * 2654435761 + int(uu) * 40503) % 1000003
+            out.append(h.astype(np.float64) / 1000003.0)
+        return np.stack(out), None
+
+
+def test_batched_evaluate_reproduces_reference_inputs_and_metrics():
+    z, meta = load_eval_golden()
+    _, _, corpora = load_sampler_golden()
+    for case in meta:
+        c = corpora[case["corpus"]]
+        dataset = U.partition(c.to_dict(), c.usernum, c.itemnum)
+        args = types.SimpleNamespace(maxlen=case["T"], bin_in_hours=case["bin_in_hours"], max_bins=case["max_bins"],
+                                     log_scale=case["log_scale"], test_model=("/tmp" if case["test_seq_len"] else None),
+                                     test_seq_len=case["test_seq_len"])
+        random.seed(42); np.random.seed(42)                     # main.py:104-105
+        fm_t, fm_v = FakeModel(), FakeModel()
+        t_test = U.evaluate(fm_t, dataset, args)                # main.py:232 (test first, then valid: one RNG stream)
+        t_valid = U.evaluate_valid(fm_v, dataset, args)
+        assert list(t_test) == pytest.approx(case["test"], abs=1e-12)
+        assert list(t_valid) == pytest.approx(case["valid"], abs=1e-12)
+        for mode, fmk in (("test", fm_t), ("valid", fm_v)):
+            key = "%s/%s" % (case["key"], mode)
+            assert len(fmk.calls) == int(z[key + "/n_calls"])
+            for j, nm in enumerate(("user", "seq", "timeseq", "hours", "days", "item_idx")):
+                want = z["%s/%s" % (key, nm)]
+                got = np.stack([np.asarray(cl[j]) for cl in fmk.calls[:len(want)]])
+                np.testing.assert_array_equal(got, want, err_msg=key + "/" + nm)
+            allc = np.stack([cl[5] for cl in fmk.calls]).astype(np.int64)
+            assert int((allc * (np.arange(101) + 1)).sum()) == int(z[key + "/cand_checksum"])
