@@ -22,8 +22,15 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d) {
             d.table_grad[i] = 0.0f;
         } else {
             const int j = i - d.n_table;
-            g = 0.0f;
-            for (int s = 0; s < d.n_slabs; ++s) g += d.dense_slabs[(size_t)s * d.n_dense + j];
+            // slab sum with 8 loads in flight per thread (fixed association: bitwise reproducible)
+            float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 8 <= d.n_slabs; s += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p8[u] += d.dense_slabs[(size_t)(s + u) * d.n_dense + j];
+            }
+            for (; s < d.n_slabs; ++s) p8[0] += d.dense_slabs[(size_t)s * d.n_dense + j];
+            g = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
         }
         g *= inv_n;
         const float m = d.beta1 * d.m[i] + (1.0f - d.beta1) * g;
@@ -53,9 +60,14 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* slabs, int n_slabs, int n_dense, float* out,
                                                       const float* state, float* stats_out) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_dense; i += gridDim.x * 256) {
-        float g = 0.0f;
-        for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * n_dense + i];
-        out[i] = g;
+        float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= n_slabs; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p8[u] += slabs[(size_t)(s + u) * n_dense + i];
+        }
+        for (; s < n_slabs; ++s) p8[0] += slabs[(size_t)s * n_dense + i];
+        out[i] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     }
     if (blockIdx.x == 0 && threadIdx.x < 3 && stats_out) stats_out[threadIdx.x] = state[threadIdx.x];
 }

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(1024) void k_ln_bwd(cr_ln_bwd_desc d) {
             }
         }
     }
-    // fold the RPW row groups of the wave, then the 16 waves through LDS float atomics
+    // fold the RPW row groups of the wave (shuffles), then the 16 waves through per-wave LDS slots summed
+    // in a fixed order (bitwise reproducible)
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
 #pragma unroll
@@ -142,13 +144,17 @@ __global__ __launch_bounds__(1024) void k_ln_bwd(cr_ln_bwd_desc d) {
             ag[i] += __shfl_xor(ag[i], o, 64);
             ab[i] += __shfl_xor(ab[i], o, 64);
         }
-        const int c = l + LPR * i;
-        if (sub == 0 && c < d.D) {
-            atomicAdd(&sg[c], ag[i]);
-            atomicAdd(&sb[c], ab[i]);
-        }
     }
-    __syncthreads();
+    for (int w = 0; w < 16; ++w) {                       // serialised on purpose: 16 x D adds, fixed order
+        if (wave == w && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = l + LPR * i;
+                if (c < d.D) { sg[c] += ag[i]; sb[c] += ab[i]; }
+            }
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < d.D; c += 1024) {
         d.dgamma[(size_t)blockIdx.x * d.slab_stride + c] = sg[c];
         d.dbeta[(size_t)blockIdx.x * d.slab_stride + c] = sb[c];

@@ -161,7 +161,7 @@ class ParamLayout:
 # ---------------------------------------------------------------------------------------------------
 class Engine:
     def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=256,
-                 share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda"):
+                 share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda", fused=None):
         if model not in MODELS:
             raise ValueError("model must be one of %s" % MODELS)
         if not torch.cuda.is_available():
@@ -171,6 +171,10 @@ class Engine:
         self.M = self.B * self.T
         self.usernum, self.itemnum = usernum, itemnum
         self.training = training
+        # fused row-phase kernels (cr_block_*) need the hidden size to fit one 64-column tile
+        self.fused = (hp.hidden_units <= 64) if fused is None else bool(fused)
+        if self.fused and hp.hidden_units > 64:
+            raise ValueError("fused block kernels need hidden_units <= 64")
         self.dev = torch.device(device)
         self.seed = hp.seed if seed is None else seed
         self.layout = share.layout if share is not None else ParamLayout(model, usernum, itemnum, hp)
@@ -370,6 +374,8 @@ class Engine:
         kvalid, qvalid = self.vec(pfx + "kvalid"), self.vec(pfx + "qvalid")
         ids = self.ids["seq"]
         wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
+        if self.fused:
+            return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid)
         # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
         ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
                        1e-8, kvalid.data_ptr(), qvalid.data_ptr())
@@ -446,6 +452,45 @@ class Engine:
             l1 = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), dq_in.data_ptr(), D, dx.data_ptr(), D, 1,
                              self._gptr(pfx + "ln1.gamma"), self._gptr(pfx + "ln1.beta"), S, self.n_slabs, M, D, 1e-8)
             self._call(lst, "cr_layernorm_bwd", C.byref(l1))
+            return lst
+        self._bwd_factories.append(factory)
+
+    def _op_block_fused(self, x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid):
+        """Same block through the fused row-phase kernels (cr_block_*): 3 launches forward, 4 backward."""
+        M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
+        ids = self.ids["seq"]
+        P = self._pptr
+        bd = L.BlockDesc(M, D, P(pfx + "ln1.gamma"), P(pfx + "ln1.beta"), P(pfx + "wqkv"), P(pfx + "bqkv"),
+                         P(pfx + "ln2.gamma"), P(pfx + "ln2.beta"), P(pfx + "w1"), P(pfx + "b1"), P(pfx + "w2"), P(pfx + "b2"),
+                         x.data_ptr(), q_in.data_ptr(), qkv.data_ptr(), kvalid.data_ptr(), qvalid.data_ptr(), o.data_ptr(),
+                         f_in.data_ptr(), hid.data_ptr(), y.data_ptr(), ids.data_ptr(),
+                         self.rng(pfx[:-1] + ".ffn1"), self.rng(pfx[:-1] + ".ffn2"))
+        self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
+        ad = O.attn_desc(qkv, None, None, 3 * D, kvalid, qvalid, q_in, D, o, D, B, T, H, D // H,
+                         rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
+                         dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
+        ad.K, ad.V = qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
+        self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
+        self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
+        if not self.training:
+            return
+
+        def factory():
+            lst = []
+            dy, dx = self._grad_of(y), self._grad_of(x)
+            do = self.buf(pfx + "do", D)
+            dqkv = self.buf(pfx + "dqkv", 3 * D)
+            stats = self.vec(pfx + "stats", H * B * T * 4)
+            G = self._gptr
+            bbd = L.BlockBwdDesc(L.BlockDesc.from_buffer_copy(bd), dy.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dx.data_ptr(),
+                                 self._acc(id(dx)), G(pfx + "ln1.gamma"), G(pfx + "ln1.beta"), G(pfx + "wqkv"), G(pfx + "bqkv"),
+                                 G(pfx + "ln2.gamma"), G(pfx + "ln2.beta"), G(pfx + "w1"), G(pfx + "b1"), G(pfx + "w2"), G(pfx + "b2"),
+                                 self.Gs.shape[1], self.n_slabs)
+            self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
+            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + 4 * D,
+                                dqkv.data_ptr() + 8 * D, 3 * D, stats.data_ptr())
+            self._call(lst, "cr_attn_bwd", C.byref(abd))
+            self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst
         self._bwd_factories.append(factory)
 

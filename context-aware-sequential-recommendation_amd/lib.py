@@ -82,6 +82,19 @@ class AttnBwdDesc(C.Structure):
                 ("ldg", c_i), ("stats", c_p)]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = [("M", c_i), ("D", c_i), ("ln1_g", c_p), ("ln1_b", c_p), ("wqkv", c_p), ("bqkv", c_p), ("ln2_g", c_p),
+                ("ln2_b", c_p), ("w1", c_p), ("b1", c_p), ("w2", c_p), ("b2", c_p), ("x", c_p), ("q_in", c_p), ("qkv", c_p),
+                ("k_valid", c_p), ("q_valid", c_p), ("o", c_p), ("f_in", c_p), ("hid", c_p), ("y", c_p), ("mask_ids", c_p),
+                ("drop_ffn1", Rng), ("drop_ffn2", Rng)]
+
+
+class BlockBwdDesc(C.Structure):
+    _fields_ = [("f", BlockDesc), ("dy", c_p), ("d_o", c_p), ("dqkv", c_p), ("dx", c_p), ("dx_accumulate", c_i),
+                ("g_ln1_g", c_p), ("g_ln1_b", c_p), ("g_wqkv", c_p), ("g_bqkv", c_p), ("g_ln2_g", c_p), ("g_ln2_b", c_p),
+                ("g_w1", c_p), ("g_b1", c_p), ("g_w2", c_p), ("g_b2", c_p), ("slab_stride", c_i), ("n_slabs", c_i)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [("seq_emb", c_p), ("ld", c_i), ("table", c_p), ("pos", c_p), ("neg", c_p),
                 ("M", c_i), ("D", c_i), ("V", c_i), ("state", c_p), ("d_seq_emb", c_p), ("ldd", c_i),
@@ -114,6 +127,10 @@ _sig("cr_gemm_wgrad", c_i, [C.POINTER(WgradDesc), c_i, c_i, c_i, c_p])
 _sig("cr_eltwise", c_i, [C.POINTER(EltDesc), c_p])
 _sig("cr_attn_fwd", c_i, [C.POINTER(AttnDesc), c_p])
 _sig("cr_attn_bwd", c_i, [C.POINTER(AttnBwdDesc), c_p])
+_sig("cr_block_ln_qkv_fwd", c_i, [C.POINTER(BlockDesc), c_p])
+_sig("cr_block_ln_ffn_fwd", c_i, [C.POINTER(BlockDesc), c_p])
+_sig("cr_block_ln_ffn_bwd", c_i, [C.POINTER(BlockBwdDesc), c_p])
+_sig("cr_block_ln_qkv_bwd", c_i, [C.POINTER(BlockBwdDesc), c_p])
 _sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
 _sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 _sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
@@ -128,6 +145,7 @@ _sig("cr_sampler_destroy", None, [c_p])
 
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
+           "cr_block_ln_qkv_fwd", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd",
            "cr_head_fwd_bwd", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]
 

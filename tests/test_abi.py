@@ -42,7 +42,7 @@ def test_struct_sizes_match_c_layout(tmp_path):
     pairs = [("cr_rng", L.Rng), ("cr_embed_desc", L.EmbedDesc), ("cr_embed_bwd_desc", L.EmbedBwdDesc), ("cr_ln_desc", L.LnDesc),
              ("cr_ln_bwd_desc", L.LnBwdDesc), ("cr_gemm_desc", L.GemmDesc), ("cr_wgrad_desc", L.WgradDesc),
              ("cr_elt_desc", L.EltDesc), ("cr_attn_desc", L.AttnDesc), ("cr_attn_bwd_desc", L.AttnBwdDesc),
-             ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
+             ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "castrec.h"\nint main(void){' +
                    "".join('printf("%%zu\\n", sizeof(%s));' % c for c, _ in pairs) + "return 0;}\n")

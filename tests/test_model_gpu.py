@@ -54,18 +54,20 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-CASES = [(m, 0.0) for m in fm.MODELS] + [("sasrec", 0.3), ("cast_1", 0.3), ("cast_4", 0.25), ("cast_9", 0.2)]
+CASES = [(m, 0.0, True) for m in fm.MODELS] + [("sasrec", 0.3, True), ("cast_1", 0.3, True), ("cast_4", 0.25, True), ("cast_9", 0.2, True)]
+# the unfused kernel path (used for hidden sizes > 64) stays covered at the same small shapes
+CASES += [("sasrec", 0.0, False), ("cast_1", 0.3, False), ("cast_3", 0.0, False), ("cast_9", 0.2, False)]
 
 
-@pytest.mark.parametrize("model,rate", CASES)
-def test_model_grads_and_adam_match_oracle(E, model, rate):
+@pytest.mark.parametrize("model,rate,fused", CASES)
+def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
     rs = np.random.RandomState(abs(hash(model)) % 1000 + int(rate * 100))
     B, T, D, H, itemnum, max_bins = 5, 24, 20, 2, 37, 12
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=rate, max_bins=max_bins,
                  num_context_blocks=1, lr=1e-3, seed=7)
     ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=rate, max_bins=max_bins,
                    num_context_blocks=1, lr=1e-3)
-    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=7)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=7, fused=fused)
     # oracle parameters: perturbed init so LN gains / biases are off their defaults
     P = fm.init_params(model, 9, itemnum, ohp, seed=3)
     P = {k: v + 0.1 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
