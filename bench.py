@@ -73,6 +73,7 @@ def kernel_profile(eng, staged, n_steps=8):
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
     prog = [("cr_step_begin", L.lib.cr_step_begin, (eng.state.data_ptr(),))] + eng.fwd + eng.bwd + [eng._adam]
+    eng.Gflat.zero_()
     for it in range(n_steps + 2):
         eng.ids_all.copy_(staged[it % staged.shape[0]])
         rec = []
@@ -157,9 +158,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CASTREC_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B, T = args.batch_size, args.maxlen
@@ -178,17 +183,18 @@ def main():
 
     eng = E.Engine(args.model, corpus.usernum, corpus.itemnum, hyper(args), B, training=True, n_slabs=args.n_slabs,
                    batch_global=Bg, row_offset=rank * B * T)
-    if world > 1:
+    dp = dist is not None
+    if dp:
         dist.broadcast(eng.P, 0)
     use_graph = not args.no_graph
     if use_graph:
         eng.ids_all.copy_(staged[0])
-        eng.capture(dp=(world > 1))
+        eng.capture(dp=dp)
         eng.state.zero_(); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
 
     def step(i):
         eng.ids_all.copy_(staged[i % NB])
-        if world == 1:
+        if not dp:
             if use_graph:
                 eng.graph.launch()
             else:

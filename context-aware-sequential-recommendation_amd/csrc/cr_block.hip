@@ -11,6 +11,8 @@
 // burst of loads and one barrier -- after it every wave works only on rows it owns.  The persistent backward
 // kernels prefetch the next tile into registers under the MFMAs of the current one, and obtain the bias
 // gradients for free by planting a column of ones in the A-tile of the weight-gradient MFMA (D < 64).
+#include <stdlib.h>
+
 #include "cr_common.hpp"
 
 #define BK_PW 80
@@ -19,6 +21,8 @@ struct BlockGeom {
     int P;        // row-tile pitch
     int ks;       // k-steps of 4 covering D
     int ones;     // column holding 1.0 for the bias-gradient trick, or -1 (D == 64)
+    int dbg;      // timing-only ablation switches (env CR_BLOCK_DBG); 0 in production
+    uint32_t invD;  // floor(2^32 / D) + 1: e / D == umulhi(e, invD) for e < 2^16
 };
 
 // ---- small helpers ---------------------------------------------------------------------------------
@@ -114,6 +118,48 @@ __device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, co
     }
 }
 
+// The wave's 16 rows of a DENSE [M, D] matrix (ld == D) are one contiguous 16*D-float block: move it as
+// a 16-byte-per-lane stream (full cache lines) instead of 4-byte lanes on 4*D-byte row segments.
+__device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, int P, int D, int nrows, uint32_t invD) {
+    const int lane = threadIdx.x & 63;
+    const int total = nrows * D, nf4 = total >> 2;
+    for (int f = lane; f < nf4; f += 64) {
+        const int e = 4 * f;
+        int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
+        float4 v;
+        float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pv[u] = Ts[r * P + c];
+            if (++c == D) { c = 0; ++r; }
+        }
+        reinterpret_cast<float4*>(gdst)[f] = v;
+    }
+    for (int e = 4 * nf4 + lane; e < total; e += 64) {
+        const int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
+        gdst[e] = Ts[r * P + c];
+    }
+}
+__device__ __forceinline__ void wave_load_rows(float* Ts, const float* gsrc, int P, int D, int nrows, uint32_t invD) {
+    const int lane = threadIdx.x & 63;
+    const int total = nrows * D, nf4 = total >> 2;
+    for (int f = lane; f < nf4; f += 64) {
+        const int e = 4 * f;
+        int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
+        const float4 v = reinterpret_cast<const float4*>(gsrc)[f];
+        const float* pv = reinterpret_cast<const float*>(&v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Ts[r * P + c] = pv[u];
+            if (++c == D) { c = 0; ++r; }
+        }
+    }
+    for (int e = 4 * nf4 + lane; e < total; e += 64) {
+        const int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
+        Ts[r * P + c] = gsrc[e];
+    }
+}
+
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -156,7 +202,7 @@ __device__ __forceinline__ void ln_rows(const float* Xs, float* Ys, int P, const
             const int c = l + 16 * i;
             const float y = (c < D) ? g[i] * ((x[i] - mean) / sd) + b[i] : 0.0f;
             if (c < P) Ys[r * P + c] = y;
-            if (c < D && m < M) yg[(size_t)m * D + c] = y;
+            if (yg && c < D && m < M) yg[(size_t)m * D + c] = y;
             ys += y;
         }
         ys = sum16(ys);
@@ -206,22 +252,31 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
 __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, BlockGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = g.P, D = d.D;
-    float* Os = smem;                       // [64][P]  input tile, reused for the hidden tile after LN2
+    float* Os = smem;                       // [64][P]  input tile, reused for the hidden tile and the output tile
     float* Fs = Os + 64 * P;                // [64][P]
     float* W1s = Fs + 64 * P;               // [4*ks][PW]
     float* W2s = W1s + 4 * g.ks * BK_PW;    // [4*ks][PW]
     float* Hs = Os;
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    load_tile(Os, d.o, D, 0, m0, d.M, D, P, -1);
+    const int mw = m0 + 16 * wave;                                  // first row of this wave
+    const int nr = max(0, min(16, d.M - mw));                       // its valid rows
+    // zero the wave's rows (pad columns / rows must be 0), then stream its rows in
+    for (int e = lane; e < 16 * P; e += 64) Os[16 * wave * P + e] = 0.0f;
+    if (nr > 0) wave_load_rows(Os + 16 * wave * P, d.o + (size_t)mw * D, P, D, nr, g.invD);
     load_w(W1s, BK_PW, d.w1, D, 0, D, 4 * g.ks);
     load_w(W2s, BK_PW, d.w2, D, 0, D, 4 * g.ks);
-    __syncthreads();                        // the only barrier
-    ln_rows(Os, Fs, P, d.ln2_g, d.ln2_b, d.f_in, nullptr, nullptr, m0, d.M, D, wave);        // sasrec.py:81
-    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
+    __syncthreads();                        // the only barrier (weights)
+    if (g.dbg & 1) return;
+    ln_rows(Os, Fs, P, d.ln2_g, d.ln2_b, nullptr, nullptr, nullptr, m0, d.M, D, wave);       // sasrec.py:81
+    if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * P, P, D, nr, g.invD);
+    if (g.dbg & 2) return;
+    DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
+    if (g.dbg & 16) { d1.on = false; d2.on = false; }
+    const int ksx = (g.dbg & 8) ? 0 : g.ks;
     f32x4 acc[4];
     zero_acc(acc);
-    tile_mma(acc, Fs, P, W1s, g.ks, wave);                                                  // modules.py:300-302
+    tile_mma(acc, Fs, P, W1s, ksx, wave);                                                   // modules.py:300-302
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = 16 * j + li;
@@ -233,31 +288,32 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
             if (col < D) {
                 v = fmaxf(acc[j][r] + bias, 0.0f);
                 v = drop_apply(d1, (d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col, v);   // modules.py:303-304
-                if (m < d.M) d.hid[(size_t)m * D + col] = v;
             }
             if (col < P) Hs[row * P + col] = v;
         }
     }
+    if (nr > 0) wave_store_rows(d.hid + (size_t)mw * D, Hs + 16 * wave * P, P, D, nr, g.invD);
+    if (g.dbg & 4) return;
     zero_acc(acc);
-    tile_mma(acc, Hs, P, W2s, g.ks, wave);                                                  // modules.py:306-308
+    tile_mma(acc, Hs, P, W2s, ksx, wave);                                                   // modules.py:306-308
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = 16 * j + li;
-        if (col < D) {
-            const float bias = d.b2[col];
+        const float bias = (col < D) ? d.b2[col] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * wave + 4 * lg + r, m = m0 + row;
-                if (m < d.M) {
-                    float v = acc[j][r] + bias;
-                    v = drop_apply(d2, (d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col, v);   // modules.py:309-310
-                    v += Fs[row * P + col];                                              // modules.py:313
-                    if (d.mask_ids[m] == 0) v = 0.0f;                                    // sasrec.py:83
-                    d.y[(size_t)m * D + col] = v;
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + 4 * lg + r, m = m0 + row;
+            float v = 0.0f;
+            if (col < D && m < d.M) {
+                v = acc[j][r] + bias;
+                v = drop_apply(d2, (d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col, v);   // modules.py:309-310
+                v += Fs[row * P + col];                                                  // modules.py:313
+                if (d.mask_ids[m] == 0) v = 0.0f;                                        // sasrec.py:83
             }
+            if (col < P) Hs[row * P + col] = v;            // the MFMAs above have consumed the wave's Hs rows
         }
     }
+    if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * P, P, D, nr, g.invD);
 }
 
 // =====================================================================================================
@@ -576,6 +632,9 @@ static int block_check(const cr_block_desc* d, BlockGeom* g, const char* who) {
     g->ks = (d->D + 3) / 4;
     g->P = 4 * g->ks + 2;
     g->ones = d->D < 64 ? d->D : -1;
+    g->invD = (uint32_t)(4294967296.0 / d->D) + 1u;
+    const char* e = getenv("CR_BLOCK_DBG");
+    g->dbg = e ? atoi(e) : 0;
     return CR_OK;
 }
 
