@@ -165,11 +165,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-__device__ __forceinline__ float sum16(float v) {        // over the 16 lanes of a row group
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float sum16(float v) { return cr_row16_sum(v); }   // over the 16 lanes of a row group
 
 // LayerNorm of the wave's 16 rows of Xs (modules.py:74-78): 16 lanes per row, 4 rows per pass.
 // Writes y to Ys (LDS, zero beyond D) and to global `yg`; optional row-nonzero flags of x and y.
@@ -249,71 +245,95 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
 }
 
 // ---- F3: LN2 + point-wise feed-forward + residual + mask -----------------------------------------------
+// Pad-tolerant, branch-free element code: tiles have pitch 66 and ALL 64 columns are computed and written to
+// LDS unconditionally -- weights, biases and inputs are zero beyond D, so pad columns come out as exact zeros
+// (relu(0) = 0, dropout(0) = 0) without a single per-lane condition.  Global traffic goes through the
+// wave-contiguous row streams, which know the valid row count.
+#define F3_P 66
+__device__ __forceinline__ void ln_rows_fast(const float* Xs, float* Ys, const float* gam, const float* bet, int D, int wave) {
+    // LayerNorm (modules.py:74-78) of the wave's 16 rows; gam/bet are zero-padded LDS arrays of 64 floats
+    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
+    const float invD = 1.0f / (float)D;
+    float g[4], b[4], in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] = gam[l + 16 * i]; b[i] = bet[l + 16 * i]; in[i] = (l + 16 * i < D) ? 1.0f : 0.0f; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = 16 * wave + 4 * p + sub;
+        float x[4], s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = Xs[r * F3_P + l + 16 * i]; s += x[i]; }        // pad columns hold 0
+        const float mean = sum16(s) * invD;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = (x[i] - mean) * in[i]; v += x[i] * x[i]; }
+        const float rs = 1.0f / sqrtf(sum16(v) * invD + 1e-8f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ys[r * F3_P + l + 16 * i] = g[i] * (x[i] * rs) + b[i];  // pad: 0*.. + 0 = 0
+    }
+}
+
 __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, BlockGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int P = g.P, D = d.D;
-    float* Os = smem;                       // [64][P]  input tile, reused for the hidden tile and the output tile
-    float* Fs = Os + 64 * P;                // [64][P]
-    float* W1s = Fs + 64 * P;               // [4*ks][PW]
+    const int D = d.D;
+    float* Os = smem;                       // [64][66] input tile, reused for the hidden tile and the output tile
+    float* Fs = Os + 64 * F3_P;             // [64][66]
+    float* W1s = Fs + 64 * F3_P;            // [4*ks][PW]
     float* W2s = W1s + 4 * g.ks * BK_PW;    // [4*ks][PW]
+    float* vec = W2s + 4 * g.ks * BK_PW;    // 4 x [64]: gamma2, beta2, b1, b2 (zero padded)
+    float* msk = vec + 256;                 // [64] row mask (sasrec.py:83)
     float* Hs = Os;
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;                                  // first row of this wave
     const int nr = max(0, min(16, d.M - mw));                       // its valid rows
-    // zero the wave's rows (pad columns / rows must be 0), then stream its rows in
-    for (int e = lane; e < 16 * P; e += 64) Os[16 * wave * P + e] = 0.0f;
-    if (nr > 0) wave_load_rows(Os + 16 * wave * P, d.o + (size_t)mw * D, P, D, nr, g.invD);
+    for (int e = lane; e < 16 * F3_P; e += 64) Os[16 * wave * F3_P + e] = 0.0f;
+    if (nr > 0) wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
     load_w(W1s, BK_PW, d.w1, D, 0, D, 4 * g.ks);
     load_w(W2s, BK_PW, d.w2, D, 0, D, 4 * g.ks);
-    __syncthreads();                        // the only barrier (weights)
-    if (g.dbg & 1) return;
-    ln_rows(Os, Fs, P, d.ln2_g, d.ln2_b, nullptr, nullptr, nullptr, m0, d.M, D, wave);       // sasrec.py:81
-    if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * P, P, D, nr, g.invD);
-    if (g.dbg & 2) return;
-    DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
-    if (g.dbg & 16) { d1.on = false; d2.on = false; }
-    const int ksx = (g.dbg & 8) ? 0 : g.ks;
+    {
+        const int t = threadIdx.x, c = t & 63, which = t >> 6;
+        const float* src = which == 0 ? d.ln2_g : (which == 1 ? d.ln2_b : (which == 2 ? d.b1 : d.b2));
+        vec[t] = (c < D) ? src[c] : 0.0f;
+        if (t < 64) msk[t] = (m0 + t < d.M && d.mask_ids[m0 + t] != 0) ? 1.0f : 0.0f;
+    }
+    __syncthreads();                        // the only barrier
+    ln_rows_fast(Os, Fs, vec, vec + 64, D, wave);                                           // sasrec.py:81
+    if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
+    // per-lane hashing bases: idx = (row_offset + m) * D + col
+    uint32_t rb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r] = (d.drop_ffn1.row_offset + (uint32_t)(mw + 4 * lg + r)) * (uint32_t)D + (uint32_t)li;
     f32x4 acc[4];
     zero_acc(acc);
-    tile_mma(acc, Fs, P, W1s, ksx, wave);                                                   // modules.py:300-302
+    tile_mma(acc, Fs, F3_P, W1s, g.ks, wave);                                               // modules.py:300-302
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = 16 * j + li;
-        const float bias = (col < D) ? d.b1[col] : 0.0f;
+        const float bias = vec[128 + 16 * j + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + 4 * lg + r, m = m0 + row;
-            float v = 0.0f;
-            if (col < D) {
-                v = fmaxf(acc[j][r] + bias, 0.0f);
-                v = drop_apply(d1, (d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col, v);   // modules.py:303-304
-            }
-            if (col < P) Hs[row * P + col] = v;
+            float v = fmaxf(acc[j][r] + bias, 0.0f);
+            if (d1.on) v *= (cr_fmix32((rb[r] + 16u * j) * 0x9E3779B1u + d1.key) >= d1.thresh) ? d1.scale : 0.0f;   // modules.py:303-304
+            Hs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = v;
         }
     }
-    if (nr > 0) wave_store_rows(d.hid + (size_t)mw * D, Hs + 16 * wave * P, P, D, nr, g.invD);
-    if (g.dbg & 4) return;
+    if (nr > 0) wave_store_rows(d.hid + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
     zero_acc(acc);
-    tile_mma(acc, Hs, P, W2s, ksx, wave);                                                   // modules.py:306-308
+    tile_mma(acc, Hs, F3_P, W2s, g.ks, wave);                                               // modules.py:306-308
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = 16 * j + li;
-        const float bias = (col < D) ? d.b2[col] : 0.0f;
+        const float bias = vec[192 + 16 * j + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + 4 * lg + r, m = m0 + row;
-            float v = 0.0f;
-            if (col < D && m < d.M) {
-                v = acc[j][r] + bias;
-                v = drop_apply(d2, (d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col, v);   // modules.py:309-310
-                v += Fs[row * P + col];                                                  // modules.py:313
-                if (d.mask_ids[m] == 0) v = 0.0f;                                        // sasrec.py:83
-            }
-            if (col < P) Hs[row * P + col] = v;            // the MFMAs above have consumed the wave's Hs rows
+            const int row = 16 * wave + 4 * lg + r;
+            float v = acc[j][r] + bias;
+            if (d2.on) v *= (cr_fmix32((rb[r] + 16u * j) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;   // modules.py:309-310
+            v = (v + Fs[row * F3_P + 16 * j + li]) * msk[row];                               // modules.py:313, sasrec.py:83
+            Hs[row * F3_P + 16 * j + li] = v;              // the MFMAs above have consumed the wave's Hs rows
         }
     }
-    if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * P, P, D, nr, g.invD);
+    if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
 }
 
 // =====================================================================================================
@@ -670,7 +690,7 @@ extern "C" int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (2 * 64 * g.P + 2 * 4 * g.ks * BK_PW);
+    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 2 * 4 * g.ks * BK_PW + 256 + 64);
     hipLaunchKernelGGL(k_block_ln_ffn_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
     return cr_check_launch("cr_block_ln_ffn_fwd");
 }

@@ -71,4 +71,20 @@ __device__ __forceinline__ float drop_apply(const DropCtx& c, uint32_t idx, floa
     return c.on ? (cr_keep(c.key, idx, c.thresh) ? v * c.scale : 0.0f) : v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15) with four DPP adds (quad xor 1, quad xor 2,
+// row_half_mirror, row_mirror) instead of four ds_bpermute round trips (__shfl_xor): every lane ends up
+// with the row total.  The association differs from a shuffle butterfly only in order.
+template <int CTRL>
+__device__ __forceinline__ float cr_dpp_add(float v) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(x);
+}
+__device__ __forceinline__ float cr_row16_sum(float v) {
+    v = cr_dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = cr_dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = cr_dpp_add<0x141>(v);    // row_half_mirror
+    v = cr_dpp_add<0x140>(v);    // row_mirror
+    return v;
+}
+
 static inline int cr_ceil_div(int a, int b) { return (a + b - 1) / b; }

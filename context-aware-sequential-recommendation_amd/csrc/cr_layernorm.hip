@@ -6,6 +6,7 @@
 
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
+    if (LPR == 16) return cr_row16_sum(v);
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
