@@ -106,6 +106,28 @@ def kernel_profile(eng, staged, n_steps=8):
     return per_launch, by_name
 
 
+KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd"], "cr_attn_bwd": ["k_attn_bwd_q", "k_attn_bwd_kv"],
+              "cr_layernorm_fwd": ["k_ln_fwd"], "cr_layernorm_bwd": ["k_ln_bwd"], "cr_adam_step": ["k_adam"],
+              "cr_head_fwd_bwd": ["k_head"], "cr_embed_fwd": ["k_embed_fwd"], "cr_embed_bwd": ["k_embed_bwd"]}
+
+
+def pmc_traffic(abi_name):
+    """HBM bytes per launch of the device kernels behind a C-ABI entry, from the committed rocprofv3 --pmc
+    summary of this same command (profiles/*_pmc_summary.json, tools/pmc_summary.py); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, "n/a"
+    with open(files[-1]) as f:
+        summ = json.load(f)
+    want = KERNELS_OF.get(abi_name, ["k_" + abi_name[3:]])
+    tot, hit = 0, 0
+    for k, e in summ.items():
+        if any(k.startswith(w) for w in want):
+            tot += e["hbm_traffic_bytes"]; hit += 1
+    return (tot if hit else None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(args, batches, usernum, itemnum, budget_s=20.0):
     """The oracle's torch-CPU restatement of the same training step (fp32, all host threads)."""
     from oracle import fpmodel as fm
@@ -238,11 +260,14 @@ def main():
             achieved = d["flops"] / (d["us"] * 1e-6) / 1e12
         else:
             achieved = d["bytes"] / (d["us"] * 1e-6) / 1e9
+        traffic, src = pmc_traffic(name)
         roofline = dict(kernel=name, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 5), traffic=None, launches_per_step=d["launches"],
-                        us_per_step=round(d["us"], 2),
-                        note="achieved = algorithmic %s of all %d launches of this kernel in one step / their summed HIP-event "
-                             "durations (eager instrumented pass, 8 steps)" % ("flops" if bound == "mfma" else "bytes", d["launches"]))
+                        frac=round(achieved / peak, 5), traffic=traffic, launches_per_step=d["launches"],
+                        us_per_launch=round(d["us"] / d["launches"], 2),
+                        algorithmic_per_launch=(d["flops"] if bound == "mfma" else d["bytes"]) / d["launches"],
+                        note="achieved = algorithmic %s per launch / average HIP-event duration of its %d launches per step "
+                             "(eager instrumented pass, 8 steps); traffic = HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB "
+                             "from %s" % ("flops" if bound == "mfma" else "bytes", d["launches"], src))
         if args.profile_json:
             with open(args.profile_json, "w") as f:
                 json.dump(dict(per_launch=per_launch, by_name=by_name, n_launches=eng.n_launches()), f, indent=1, default=str)
