@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     }
     __syncthreads();
     const uint64_t kbits = key_bits<NKT>(kv, T);
+    const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
     float* Qw = Qs + wave * 16 * g.PA;
     const int nwaves = gridDim.y * nw;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         f32x4 st[NKT];
         float m2, inv;
         bool uniform;
-        score_rows<NKT, NDS>(g, Ks, qf, kbits, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
         const float qvq = qv[q];
         const bool live = !uniform && !is_dead && (q < T);
         const float wq = live ? qvq : 0.0f;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kt <= qt) {
+            if (kt >= kt_first && kt <= qt) {                // below kt_first every probability is 0 (uniform rows have dS = 0)
                 acc = mma_tile_frag<NDS>(Vs + 16 * kt * g.PA, g.PA, dof);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         f32x4 acc[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma_prob_rows<NKT, NDT>(st, Ks, g.PA, qt + 1, acc);
+        mma_prob_rows<NKT, NDT>(st, Ks, g.PA, kt_first, qt + 1, acc);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
 #pragma unroll
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
         stage_rows(Kw, g.PA, d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, 16, 0, 1);
         load_frag<NDS>(Kw, g.PA, vf);
         const bool kvk = (key < T) && (d.k_valid[base_row + (key < T ? key : 0)] != 0.0f);
+        const bool tile_has_key = __any(kvk ? 1 : 0) != 0;      // all-padding key tile: only uniform rows reach it
         f32x4 dk[NDT], dv[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
 #pragma unroll 1
         for (int qt = 0; qt < g.nkt; ++qt) {
             if (tile_live[qt] == 0.0f) continue;                          // nothing flows through dead query tiles
-            if (qt < kt && tile_uni[qt] == 0.0f) continue;                // causal skip (uniform rows see all keys)
+            if ((qt < kt || !tile_has_key) && tile_uni[qt] == 0.0f) continue;   // causal / padding skip (uniform rows see all keys)
             const f32x4 s_acc = mma_tile_frag<NDS>(Qs + 16 * qt * g.PA, g.PA, kf);   // S[q][key]
             const f32x4 p_acc = mma_tile_frag<NDS>(Os + 16 * qt * g.PA, g.PA, vf);   // dP[q][key]
             float pa[4], pd[4];

@@ -125,20 +125,36 @@ __device__ __forceinline__ uint64_t key_bits(const float* kv, int T) {
     return bits;
 }
 
+// first 16-key tile that holds a valid key (wave-uniform); NKT if none.  Left-padded sequences make the
+// first tiles all-invalid: their probabilities are exactly 0, so their MFMAs are skipped.
+template <int NKT>
+__device__ __forceinline__ int first_valid_tile(uint64_t kbits) {
+    // a tile's 16 keys are spread over the 4 lane groups: OR the per-lane bits across lg with two shuffles
+    uint32_t lo = (uint32_t)kbits, hi = (uint32_t)(kbits >> 32);
+    lo |= __shfl_xor(lo, 16, 64); lo |= __shfl_xor(lo, 32, 64);
+    hi |= __shfl_xor(hi, 16, 64); hi |= __shfl_xor(hi, 32, 64);
+    const uint64_t all = ((uint64_t)hi << 32) | lo;
+    int t = NKT;
+#pragma unroll
+    for (int kt = NKT - 1; kt >= 0; --kt)
+        if ((all >> (4 * kt)) & 0xFull) t = kt;
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
 // Score row block of one 16-query tile.  On return st[kt][r] = SOFTMAX probability (before query mask /
 // dropout) of key 16*kt + 4*lg + r for query q0 + li; m2 = row max in base-2 exponent units,
 // inv = 1/sum; `uniform` marks rows with no valid key.
 template <int NKT, int NDS>
 __device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, const float (&qf)[NDS], uint64_t kbits,
-                                           int qt, int T, bool is_dead, bool q_in_range, f32x4 (&st)[NKT], float& m2,
-                                           float& inv, bool& uniform) {
+                                           int kt_lo, int qt, int T, bool is_dead, bool q_in_range, f32x4 (&st)[NKT],
+                                           float& m2, float& inv, bool& uniform) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     float mx = -INFINITY;
     const float c2 = is_dead ? 0.0f : g.isd_log2e;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         f32x4 acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (kt <= qt) {                                                          // wave-uniform
+        if (kt >= kt_lo && kt <= qt) {                                           // wave-uniform; tiles below kt_lo hold no valid key
             acc = mma_tile_frag<NDS>(Ks + 16 * kt * g.PA, g.PA, qf);             // St tile (modules.py:216)
             const bool below_diag = kt < qt;
 #pragma unroll
@@ -158,7 +174,7 @@ __device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, c
     float sum = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        if (kt <= qt) {
+        if (kt >= kt_lo && kt <= qt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __builtin_amdgcn_exp2f(st[kt][r] - off);   // v_exp_f32; exp2(-inf) = 0 for masked entries
@@ -187,12 +203,12 @@ __device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, c
 // out[q][16 cols] tiles: acc[jt] += sum over keys of st[kt][r] * Bs[key][16*jt + li]  (B-pattern reads,
 // one batch of 4*NDT operands per key tile ahead of its 4*NDT MFMAs)
 template <int NKT, int NDT>
-__device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const float* Bs, int pb, int kt_end, f32x4 (&acc)[NDT]) {
+__device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const float* Bs, int pb, int kt_lo, int kt_end, f32x4 (&acc)[NDT]) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const float* bp = Bs + (4 * lg) * pb + li;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        if (kt < kt_end) {
+        if (kt >= kt_lo && kt < kt_end) {
             float b[4][NDT];
 #pragma unroll
             for (int r = 0; r < 4; ++r)

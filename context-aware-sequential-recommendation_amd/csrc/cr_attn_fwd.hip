@@ -24,6 +24,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     }
     __syncthreads();
     const uint64_t kbits = key_bits<NKT>(kv, T);
+    const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
     float* Qw = Qs + wave * 16 * g.PA;
     const int nwaves = gridDim.y * nw;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         f32x4 st[NKT];
         float m2, inv;
         bool uniform;
-        score_rows<NKT, NDS>(g, Ks, qf, kbits, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
         const float qvq = qv[q];
         const bool any_uni = __any(uniform ? 1 : 0) != 0;
         const uint32_t ridx = attn_row_idx(d, head, n, q);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         f32x4 acc[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma_prob_rows<NKT, NDT>(st, Vs, g.PB, any_uni ? g.nkt : qt + 1, acc);        // modules.py:262
+        mma_prob_rows<NKT, NDT>(st, Vs, g.PB, any_uni ? 0 : kt_first, any_uni ? g.nkt : qt + 1, acc);   // modules.py:262
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
 #pragma unroll
