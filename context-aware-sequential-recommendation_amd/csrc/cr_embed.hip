@@ -100,6 +100,32 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
     for (int i = threadIdx.x; i < n; i += 256) slab[i] = tab[i];
 }
 
+// Large table without a positional-table gradient (static sinusoid graphs, context-free inputs): nothing
+// couples the rows, so the scatter-add runs row-parallel with 16 lanes per row (D <= 64) instead of one
+// workgroup per position.
+__global__ __launch_bounds__(256) void k_embed_bwd_rows16(cr_embed_bwd_desc bd) {
+    const cr_embed_desc& d = bd.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, l = lane & 15;
+    const DropCtx dc = drop_ctx(d.drop);
+    for (int mb = (blockIdx.x * 4 + wave) * 4; mb < d.M; mb += gridDim.x * 16) {
+        const int m = mb + sub;
+        if (m >= d.M) continue;
+        const int id = d.ids[m];
+        const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
+        const bool skip_table = (d.zero_pad && id == 0) || bd.table_grad == nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = l + 16 * i;
+            if (c < d.D) {
+                float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
+                g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
+                if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
+                if (!skip_table && g != 0.0f) atomicAdd(bd.table_grad + (size_t)id * d.D + c, g * d.scale);
+            }
+        }
+    }
+}
+
 extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd && bd->f.ids && bd->f.out, "cr_embed_bwd: NULL pointer");
     const cr_embed_desc* d = &bd->f;
@@ -112,6 +138,12 @@ extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
         return cr_check_launch("cr_embed_bwd(small)");
     }
     if (d->D > 64 * EMB_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_embed_bwd: D=%d > %d", d->D, 64 * EMB_MAXC);
+    if (bd->pos_grad == nullptr && d->D <= 64) {
+        int grid = cr_ceil_div(d->M, 16);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(k_embed_bwd_rows16, dim3(grid), dim3(256), 0, cr_stream(stream), *bd);
+        return cr_check_launch("cr_embed_bwd(rows)");
+    }
     hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(256), 0, cr_stream(stream), *bd);
     return cr_check_launch("cr_embed_bwd");
 }

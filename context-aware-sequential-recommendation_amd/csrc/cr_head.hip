@@ -6,31 +6,43 @@
 
 #include "cr_common.hpp"
 
-#define HEAD_MAXC 8
+// Row mapping as in cr_layernorm.hip: hidden sizes <= 64 give a row 16 lanes (4 rows per wave in flight,
+// DPP row sums); larger ones a whole wave.
+template <int LPR>
+__device__ __forceinline__ float head_row_sum(float v) {
+    if (LPR == 16) return cr_row16_sum(v);
+    return wave_sum(v);
+}
 
+template <int LPR, int MAXC>
 __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
-    __shared__ float red[3][4];
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red[3][4 * RPW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
     float loss_acc = 0.0f, auc_acc = 0.0f, n_acc = 0.0f;
-    for (int m = blockIdx.x * 4 + wave; m < d.M; m += gridDim.x * 4) {
-        const int p = d.pos[m], ng = d.neg[m];
-        float s[HEAD_MAXC], ep[HEAD_MAXC], en[HEAD_MAXC];
+    for (int mb = (blockIdx.x * 4 + wave) * RPW; mb < d.M; mb += gridDim.x * 4 * RPW) {
+        const int m = mb + sub;
+        const bool act = m < d.M;
+        const int mm = act ? m : d.M - 1;
+        const int p = act ? d.pos[mm] : 0, ng = act ? d.neg[mm] : 0;
+        float s[MAXC], ep[MAXC], en[MAXC];
         float pl = 0.0f, nl = 0.0f;
 #pragma unroll
-        for (int i = 0; i < HEAD_MAXC; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
             const bool ok = c < d.D;
-            s[i] = ok ? d.seq_emb[(size_t)m * d.ld + c] : 0.0f;
+            s[i] = ok ? d.seq_emb[(size_t)mm * d.ld + c] : 0.0f;
             ep[i] = (ok && p != 0) ? d.table[(size_t)p * d.D + c] : 0.0f;      // row 0 == zeros (modules.py:154-156)
             en[i] = (ok && ng != 0) ? d.table[(size_t)ng * d.D + c] : 0.0f;
             pl += ep[i] * s[i];
             nl += en[i] * s[i];
         }
-        pl = wave_sum(pl);                                                     // sasrec.py:100
-        nl = wave_sum(nl);                                                     // sasrec.py:101
+        pl = head_row_sum<LPR>(pl);                                            // sasrec.py:100
+        nl = head_row_sum<LPR>(nl);                                            // sasrec.py:101
         const float ist = (p != 0) ? 1.0f : 0.0f;                              // sasrec.py:104
         const float sp = 1.0f / (1.0f + expf(-pl)), sn = 1.0f / (1.0f + expf(-nl));
-        if (lane == 0) {
+        if (l == 0 && act) {
             loss_acc += ist * (-logf(sp + 1e-24f) - logf(1.0f - sn + 1e-24f)); // sasrec.py:105-108
             const float dlt = pl - nl;
             const float sg = (dlt > 0.0f) ? 1.0f : ((dlt < 0.0f) ? -1.0f : 0.0f);
@@ -39,13 +51,13 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
             if (d.pos_logits) d.pos_logits[m] = pl;
             if (d.neg_logits) d.neg_logits[m] = nl;
         }
-        if (d.d_seq_emb || d.table_grad) {
+        if (act && (d.d_seq_emb || d.table_grad)) {
             // d/dpl [-log(sig(pl)+e)] = -sig(1-sig)/(sig+e);  d/dnl [-log(1-sig(nl)+e)] = sig(1-sig)/(1-sig+e)
             const float dpl = -ist * sp * (1.0f - sp) / (sp + 1e-24f);
             const float dnl = ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f);
 #pragma unroll
-            for (int i = 0; i < HEAD_MAXC; ++i) {
-                const int c = lane + 64 * i;
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = l + LPR * i;
                 if (c < d.D) {
                     if (d.d_seq_emb) d.d_seq_emb[(size_t)m * d.ldd + c] = dpl * ep[i] + dnl * en[i];
                     if (d.table_grad && ist != 0.0f) {
@@ -56,10 +68,11 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
             }
         }
     }
-    if (lane == 0) { red[0][wave] = loss_acc; red[1][wave] = auc_acc; red[2][wave] = n_acc; }
+    if (l == 0) { red[0][wave * RPW + sub] = loss_acc; red[1][wave * RPW + sub] = auc_acc; red[2][wave * RPW + sub] = n_acc; }
     __syncthreads();
     if (threadIdx.x < 3) {
-        const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        float v = 0.0f;
+        for (int i = 0; i < 4 * RPW; ++i) v += red[threadIdx.x][i];
         if (v != 0.0f) atomicAdd(d.state + threadIdx.x, v);
     }
 }
@@ -67,10 +80,16 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
 extern "C" int cr_head_fwd_bwd(const cr_head_desc* d, void* stream) {
     CR_REQUIRE(d && d->seq_emb && d->table && d->pos && d->neg && d->state, "cr_head_fwd_bwd: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->D > 0 && d->V > 0 && d->ld >= d->D, "cr_head_fwd_bwd: bad shape");
-    if (d->D > 64 * HEAD_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd: D=%d > %d", d->D, 64 * HEAD_MAXC);
-    int grid = cr_ceil_div(d->M, 4);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_head, dim3(grid), dim3(256), 0, cr_stream(stream), *d);
+    if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd: D=%d > 512", d->D);
+    if (d->D <= 64) {
+        int grid = cr_ceil_div(d->M, 16);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL((k_head<16, 4>), dim3(grid), dim3(256), 0, cr_stream(stream), *d);
+    } else {
+        int grid = cr_ceil_div(d->M, 4);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL((k_head<64, 8>), dim3(grid), dim3(256), 0, cr_stream(stream), *d);
+    }
     return cr_check_launch("cr_head_fwd_bwd");
 }
 

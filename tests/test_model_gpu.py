@@ -115,9 +115,11 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
         # one Adam step moves a weight by ~lr = 1e-3; m/(sqrt(v)+eps) is ill-conditioned where |g| ~ eps, so the
         # bound is 10% of a step (the Adam kernel itself is checked to 1e-6 in test_ops_gpu.py)
         assert worst[0] < 1e-4, worst
+        # continue from the engine's parameters so step 2 compares gradients at identical points (the allowed
+        # 1e-4 Adam differences would otherwise show up as 1e-4 activation differences)
         for k in P:
+            P[k] = now[k].cpu().double()
             if k.endswith(".bk"):
-                P[k] = now[k].cpu().double()
                 opt.m[k].zero_(); opt.v[k].zero_()
         off = eng.layout
         for k in P:
@@ -126,6 +128,36 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
         loss, auc = eng.loss_auc()
         assert loss == pytest.approx(float(out["loss"]), rel=2e-5)
         P = {k: v.detach() for k, v in P.items()}
+
+
+@pytest.mark.parametrize("model,D,H,T,L", [("sasrec", 64, 2, 50, 2),      # BASELINE config 3 shape (Beauty: D=64, 2 heads)
+                                           ("cast_2", 64, 2, 24, 1),
+                                           ("sasrec", 128, 4, 40, 2),     # config 4 shape (Books: D=128, 4 heads) -> unfused path
+                                           ("cast_9", 128, 4, 24, 1)])
+def test_other_baseline_shapes_match_oracle(E, model, D, H, T, L):
+    rs = np.random.RandomState(D + T)
+    B, itemnum, max_bins = 3, 41, 9
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
+                 num_context_blocks=1, lr=1e-3, seed=11)
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
+                   num_context_blocks=1, lr=1e-3)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=5)
+    assert eng.fused == (D <= 64)
+    P = fm.init_params(model, 9, itemnum, ohp, seed=8)
+    P = {k: v + 0.05 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
+    eng.load_params(P)
+    P = {k: v.double().cpu() for k, v in eng.get_params().items()}
+    seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, max_bins)
+    out, G = fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), oracle_drop(E, 11, 1, 0.1, B, T, H))
+    eng.set_batch(seq, pos, neg, time, hours, days)
+    eng.launch_step(apply=False)
+    torch.cuda.synchronize()
+    st = eng.state.cpu().numpy()
+    assert st[0] / st[2] == pytest.approx(float(out["loss"]), rel=2e-5)
+    got = eng.grads()
+    gmax = max(float(G[k].abs().max()) for k in G)
+    worst = max((float((got[k].cpu().double() - G[k]).abs().max()) / max(float(G[k].abs().max()), 1e-3 * gmax), k) for k in G)
+    assert worst[0] < 2e-4, worst
 
 
 @pytest.mark.parametrize("model", ["sasrec", "cast_1", "cast_5", "cast_8"])
