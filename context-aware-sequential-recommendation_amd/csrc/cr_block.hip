@@ -122,7 +122,8 @@ __device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, co
 // a 16-byte-per-lane stream (full cache lines) instead of 4-byte lanes on 4*D-byte row segments.
 __device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, int P, int D, int nrows, uint32_t invD) {
     const int lane = threadIdx.x & 63;
-    const int total = nrows * D, nf4 = total >> 2;
+    const int total = nrows * D;
+    const int nf4 = ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) ? (total >> 2) : 0;   // vector path needs 16-B alignment
     for (int f = lane; f < nf4; f += 64) {
         const int e = 4 * f;
         int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
@@ -142,7 +143,8 @@ __device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, in
 }
 __device__ __forceinline__ void wave_load_rows(float* Ts, const float* gsrc, int P, int D, int nrows, uint32_t invD) {
     const int lane = threadIdx.x & 63;
-    const int total = nrows * D, nf4 = total >> 2;
+    const int total = nrows * D;
+    const int nf4 = ((reinterpret_cast<uintptr_t>(gsrc) & 15) == 0) ? (total >> 2) : 0;
     for (int f = lane; f < nf4; f += 64) {
         const int e = 4 * f;
         int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
@@ -205,41 +207,6 @@ __device__ __forceinline__ void ln_rows(const float* Xs, float* Ys, int P, const
         if (l == 0 && m < M) {
             if (x_nz) x_nz[m] = (s != 0.0f) ? 1.0f : 0.0f;
             if (y_nz) y_nz[m] = (ys != 0.0f) ? 1.0f : 0.0f;
-        }
-    }
-}
-
-// ---- F1: LN1 + Q/K/V projections --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int P = g.P, D = d.D;
-    float* Xs = smem;                       // [64][P]
-    float* Qs = Xs + 64 * P;                // [64][P]
-    float* Ws = Qs + 64 * P;                // 3 x [4*ks][PW]: Wq, Wk, Wv (k rows beyond D are zero)
-    const int wsz = 4 * g.ks * BK_PW;
-    const int m0 = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    load_tile(Xs, d.x, D, 0, m0, d.M, D, P, -1);
-#pragma unroll 1
-    for (int part = 0; part < 3; ++part) load_w(Ws + part * wsz, BK_PW, d.wqkv, 3 * D, part * D, D, 4 * g.ks);
-    __syncthreads();                        // the only barrier: from here on a wave touches only rows it owns
-    ln_rows(Xs, Qs, P, d.ln1_g, d.ln1_b, d.q_in, d.k_valid, d.q_valid, m0, d.M, D, wave);   // sasrec.py:69; masks modules.py:222,248
-#pragma unroll 1
-    for (int part = 0; part < 3; ++part) {                                                  // modules.py:203-205
-        f32x4 acc[4];
-        zero_acc(acc);
-        tile_mma(acc, part == 0 ? Qs : Xs, P, Ws + part * wsz, g.ks, wave);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = 16 * j + li;
-            if (col < D) {
-                const float bias = d.bqkv[part * D + col];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * wave + 4 * lg + r;
-                    if (m < d.M) d.qkv[(size_t)m * 3 * D + part * D + col] = acc[j][r] + bias;
-                }
-            }
         }
     }
 }
@@ -336,22 +303,118 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
 }
 
+// ---- F1: LN1 + Q/K/V projections --------------------------------------------------------------------
+// Q, K, V are stored as three dense [M, D] matrices ([3, M, D]) so each wave's 16 output rows of each are one
+// contiguous block.
+__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = d.D;
+    float* Xs = smem;                       // [64][66]
+    float* Qs = Xs + 64 * F3_P;             // [64][66] LN1 output, then staging of each projection's result
+    float* Ws = Qs + 64 * F3_P;             // 3 x [4*ks][PW]: Wq, Wk, Wv
+    const int wsz = 4 * g.ks * BK_PW;
+    float* vec = Ws + 3 * wsz;              // 5 x [64]: gamma1, beta1, bq, bk, bv (zero padded)
+    const int m0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int mw = m0 + 16 * wave;
+    const int nr = max(0, min(16, d.M - mw));
+    for (int e = lane; e < 16 * F3_P; e += 64) Xs[16 * wave * F3_P + e] = 0.0f;
+    if (nr > 0) wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) load_w(Ws + part * wsz, BK_PW, d.wqkv, 3 * D, part * D, D, 4 * g.ks);
+    for (int t = threadIdx.x; t < 320; t += 256) {
+        const int c = t & 63, which = t >> 6;
+        const float* src = which == 0 ? d.ln1_g : (which == 1 ? d.ln1_b : d.bqkv + (which - 2) * D);
+        vec[t] = (c < D) ? src[c] : 0.0f;
+    }
+    __syncthreads();                        // the only barrier
+    // LN1 with the data-dependent key / query masks (modules.py:222,248-249)
+    {
+        const int l = lane & 15, sub = lane >> 4;
+        const float invD = 1.0f / (float)D;
+        float gm[4], bt[4], in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gm[i] = vec[l + 16 * i]; bt[i] = vec[64 + l + 16 * i]; in[i] = (l + 16 * i < D) ? 1.0f : 0.0f; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 16 * wave + 4 * p + sub, m = m0 + r;
+            float x[4], s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = Xs[r * F3_P + l + 16 * i]; s += x[i]; }
+            s = sum16(s);
+            const float mean = s * invD;
+            float v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = (x[i] - mean) * in[i]; v += x[i] * x[i]; }
+            const float rs = 1.0f / sqrtf(sum16(v) * invD + 1e-8f);
+            float ys = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float y = gm[i] * (x[i] * rs) + bt[i]; Qs[r * F3_P + l + 16 * i] = y; ys += y; }
+            ys = sum16(ys);
+            if (l == 0 && m < d.M) {
+                d.k_valid[m] = (s != 0.0f) ? 1.0f : 0.0f;
+                d.q_valid[m] = (ys != 0.0f) ? 1.0f : 0.0f;
+            }
+        }
+    }
+    if (nr > 0) wave_store_rows(d.q_in + (size_t)mw * D, Qs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {                                                  // modules.py:203-205
+        f32x4 acc[4];
+        zero_acc(acc);
+        tile_mma(acc, part == 0 ? Qs : Xs, F3_P, Ws + part * wsz, g.ks, wave);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bias = vec[128 + 64 * part + 16 * j + li];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Qs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = acc[j][r] + bias;
+        }
+        if (nr > 0) wave_store_rows(d.qkv + ((size_t)part * d.M + mw) * D, Qs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    }
+}
+
 // =====================================================================================================
 // backward
 // =====================================================================================================
-// the wave's 16 rows of a [M, ld] matrix -> its rows of a tile (no block barrier needed)
-__device__ __forceinline__ void load_rows_wave(float* dst, int P, const float* src, int ld, int c0, int m0, int m_end, int D, int wave) {
+// A wave's 16 rows x D floats as <= 4 float4 per lane (D <= 64): fetched early, placed into LDS later.
+struct Stream4 { float4 v[4]; };
+__device__ __forceinline__ void stream_fetch(Stream4& s, const float* gsrc, int total) {
     const int lane = threadIdx.x & 63;
-    float v[16];
+    const bool vec = (reinterpret_cast<uintptr_t>(gsrc) & 15) == 0;     // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = m0 + 16 * wave + i;
-        v[i] = (m < m_end && lane < D) ? src[(size_t)m * ld + c0 + lane] : 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        const int f = lane + 64 * i;
+        s.v[i] = (vec && 4 * f + 3 < total) ? reinterpret_cast<const float4*>(gsrc)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * f < total && (!vec || 4 * f + 3 >= total)) {   // unaligned base or ragged tail: element-wise
+            float* pv = reinterpret_cast<float*>(&s.v[i]);
+            for (int u = 0; u < 4; ++u) pv[u] = (4 * f + u < total) ? gsrc[4 * f + u] : 0.0f;
+        }
     }
-    if (lane < P) {
+}
+// place the stream into the wave's rows of a pitch-66 tile; `scale_fn(e, v)` maps flat element e -> value
+template <class F>
+__device__ __forceinline__ void stream_put(float* Ts, const Stream4& s, int D, int total, uint32_t invD, F fn) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[(16 * wave + i) * P + lane] = v[i];
+    for (int i = 0; i < 4; ++i) {
+        const int e0 = 4 * (lane + 64 * i);
+        if (e0 < total) {
+            int r = (int)__umulhi((uint32_t)e0, invD), c = e0 - r * D;
+            const float* pv = reinterpret_cast<const float*>(&s.v[i]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + u < total) Ts[r * F3_P + c] = fn(e0 + u, r, pv[u]);
+                if (++c == D) { c = 0; ++r; }
+            }
+        }
     }
+}
+struct PutPlain { __device__ __forceinline__ float operator()(int, int, float v) const { return v; } };
+
+// zero the wave's 16 rows of a tile (pad columns / rows beyond the valid count must read as 0)
+__device__ __forceinline__ void zero_rows(float* Ts) {
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < 16 * F3_P; e += 64) Ts[e] = 0.0f;
 }
 
 // strip of a [D,D] weight gradient held as (wave, lg, r) x (j, li) accumulators -> slab (row pitch ldw);
@@ -365,65 +428,55 @@ __device__ __forceinline__ void store_wgrad(float* dst, int ldw, float* bias_dst
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * wave + 4 * lg + r;
             if (col < D) {
-                if (k < D) dst[(size_t)k * ldw + col] = accw[j][r];
+                if (k < D) dst[k * ldw + col] = accw[j][r];
                 else if (k == ones) bias_dst[col] = accw[j][r];
             }
         }
     }
 }
 
-__device__ __forceinline__ float colsum64(const float* Ts, int P) {     // D == 64 fallback: thread tid < 64 sums column tid
+__device__ __forceinline__ float colsum64(const float* Ts) {     // D == 64 fallback: thread tid < 64 sums column tid
     float s = 0.0f;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += Ts[r * P + threadIdx.x];
+    for (int r = 0; r < 64; ++r) s += Ts[r * F3_P + threadIdx.x];
     return s;
 }
 
-// LayerNorm backward on the wave's 16 rows (row layout, 16 lanes per row): x from Xs, incoming gradient
-// from DYs, optional extra addend ADs (already-computed part of dx).  Accumulates dgamma / dbeta partials.
-__device__ __forceinline__ void ln_bwd_rows(const float* Xs, const float* DYs, const float* ADs, int P, const float (&g)[4],
-                                            float (&ag)[4], float (&ab)[4], float* dxg, int accumulate, int m0, int m_end,
-                                            int D, int wave) {
+// LayerNorm backward on the wave's 16 rows, in place: DYs rows hold dy on entry and dx on exit
+// (dx = rstd*(dy*g - c1 - xhat*c2) [+ ADs]).  Accumulates dgamma / dbeta partials.  x from Xs (pad columns 0).
+__device__ __forceinline__ void ln_bwd_rows(const float* Xs, float* DYs, const float* ADs, const float* gam,
+                                            float (&ag)[4], float (&ab)[4], int D, int wave) {
     const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
     const float invD = 1.0f / (float)D;
+    float g[4], in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] = gam[l + 16 * i]; in[i] = (l + 16 * i < D) ? 1.0f : 0.0f; }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int r = 16 * wave + 4 * p + sub, m = m0 + r;
+        const int r = 16 * wave + 4 * p + sub;
         float x[4], dy[4], s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool in = l + 16 * i < D;
-            x[i] = in ? Xs[r * P + l + 16 * i] : 0.0f;
-            dy[i] = in ? DYs[r * P + l + 16 * i] : 0.0f;
-            s += x[i];
-        }
+        for (int i = 0; i < 4; ++i) { x[i] = Xs[r * F3_P + l + 16 * i] * in[i]; dy[i] = DYs[r * F3_P + l + 16 * i] * in[i]; s += x[i]; }
         const float mean = sum16(s) * invD;
         float v = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float dx = (l + 16 * i < D) ? x[i] - mean : 0.0f; v += dx * dx; }
+        for (int i = 0; i < 4; ++i) { x[i] = (x[i] - mean) * in[i]; v += x[i] * x[i]; }
         const float rstd = 1.0f / sqrtf(sum16(v) * invD + 1e-8f);
         float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float xh = (l + 16 * i < D) ? (x[i] - mean) * rstd : 0.0f;
-            x[i] = xh;
+            x[i] *= rstd;
             const float dg = dy[i] * g[i];
-            c1 += dg; c2 += dg * xh;
-            if (m < m_end) { ag[i] += dy[i] * xh; ab[i] += dy[i]; }
+            c1 += dg; c2 += dg * x[i];
+            ag[i] += dy[i] * x[i]; ab[i] += dy[i];                 // rows beyond the valid count hold dy = 0
         }
         c1 = sum16(c1) * invD;
         c2 = sum16(c2) * invD;
-        if (m < m_end) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = l + 16 * i;
-                if (c < D) {
-                    float dx = rstd * (dy[i] * g[i] - c1 - x[i] * c2);
-                    if (ADs) dx += ADs[r * P + c];
-                    float* pp = dxg + (size_t)m * D + c;
-                    *pp = accumulate ? (*pp + dx) : dx;
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            float dx = rstd * (dy[i] * g[i] - c1 - x[i] * c2) * in[i];
+            if (ADs) dx += ADs[r * F3_P + l + 16 * i];
+            DYs[r * F3_P + l + 16 * i] = dx;
         }
     }
 }
@@ -452,107 +505,113 @@ __device__ __forceinline__ int rows_per_wg(int M, int nwg) {       // multiple o
     return (rps + 63) / 64 * 64;
 }
 
-// B3 staging: gradient wrt the FFN2 pre-dropout output, g2 = dy * mask * keep/(1-rate) (sasrec.py:83, modules.py:309-310)
-__device__ __forceinline__ void fetch_g2(float (&v)[16], const cr_block_bwd_desc& bd, const DropCtx& d2, int m0, int m_end) {
-    const cr_block_desc& d = bd.f;
-    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63, D = d.D;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = m0 + tr + 4 * i;
-        float x = 0.0f;
-        if (m < m_end && tc < D) {
-            x = bd.dy[(size_t)m * D + tc];
-            if (d.mask_ids[m] == 0) x = 0.0f;
-            x = drop_apply(d2, (d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)tc, x);
-        }
-        v[i] = x;
-    }
+// set column `ones` of the wave's valid rows to 1 (bias-gradient trick)
+__device__ __forceinline__ void plant_ones(float* Ts, int ones, int nr) {
+    const int lane = threadIdx.x & 63;
+    if (ones >= 0 && lane < nr) Ts[lane * F3_P + ones] = 1.0f;
 }
 
 // ---- B3: backward of LN2 + FFN --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int P = gm.P, D = d.D, ks = gm.ks, ones = gm.ones;
-    float* T1 = smem;                      // g2                             -> later df
-    float* T2 = T1 + 64 * P;               // hid (+ ones column)            -> later g1
-    float* T3 = T2 + 64 * P;               // f_in (+ ones column)           -> later o
-    float* W1r = T3 + 64 * P;              // W1 [k][P], read by rows
-    float* W2r = W1r + 64 * P;             // W2 [k][P]
-    float* sg = W2r + 64 * P;              // [4][64] + [4][64]
+    const int D = d.D, ks = gm.ks, ones = gm.ones;
+    float* T1 = smem;                      // g2                             -> later df -> d_o
+    float* T2 = T1 + 64 * F3_P;            // hid (+ ones column)            -> later g1
+    float* T3 = T2 + 64 * F3_P;            // f_in (+ ones column)           -> later o
+    float* T4 = T3 + 64 * F3_P;            // dy * mask (residual branch)
+    float* W1r = T4 + 64 * F3_P;           // W1 [k][66], read by rows
+    float* W2r = W1r + 64 * F3_P;          // W2 [k][66]
+    float* gam = W2r + 64 * F3_P;          // [64] gamma2, zero padded
+    float* msk = gam + 64;                 // [64] row mask of the current tile
+    float* sg = msk + 64;                  // [4][64] + [4][64]
     float* sb = sg + 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4, l = lane & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int rps = rows_per_wg(d.M, gridDim.x);
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
-    load_w(W1r, P, d.w1, D, 0, D);
-    load_w(W2r, P, d.w2, D, 0, D);
+    load_w(W1r, F3_P, d.w1, D, 0, D);
+    load_w(W2r, F3_P, d.w2, D, 0, D);
+    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? d.ln2_g[threadIdx.x] : 0.0f;
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
     f32x4 aw1[4], aw2[4];
     zero_acc(aw1); zero_acc(aw2);
     float b1s = 0.0f, b2s = 0.0f;
-    float g[4], ag[4], ab[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { g[i] = (l + 16 * i < D) ? d.ln2_g[l + 16 * i] : 0.0f; ag[i] = 0.0f; ab[i] = 0.0f; }
-    float p1[16], p2[16], p3[16];                                  // register prefetch of the next tile
-    if (mb < me) {
-        fetch_g2(p1, bd, d2, mb, me);
-        fetch_tile(p2, d.hid, D, 0, mb, me, D);
-        fetch_tile(p3, d.f_in, D, 0, mb, me, D);
-    }
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    Stream4 sdy, shid, sfin;
+    auto fetch = [&](int m0) {
+        const int mw = m0 + 16 * wave;
+        const int tot = max(0, min(16, me - mw)) * D;
+        stream_fetch(sdy, bd.dy + (size_t)mw * D, tot);
+        stream_fetch(shid, d.hid + (size_t)mw * D, tot);
+        stream_fetch(sfin, d.f_in + (size_t)mw * D, tot);
+    };
+    if (mb < me) fetch(mb);
     for (int m0 = mb; m0 < me; m0 += 64) {
-        put_tile(T1, p1, P, -1, m0, me);
-        put_tile(T2, p2, P, ones, m0, me);
-        put_tile(T3, p3, P, ones, m0, me);
-        __syncthreads();
-        if (m0 + 64 < me) {                                        // next tile's loads fly under this tile's MFMAs
-            fetch_g2(p1, bd, d2, m0 + 64, me);
-            fetch_tile(p2, d.hid, D, 0, m0 + 64, me, D);
-            fetch_tile(p3, d.f_in, D, 0, m0 + 64, me, D);
+        const int mw = m0 + 16 * wave;
+        const int nr = max(0, min(16, me - mw)), tot = nr * D;
+        float* t1 = T1 + 16 * wave * F3_P; float* t2 = T2 + 16 * wave * F3_P;
+        float* t3 = T3 + 16 * wave * F3_P; float* t4 = T4 + 16 * wave * F3_P;
+        if (lane < 16) msk[16 * wave + lane] = (lane < nr && d.mask_ids[mw + lane] != 0) ? 1.0f : 0.0f;
+        zero_rows(t1); zero_rows(t2); zero_rows(t3); zero_rows(t4);
+        // g2 = dy * mask * keep2/(1-rate) (sasrec.py:83, modules.py:309-310); T4 = dy * mask
+        {
+            const float* mrow = msk + 16 * wave;
+            const uint32_t base = (d.drop_ffn2.row_offset + (uint32_t)mw) * (uint32_t)D;
+            stream_put(t4, sdy, D, tot, gm.invD, [&](int, int r, float v) { return v * mrow[r]; });
+            stream_put(t1, sdy, D, tot, gm.invD, [&](int e, int r, float v) {
+                float x = v * mrow[r];
+                if (d2.on) x *= (cr_fmix32((base + (uint32_t)e) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;
+                return x;
+            });
         }
+        stream_put(t2, shid, D, tot, gm.invD, PutPlain());
+        stream_put(t3, sfin, D, tot, gm.invD, PutPlain());
+        plant_ones(t2, ones, nr);
+        plant_ones(t3, ones, nr);
+        __syncthreads();
+        if (m0 + 64 < me) fetch(m0 + 64);                          // next tile's loads fly under this tile's MFMAs
         // dW2 (+ db2 in row `ones`) += hid^T g2
-        tile_wgrad(aw2, T2, T1, P, wave);
-        if (ones < 0 && threadIdx.x < 64) b2s += colsum64(T1, P);
+        tile_wgrad(aw2, T2, T1, F3_P, wave);
+        if (ones < 0 && threadIdx.x < 64) b2s += colsum64(T1);
         __syncthreads();
         // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (in place over hid, own rows)
         {
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma_t(acc, T1, W2r, P, ks, wave);
+            tile_mma_t(acc, T1, W2r, F3_P, ks, wave);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + 4 * lg + r, col = 16 * j + li;
-                    if (col < P) {
-                        const float h = T2[row * P + col];
-                        T2[row * P + col] = (h > 0.0f && col < D) ? acc[j][r] * scale1 : 0.0f;           // modules.py:300-304
-                    }
+                    float* ph = T2 + (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
+                    const bool gate = (*ph > 0.0f) && (16 * j + li != ones);
+                    *ph = gate ? acc[j][r] * scale1 : 0.0f;                                 // modules.py:300-304
                 }
         }
         __syncthreads();
         // dW1 (+ db1) += f_in^T g1
-        tile_wgrad(aw1, T3, T2, P, wave);
-        if (ones < 0 && threadIdx.x < 64) b1s += colsum64(T2, P);
-        // df = (g1 W1^T + dy) * mask  (residual of modules.py:313) -> T1 (own rows)
+        tile_wgrad(aw1, T3, T2, F3_P, wave);
+        if (ones < 0 && threadIdx.x < 64) b1s += colsum64(T2);
+        // df = g1 W1^T + dy*mask  (residual of modules.py:313; g1 rows of masked positions are 0) -> T1 (own rows)
         {
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma_t(acc, T2, W1r, P, ks, wave);
+            tile_mma_t(acc, T2, W1r, F3_P, ks, wave);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + 4 * lg + r, col = 16 * j + li, m = m0 + row;
-                    float v = 0.0f;
-                    if (m < me && col < D && d.mask_ids[m] != 0) v = acc[j][r] + bd.dy[(size_t)m * D + col];
-                    if (col < P) T1[row * P + col] = v;
+                    const int o = (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
+                    T1[o] = acc[j][r] + T4[o];
                 }
         }
         __syncthreads();                                           // all waves are done with every row of T3
-        // LN2 backward: x = o (own rows into T3), dy = df
-        load_rows_wave(T3, P, d.o, D, 0, m0, me, D, wave);
-        ln_bwd_rows(T3, T1, nullptr, P, g, ag, ab, bd.d_o, 0, m0, me, D, wave);
+        // LN2 backward in place on own rows: x = o (streamed into T3), dy = df (T1) -> d_o (T1)
+        zero_rows(t3);
+        if (nr > 0) wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
+        ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, wave);
+        if (nr > 0) wave_store_rows(bd.d_o + (size_t)mw * D, t1, F3_P, D, nr, gm.invD);
         __syncthreads();
     }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
@@ -563,73 +622,89 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
 }
 
 // ---- B1: backward of LN1 + Q/K/V projections --------------------------------------------------------------
+// dqkv is [3, M, D] (dQ rows, dK rows, dV rows), like qkv.
 __global__ __launch_bounds__(256) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int P = gm.P, D = d.D, ks = gm.ks, ones = gm.ones;
-    float* TA = smem;                      // dQ                 -> later dq_in
-    float* TB = TA + 64 * P;               // dK                 -> later dx part (dK Wk^T + dV Wv^T)
-    float* TC = TB + 64 * P;               // dV
-    float* TQ = TC + 64 * P;               // q_in (+ ones column)
-    float* TX = TQ + 64 * P;               // x    (+ ones column)
-    float* Wqr = TX + 64 * P;              // Wq, Wk, Wv as [k][P], read by rows
-    float* Wkr = Wqr + 64 * P;
-    float* Wvr = Wkr + 64 * P;
-    float* sg = Wvr + 64 * P;
+    const int D = d.D, ks = gm.ks, ones = gm.ones;
+    float* TA = smem;                      // dQ                 -> later dq_in -> dx
+    float* TB = TA + 64 * F3_P;            // dK                 -> later dx part (dK Wk^T + dV Wv^T)
+    float* TC = TB + 64 * F3_P;            // dV
+    float* TQ = TC + 64 * F3_P;            // q_in (+ ones column)
+    float* TX = TQ + 64 * F3_P;            // x    (+ ones column)
+    float* Wqr = TX + 64 * F3_P;           // Wq, Wk, Wv as [k][66], read by rows
+    float* Wkr = Wqr + 64 * F3_P;
+    float* Wvr = Wkr + 64 * F3_P;
+    float* gam = Wvr + 64 * F3_P;          // [64] gamma1
+    float* sg = gam + 64;
     float* sb = sg + 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4, l = lane & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int rps = rows_per_wg(d.M, gridDim.x);
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
-    load_w(Wqr, P, d.wqkv, 3 * D, 0, D);
-    load_w(Wkr, P, d.wqkv, 3 * D, D, D);
-    load_w(Wvr, P, d.wqkv, 3 * D, 2 * D, D);
+    load_w(Wqr, F3_P, d.wqkv, 3 * D, 0, D);
+    load_w(Wkr, F3_P, d.wqkv, 3 * D, D, D);
+    load_w(Wvr, F3_P, d.wqkv, 3 * D, 2 * D, D);
+    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? d.ln1_g[threadIdx.x] : 0.0f;
     f32x4 awq[4], awk[4], awv[4];
     zero_acc(awq); zero_acc(awk); zero_acc(awv);
     float bqs = 0.0f, bks = 0.0f, bvs = 0.0f;
-    float g[4], ag[4], ab[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { g[i] = (l + 16 * i < D) ? d.ln1_g[l + 16 * i] : 0.0f; ag[i] = 0.0f; ab[i] = 0.0f; }
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t MD = (size_t)d.M * D;
     for (int m0 = mb; m0 < me; m0 += 64) {
-        {   // one burst of loads for the five tiles, then one barrier
-            float va[16], vb[16], vc[16], vq[16], vx[16];
-            fetch_tile(va, bd.dqkv, 3 * D, 0, m0, me, D);
-            fetch_tile(vb, bd.dqkv, 3 * D, D, m0, me, D);
-            fetch_tile(vc, bd.dqkv, 3 * D, 2 * D, m0, me, D);
-            fetch_tile(vq, d.q_in, D, 0, m0, me, D);
-            fetch_tile(vx, d.x, D, 0, m0, me, D);
-            put_tile(TA, va, P, -1, m0, me);
-            put_tile(TB, vb, P, -1, m0, me);
-            put_tile(TC, vc, P, -1, m0, me);
-            put_tile(TQ, vq, P, ones, m0, me);
-            put_tile(TX, vx, P, ones, m0, me);
+        const int mw = m0 + 16 * wave;
+        const int nr = max(0, min(16, me - mw)), tot = nr * D;
+        float* ta = TA + 16 * wave * F3_P; float* tb = TB + 16 * wave * F3_P; float* tc = TC + 16 * wave * F3_P;
+        float* tq = TQ + 16 * wave * F3_P; float* tx = TX + 16 * wave * F3_P;
+        {   // one burst of five contiguous streams per wave, then one barrier
+            Stream4 s0, s1, s2, s3, s4;
+            stream_fetch(s0, bd.dqkv + (size_t)mw * D, tot);
+            stream_fetch(s1, bd.dqkv + MD + (size_t)mw * D, tot);
+            stream_fetch(s2, bd.dqkv + 2 * MD + (size_t)mw * D, tot);
+            stream_fetch(s3, d.q_in + (size_t)mw * D, tot);
+            stream_fetch(s4, d.x + (size_t)mw * D, tot);
+            zero_rows(ta); zero_rows(tb); zero_rows(tc); zero_rows(tq); zero_rows(tx);
+            stream_put(ta, s0, D, tot, gm.invD, PutPlain());
+            stream_put(tb, s1, D, tot, gm.invD, PutPlain());
+            stream_put(tc, s2, D, tot, gm.invD, PutPlain());
+            stream_put(tq, s3, D, tot, gm.invD, PutPlain());
+            stream_put(tx, s4, D, tot, gm.invD, PutPlain());
+            plant_ones(tq, ones, nr);
+            plant_ones(tx, ones, nr);
         }
         __syncthreads();
         // weight (+ bias) gradients: reductions over all 64 rows of the tiles
-        tile_wgrad(awq, TQ, TA, P, wave);
-        tile_wgrad(awk, TX, TB, P, wave);
-        tile_wgrad(awv, TX, TC, P, wave);
-        if (ones < 0 && threadIdx.x < 64) { bqs += colsum64(TA, P); bks += colsum64(TB, P); bvs += colsum64(TC, P); }
+        tile_wgrad(awq, TQ, TA, F3_P, wave);
+        tile_wgrad(awk, TX, TB, F3_P, wave);
+        tile_wgrad(awv, TX, TC, F3_P, wave);
+        if (ones < 0 && threadIdx.x < 64) { bqs += colsum64(TA); bks += colsum64(TB); bvs += colsum64(TC); }
         // data gradients on own rows: dx_part = dK Wk^T + dV Wv^T ; dq_in = dQ Wq^T + d_o (modules.py:269)
         f32x4 dxa[4], acc[4];
         zero_acc(dxa); zero_acc(acc);
-        tile_mma_t(dxa, TB, Wkr, P, ks, wave);
-        tile_mma_t(dxa, TC, Wvr, P, ks, wave);
-        tile_mma_t(acc, TA, Wqr, P, ks, wave);
-        __syncthreads();                                           // every wave is done reading all rows of TA / TB
+        tile_mma_t(dxa, TB, Wkr, F3_P, ks, wave);
+        tile_mma_t(dxa, TC, Wvr, F3_P, ks, wave);
+        tile_mma_t(acc, TA, Wqr, F3_P, ks, wave);
+        __syncthreads();                                           // every wave is done reading all rows of TA / TB / TC
+        zero_rows(tc);
+        if (nr > 0) wave_load_rows(tc, bd.d_o + (size_t)mw * D, F3_P, D, nr, gm.invD);      // residual branch
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * wave + 4 * lg + r, col = 16 * j + li, m = m0 + row;
-                if (col < P) {
-                    float v = 0.0f;
-                    if (m < me && col < D) v = acc[j][r] + bd.d_o[(size_t)m * D + col];
-                    TA[row * P + col] = v;
-                    TB[row * P + col] = dxa[j][r];
-                }
+                const int o = (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
+                TA[o] = acc[j][r] + TC[o];
+                TB[o] = dxa[j][r];
             }
-        // LN1 backward on own rows: dx = dx_part + LNbwd(dq_in; x)
-        ln_bwd_rows(TX, TA, TB, P, g, ag, ab, bd.dx, bd.dx_accumulate, m0, me, D, wave);
+        if (ones >= 0 && lane < 16) tx[lane * F3_P + ones] = 0.0f;     // remove the ones column before LN reads x
+        // LN1 backward in place on own rows: dx = dx_part + LNbwd(dq_in; x)  -> TA
+        ln_bwd_rows(TX, TA, TB, gam, ag, ab, D, wave);
+        if (nr > 0) {
+            float* gdx = bd.dx + (size_t)mw * D;
+            if (bd.dx_accumulate) {
+                wave_load_rows(tb, gdx, F3_P, D, nr, gm.invD);
+                for (int e = lane; e < 16 * F3_P; e += 64) ta[e] += tb[e];
+            }
+            wave_store_rows(gdx, ta, F3_P, D, nr, gm.invD);
+        }
         __syncthreads();
     }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
@@ -676,7 +751,7 @@ extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (2 * 64 * g.P + 3 * 4 * g.ks * BK_PW);
+    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 3 * 4 * g.ks * BK_PW + 320);
     hipLaunchKernelGGL(k_block_ln_qkv_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
     return cr_check_launch("cr_block_ln_qkv_fwd");
 }
@@ -706,7 +781,7 @@ extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (5 * 64 * g.P + 512);
+    const size_t lds = sizeof(float) * (6 * 64 * F3_P + 128 + 512);
     hipLaunchKernelGGL(k_block_ln_ffn_bwd, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
     return cr_check_launch("cr_block_ln_ffn_bwd");
 }
@@ -722,7 +797,7 @@ extern "C" int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* bd, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (8 * 64 * g.P + 512);
+    const size_t lds = sizeof(float) * (8 * 64 * F3_P + 64 + 512);
     hipLaunchKernelGGL(k_block_ln_qkv_bwd, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
     return cr_check_launch("cr_block_ln_qkv_bwd");
 }

@@ -370,7 +370,7 @@ class Engine:
         M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
         d_head = D // H
         q_in, o, f_in, hid = (self.buf(pfx + n, D) for n in ("q_in", "o", "f_in", "hid"))
-        qkv = self.buf(pfx + "qkv", 3 * D)
+        qkv = self.buf(pfx + "qkv", D, rows=3 * M)            # [3, M, D]: Q rows, K rows, V rows
         kvalid, qvalid = self.vec(pfx + "kvalid"), self.vec(pfx + "qvalid")
         ids = self.ids["seq"]
         wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
@@ -380,17 +380,19 @@ class Engine:
         ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
                        1e-8, kvalid.data_ptr(), qvalid.data_ptr())
         self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln1))
-        # Q = LN1(x) Wq + bq ; [K|V] = x [Wk|Wv] + [bk|bv]   (modules.py:203-205), one batched launch
-        gq = O.gemm_desc(q_in, D, None, 3 * D, qkv, 3 * D, M, D, D)
-        gq.B, gq.bias = wqkv, bqkv
-        gkv = O.gemm_desc(x, D, None, 3 * D, None, 3 * D, M, 2 * D, D)
-        gkv.B, gkv.bias, gkv.C = wqkv + 4 * D, bqkv + 4 * D, qkv.data_ptr() + 4 * D
-        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 2)(gq, gkv), 2)
+        # Q = LN1(x) Wq + bq ; K = x Wk + bk ; V = x Wv + bv   (modules.py:203-205), one batched launch
+        MD4 = 4 * M * D
+        gs = []
+        for part, src in enumerate((q_in, x, x)):
+            gd = O.gemm_desc(src, D, None, 3 * D, None, D, M, D, D)
+            gd.B, gd.bias, gd.C = wqkv + 4 * part * D, bqkv + 4 * part * D, qkv.data_ptr() + part * MD4
+            gs.append(gd)
+        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 3)(*gs), 3)
         # attention core (modules.py:208-269), residual = queries
-        ad = O.attn_desc(qkv, None, None, 3 * D, kvalid, qvalid, q_in, D, o, D, B, T, H, d_head,
+        ad = O.attn_desc(qkv, None, None, D, kvalid, qvalid, q_in, D, o, D, B, T, H, d_head,
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
                          dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
-        ad.K, ad.V = qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
+        ad.K, ad.V = qkv.data_ptr() + MD4, qkv.data_ptr() + 2 * MD4
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         # LN2 + FFN (modules.py:280-318), residual = LN2 output, then * mask (sasrec.py:83)
         ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
@@ -409,7 +411,7 @@ class Engine:
             lst = []
             dy, dx = self._grad_of(y), self._grad_of(x)
             g2, g1, df, do, dq_in = (self.buf(pfx + n, D) for n in ("g2", "g1", "df", "do", "dq_in"))
-            dqkv = self.buf(pfx + "dqkv", 3 * D)
+            dqkv = self.buf(pfx + "dqkv", D, rows=3 * M)          # [3, M, D]
             stats = self.vec(pfx + "stats", H * B * T * 4)
             S = self.Gs.shape[1]
             # (a) gradient wrt FFN2 pre-dropout output: dy * mask * keep/(1-rate)
@@ -434,20 +436,24 @@ class Engine:
                              self._gptr(pfx + "ln2.gamma"), self._gptr(pfx + "ln2.beta"), S, self.n_slabs, M, D, 1e-8)
             self._call(lst, "cr_layernorm_bwd", C.byref(l2))
             # (g) attention backward -> dQ | dK | dV
-            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + 4 * D,
-                                dqkv.data_ptr() + 8 * D, 3 * D, stats.data_ptr())
+            dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + MD4, dqkv.data_ptr() + 2 * MD4
+            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dq, dk, dv, D, stats.data_ptr())
             self._call(lst, "cr_attn_bwd", C.byref(abd))
-            # (h) dWq, dbq ; [dWk|dWv], [dbk|dbv]
+            # (h) dWq, dbq ; dWk, dbk ; dWv, dbv  (column blocks of the fused [D,3D] weight gradient)
             gw = self._gptr(pfx + "wqkv"); gb = self._gptr(pfx + "bqkv")
-            w2 = (L.WgradDesc * 2)(L.WgradDesc(q_in.data_ptr(), D, dqkv.data_ptr(), 3 * D, gw, 3 * D, gb, M, D, D),
-                                   L.WgradDesc(x.data_ptr(), D, dqkv.data_ptr() + 4 * D, 3 * D, gw + 4 * D, 3 * D, gb + 4 * D, M, 2 * D, D))
-            self._call(lst, "cr_gemm_wgrad", w2, 2, S, self.n_slabs)
-            # (i) dq_in = dQ Wq^T + do (residual, modules.py:269) ; dx (+)= [dK|dV] [Wk|Wv]^T
-            bq = O.gemm_desc(dqkv, 3 * D, None, 3 * D, dq_in, D, M, D, D, trans_b=True, residual=do, ldr=D)
-            bq.B = wqkv
-            bkv = O.gemm_desc(None, 3 * D, None, 3 * D, dx, D, M, D, 2 * D, trans_b=True, accumulate=bool(self._acc(id(dx))))
-            bkv.A, bkv.B = dqkv.data_ptr() + 4 * D, wqkv + 4 * D
-            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 2)(bq, bkv), 2)
+            w2 = (L.WgradDesc * 3)(L.WgradDesc(q_in.data_ptr(), D, dq, D, gw, 3 * D, gb, M, D, D),
+                                   L.WgradDesc(x.data_ptr(), D, dk, D, gw + 4 * D, 3 * D, gb + 4 * D, M, D, D),
+                                   L.WgradDesc(x.data_ptr(), D, dv, D, gw + 8 * D, 3 * D, gb + 8 * D, M, D, D))
+            self._call(lst, "cr_gemm_wgrad", w2, 3, S, self.n_slabs)
+            # (i) dq_in = dQ Wq^T + do (residual, modules.py:269) ; dx (+)= dK Wk^T, then dx += dV Wv^T
+            bq = O.gemm_desc(None, D, None, 3 * D, dq_in, D, M, D, D, trans_b=True, residual=do, ldr=D)
+            bq.A, bq.B = dq, wqkv
+            bk = O.gemm_desc(None, D, None, 3 * D, dx, D, M, D, D, trans_b=True, accumulate=bool(self._acc(id(dx))))
+            bk.A, bk.B = dk, wqkv + 4 * D
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 2)(bq, bk), 2)
+            bv = O.gemm_desc(None, D, None, 3 * D, dx, D, M, D, D, trans_b=True, accumulate=True)
+            bv.A, bv.B = dv, wqkv + 8 * D
+            self._call(lst, "cr_gemm_rows", (L.GemmDesc * 1)(bv), 1)
             # (j) LN1 backward accumulates into dx
             l1 = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), dq_in.data_ptr(), D, dx.data_ptr(), D, 1,
                              self._gptr(pfx + "ln1.gamma"), self._gptr(pfx + "ln1.beta"), S, self.n_slabs, M, D, 1e-8)
@@ -466,10 +472,11 @@ class Engine:
                          f_in.data_ptr(), hid.data_ptr(), y.data_ptr(), ids.data_ptr(),
                          self.rng(pfx[:-1] + ".ffn1"), self.rng(pfx[:-1] + ".ffn2"))
         self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
-        ad = O.attn_desc(qkv, None, None, 3 * D, kvalid, qvalid, q_in, D, o, D, B, T, H, D // H,
+        MD4 = 4 * M * D
+        ad = O.attn_desc(qkv, None, None, D, kvalid, qvalid, q_in, D, o, D, B, T, H, D // H,
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
                          dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
-        ad.K, ad.V = qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
+        ad.K, ad.V = qkv.data_ptr() + MD4, qkv.data_ptr() + 2 * MD4
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
         if not self.training:
@@ -479,7 +486,7 @@ class Engine:
             lst = []
             dy, dx = self._grad_of(y), self._grad_of(x)
             do = self.buf(pfx + "do", D)
-            dqkv = self.buf(pfx + "dqkv", 3 * D)
+            dqkv = self.buf(pfx + "dqkv", D, rows=3 * M)          # [3, M, D]
             stats = self.vec(pfx + "stats", H * B * T * 4)
             G = self._gptr
             bbd = L.BlockBwdDesc(L.BlockDesc.from_buffer_copy(bd), dy.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dx.data_ptr(),
@@ -487,8 +494,8 @@ class Engine:
                                  G(pfx + "ln2.gamma"), G(pfx + "ln2.beta"), G(pfx + "w1"), G(pfx + "b1"), G(pfx + "w2"), G(pfx + "b2"),
                                  self.Gs.shape[1], self.n_slabs)
             self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
-            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + 4 * D,
-                                dqkv.data_ptr() + 8 * D, 3 * D, stats.data_ptr())
+            abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + MD4,
+                                dqkv.data_ptr() + 2 * MD4, D, stats.data_ptr())
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst

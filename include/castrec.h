@@ -206,7 +206,7 @@ int cr_attn_bwd(const cr_attn_bwd_desc* d, void* stream);
  * The block of sasrec.py:65-83 is, apart from the attention core, row-local: a 64-row tile of the
  * activations stays in LDS across LayerNorm -> projections (and back).  These four entry points replace
  * chains of cr_layernorm / cr_gemm_rows / cr_eltwise / cr_gemm_wgrad launches; results are identical.
- *   cr_block_ln_qkv_fwd : q_in = LN1(x) (+ key/query masks); Q = q_in Wq + bq; [K|V] = x [Wk|Wv] + [bk|bv]
+ *   cr_block_ln_qkv_fwd : q_in = LN1(x) (+ key/query masks); Q = q_in Wq + bq; K = x Wk + bk; V = x Wv + bv
  *   cr_block_ln_ffn_fwd : f_in = LN2(o); hid = drop(relu(f_in W1 + b1)); y = (drop(hid W2 + b2) + f_in) * mask
  *   cr_block_ln_ffn_bwd : dy -> d_o, and slabs of dW2 db2 dW1 db1 dgamma2 dbeta2
  *   cr_block_ln_qkv_bwd : (dQ|dK|dV, d_o) -> dx (= or +=), and slabs of dWqkv dbqkv dgamma1 dbeta1        */
@@ -217,7 +217,7 @@ typedef struct {
     const float* ln2_g; const float* ln2_b;
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* x;                            /* block input [M,D] */
-    float* q_in; float* qkv;                   /* [M,D], [M,3D] */
+    float* q_in; float* qkv;                   /* [M,D]; [3,M,D]: Q rows, then K rows, then V rows */
     float* k_valid; float* q_valid;            /* [M] */
     float* o;                                  /* attention output (+ residual) [M,D] */
     float* f_in; float* hid; float* y;         /* [M,D] */
@@ -231,7 +231,7 @@ typedef struct {
     cr_block_desc f;
     const float* dy;                           /* gradient of y [M,D] */
     float* d_o;                                /* out of ffn_bwd, in of qkv_bwd: gradient of o [M,D] */
-    const float* dqkv;                         /* [M,3D] from cr_attn_bwd */
+    const float* dqkv;                         /* [3,M,D] from cr_attn_bwd (dQ rows, dK rows, dV rows) */
     float* dx; int dx_accumulate;              /* gradient of x */
     float* g_ln1_g; float* g_ln1_b; float* g_wqkv; float* g_bqkv;      /* slab-0 pointers */
     float* g_ln2_g; float* g_ln2_b; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
