@@ -22,10 +22,85 @@ __global__ __launch_bounds__(256) void k_embed_fwd(cr_embed_desc d) {
     }
 }
 
+// Vectorised gather for hidden sizes that are a multiple of 4 (configs 3-5: D = 64, 128, 256): a row is
+// D/4 float4 chunks, LPR = D/4 lanes per row (<= 64), 64/LPR rows per wave-instruction, and each wave keeps
+// R = 4 row groups in flight (independent 16-B loads issued before any store) -- the shape the HBM-bound
+// C5 gather (1 KiB rows out of a 10 GB table) needs.  16 B per lane, full 128-B lines.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_embed_fwd_vec(cr_embed_desc d) {
+    constexpr int RPW = 64 / LPR, R = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;          // row within the group, float4 chunk within the row
+    const int nchunk = d.D >> 2;
+    const DropCtx dc = drop_ctx(d.drop);
+    const int rows_per_iter = RPW * R;
+    for (int mb = (blockIdx.x * 4 + wave) * rows_per_iter; mb < d.M; mb += gridDim.x * 4 * rows_per_iter) {
+        float4 v[R];
+        int mrow[R];
+        bool act[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int m = mb + u * RPW + sub;
+            mrow[u] = m;
+            act[u] = (m < d.M) && (l < nchunk);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act[u]) {
+                const int id = d.ids[m];
+                if (!(d.zero_pad && id == 0)) v[u] = reinterpret_cast<const float4*>(d.table + (size_t)id * d.D)[l];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (!act[u]) continue;
+            const int m = mrow[u], c = 4 * l;
+            float4 x = v[u];
+            x.x *= d.scale; x.y *= d.scale; x.z *= d.scale; x.w *= d.scale;
+            if (d.pos_table) {
+                const float4 p = reinterpret_cast<const float4*>(d.pos_table + (size_t)(m % d.T) * d.D)[l];
+                x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+            }
+            if (d.addend) {
+                const float* a = d.addend + (size_t)m * d.ld_add + c;
+                x.x += a[0]; x.y += a[1]; x.z += a[2]; x.w += a[3];
+            }
+            if (dc.on) {
+                const uint32_t base = (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c;
+                x.x = drop_apply(dc, base, x.x); x.y = drop_apply(dc, base + 1, x.y);
+                x.z = drop_apply(dc, base + 2, x.z); x.w = drop_apply(dc, base + 3, x.w);
+            }
+            if (d.mask_ids && d.mask_ids[m] == 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(d.out + (size_t)m * d.ld_out + d.col_off + c) = x;
+        }
+    }
+}
+
+static bool embed_vec_ok(const cr_embed_desc* d) {
+    return d->D % 4 == 0 && d->D / 4 <= 64 && ((d->D / 4) & (d->D / 4 - 1)) == 0 &&      // D/4 a power of two <= 64
+           d->ld_out % 4 == 0 && d->col_off % 4 == 0 && ((uintptr_t)d->table & 15) == 0 && ((uintptr_t)d->out & 15) == 0 &&
+           (!d->pos_table || ((uintptr_t)d->pos_table & 15) == 0);
+}
+
 extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
     CR_REQUIRE(d && d->ids && d->table && d->out, "cr_embed_fwd: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->T > 0 && d->D > 0 && d->V > 0 && d->M % d->T == 0, "cr_embed_fwd: bad shape M=%d T=%d D=%d", d->M, d->T, d->D);
     CR_REQUIRE(d->ld_out >= d->col_off + d->D, "cr_embed_fwd: ld_out too small");
+    if (embed_vec_ok(d)) {
+        const int lpr = d->D / 4;
+        const int rows_per_block = 4 * (64 / lpr) * 4;
+        int grid = cr_ceil_div(d->M, rows_per_block);
+        if (grid > 8192) grid = 8192;
+        hipStream_t s = cr_stream(stream);
+        switch (lpr) {
+            case 64: hipLaunchKernelGGL((k_embed_fwd_vec<64>), dim3(grid), dim3(256), 0, s, *d); break;
+            case 32: hipLaunchKernelGGL((k_embed_fwd_vec<32>), dim3(grid), dim3(256), 0, s, *d); break;
+            case 16: hipLaunchKernelGGL((k_embed_fwd_vec<16>), dim3(grid), dim3(256), 0, s, *d); break;
+            case 8: hipLaunchKernelGGL((k_embed_fwd_vec<8>), dim3(grid), dim3(256), 0, s, *d); break;
+            case 4: hipLaunchKernelGGL((k_embed_fwd_vec<4>), dim3(grid), dim3(256), 0, s, *d); break;
+            case 2: hipLaunchKernelGGL((k_embed_fwd_vec<2>), dim3(grid), dim3(256), 0, s, *d); break;
+            default: hipLaunchKernelGGL((k_embed_fwd_vec<1>), dim3(grid), dim3(256), 0, s, *d); break;
+        }
+        return cr_check_launch("cr_embed_fwd(vec)");
+    }
     hipLaunchKernelGGL(k_embed_fwd, dim3(cr_ceil_div(d->M, 4)), dim3(256), 0, cr_stream(stream), *d);
     return cr_check_launch("cr_embed_fwd");
 }
