@@ -274,13 +274,16 @@ extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd != nullptr, "cr_attn_bwd: NULL desc");
     const cr_attn_desc* d = &bd->f;
     AttnGeom g;
-    int rc = attn_geom(d, &g, "cr_attn_bwd");
+    int rc = attn_validate(d, "cr_attn_bwd");
     if (rc) return rc;
     CR_REQUIRE(bd->dout && bd->dQ && bd->dK && bd->dV && bd->stats, "cr_attn_bwd: NULL pointer");
-    const int wq = attn_pick_waves(g, lds_bwd_q), wkv = attn_pick_waves(g, lds_bwd_kv);
-    if (!wq || !wkv)
-        return cr_set_error(CR_ERR_UNSUPPORTED, "cr_attn_bwd: T=%d d=%d needs %zu B of LDS", d->T, d->d, lds_bwd_kv(g, 1));
+    CR_REQUIRE(bd->ldg >= d->H * d->d && bd->lddo >= d->H * d->d, "cr_attn_bwd: ldg / lddo too small");
     hipStream_t s = cr_stream(stream);
+    if (!attn_lds_envelope(d)) return cr_attn_wide_bwd_launch(bd, s);
+    rc = attn_geom(d, &g, "cr_attn_bwd");
+    if (rc) return rc;
+    const int wq = attn_pick_waves(g, lds_bwd_q), wkv = attn_pick_waves(g, lds_bwd_kv);
+    if (!wq || !wkv) return cr_attn_wide_bwd_launch(bd, s);
     const int nkt = attn_pick_nkt(g.nkt);
     if (nkt == 4) rc = dispatch_bwd_q<4>(bd, g, wq, s);
     else if (nkt == 13) rc = dispatch_bwd_q<13>(bd, g, wq, s);

@@ -226,13 +226,26 @@ __device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const floa
 static inline int attn_pick_nds(int d) { return d <= 32 ? 8 : (d <= 52 ? 13 : 16); }
 static inline int attn_pick_nkt(int nkt) { return nkt <= 4 ? 4 : (nkt <= 13 ? 13 : 16); }
 
-static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
+// general-shape fallback (cr_attn_wide.hip) for shapes outside the LDS-resident envelope
+int cr_attn_wide_supported(const cr_attn_desc* d);
+int cr_attn_wide_fwd_launch(const cr_attn_desc* d, hipStream_t s);
+int cr_attn_wide_bwd_launch(const cr_attn_bwd_desc* bd, hipStream_t s);
+
+static int attn_validate(const cr_attn_desc* d, const char* who) {
     CR_REQUIRE(d->Q && d->K && d->V && d->k_valid && d->q_valid, "%s: NULL pointer", who);
     CR_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->d > 0, "%s: bad shape B=%d T=%d H=%d d=%d", who, d->B, d->T, d->H, d->d);
-    if (d->d > 64) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: head dim %d > 64", who, d->d);
-    if (d->T > 256) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: T=%d > 256 (LDS-resident K/V design)", who, d->T);
+    if (!cr_attn_wide_supported(d))
+        return cr_set_error(CR_ERR_UNSUPPORTED, "%s: T=%d (max 1024) / head dim %d (max 256) not supported", who, d->T, d->d);
     CR_REQUIRE(d->ld >= d->H * d->d, "%s: ld too small", who);
     CR_REQUIRE(d->batch_global >= d->B, "%s: batch_global < B", who);
+    return CR_OK;
+}
+// the MFMA kernels keep K and V of one (sample, head) resident in LDS: T <= 256, head dim <= 64
+static inline bool attn_lds_envelope(const cr_attn_desc* d) { return d->T <= 256 && d->d <= 64; }
+
+static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
+    int rc = attn_validate(d, who);
+    if (rc) return rc;
     g->T16 = (d->T + 15) / 16 * 16;
     g->nkt = g->T16 / 16;
     g->nds = attn_pick_nds(d->d);

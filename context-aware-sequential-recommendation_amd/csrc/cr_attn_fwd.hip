@@ -119,12 +119,15 @@ static int dispatch_fwd(const cr_attn_desc* d, const AttnGeom& g, int waves, hip
 extern "C" int cr_attn_fwd(const cr_attn_desc* d, void* stream) {
     CR_REQUIRE(d != nullptr, "cr_attn_fwd: NULL desc");
     AttnGeom g;
-    int rc = attn_geom(d, &g, "cr_attn_fwd");
+    int rc = attn_validate(d, "cr_attn_fwd");
     if (rc) return rc;
     CR_REQUIRE(d->out && d->residual, "cr_attn_fwd: NULL out/residual");
-    const int waves = attn_pick_waves(g, lds_fwd);
-    if (!waves) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_attn_fwd: T=%d d=%d needs %zu B of LDS", d->T, d->d, lds_fwd(g, 1));
     hipStream_t s = cr_stream(stream);
+    if (!attn_lds_envelope(d)) return cr_attn_wide_fwd_launch(d, s);
+    rc = attn_geom(d, &g, "cr_attn_fwd");
+    if (rc) return rc;
+    const int waves = attn_pick_waves(g, lds_fwd);
+    if (!waves) return cr_attn_wide_fwd_launch(d, s);
     const int nkt = attn_pick_nkt(g.nkt);
     if (nkt == 4) return dispatch_fwd<4>(d, g, waves, s);
     if (nkt == 13) return dispatch_fwd<13>(d, g, waves, s);

@@ -133,7 +133,9 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
 @pytest.mark.parametrize("model,D,H,T,L", [("sasrec", 64, 2, 50, 2),      # BASELINE config 3 shape (Beauty: D=64, 2 heads)
                                            ("cast_2", 64, 2, 24, 1),
                                            ("sasrec", 128, 4, 40, 2),     # config 4 shape (Books: D=128, 4 heads) -> unfused path
-                                           ("cast_9", 128, 4, 24, 1)])
+                                           ("cast_9", 128, 4, 24, 1),
+                                           ("sasrec", 256, 4, 300, 1),    # config 5 shape class (D=256, maxlen > 256) -> general attention
+                                           ("cast_1", 128, 1, 20, 1)])    # head dim 128 > 64 -> general attention
 def test_other_baseline_shapes_match_oracle(E, model, D, H, T, L):
     rs = np.random.RandomState(D + T)
     B, itemnum, max_bins = 3, 41, 9

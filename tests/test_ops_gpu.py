@@ -241,6 +241,8 @@ def attn_core_ref(Q, K, V, kvalid, qvalid, resid, H, keep=None, rate=0.0):
 ATTN_CASES = [  # B, T, H, d, rate
     (3, 8, 1, 6, 0.0), (2, 50, 1, 50, 0.0), (2, 200, 1, 50, 0.2), (3, 37, 2, 32, 0.0), (2, 50, 4, 32, 0.5),
     (1, 256, 1, 64, 0.0), (2, 100, 2, 25, 0.3), (5, 16, 1, 50, 0.0),
+    # outside the LDS-resident MFMA envelope (T > 256 or head dim > 64) -> general-shape kernels (cr_attn_wide.hip)
+    (2, 300, 1, 50, 0.2), (2, 512, 2, 64, 0.0), (2, 40, 1, 100, 0.3), (2, 130, 1, 256, 0.0), (1, 1024, 1, 8, 0.0),
 ]
 
 
@@ -306,11 +308,11 @@ def test_attention_dead_rows_and_rejects(ops):
     ops.attn_fwd(desc)
     torch.cuda.synchronize()
     assert torch.equal(out[:10], R[:10])                 # dead rows: A = 0 -> residual only
-    bad = ops.attn_desc(Q, K, V, d, kv, qv, R, d, out, d, 1, 300, 1, 50)
-    with pytest.raises(RuntimeError, match="T=300"):
+    bad = ops.attn_desc(Q, K, V, d, kv, qv, R, d, out, d, 1, 1100, 1, 50)
+    with pytest.raises(RuntimeError, match="T=1100"):
         ops.attn_fwd(bad)
-    bad = ops.attn_desc(Q, K, V, 100, kv, qv, R, d, out, d, 1, 8, 1, 100)
-    with pytest.raises(RuntimeError, match="head dim"):
+    bad = ops.attn_desc(Q, K, V, 300, kv, qv, R, d, out, d, 1, 8, 1, 300)
+    with pytest.raises(RuntimeError, match="head dim 300"):
         ops.attn_fwd(bad)
 
 
