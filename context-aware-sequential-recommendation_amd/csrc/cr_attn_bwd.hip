@@ -13,14 +13,21 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const int nw = blockDim.x >> 6;
     float* Ks = smem;                                   // [T16][PA]  A-pattern (scores) and B-pattern (dQ) reads
     float* Vs = Ks + g.T16 * g.PA + A_TAIL;             // [T16][PA]  A-pattern reads (dP^T)
-    float* Qs = Vs + g.T16 * g.PA;                      // [nw][16][PA]: slot for the Q tile, then the dOut tile
-    float* kv = Qs + nw * 16 * g.PA;
+    float* kv = Vs + g.T16 * g.PA;
     float* qv = kv + g.T16;
     float* dead = qv + g.T16;
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int nwaves = gridDim.y * nw;
+    int qi = wave * gridDim.y + blockIdx.y;             // interleaved: every workgroup gets heavy and light tiles
+    float qn[NDS], don[NDS];                            // Q / dOut fragments of the wave's next tile (in flight during the staging)
+    if (qi < g.nkt) {
+        const int q0n = 16 * (g.nkt - 1 - qi);
+        frag_issue<NDS>(d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, qn);
+        frag_issue<NDS>(bd.dout, bd.lddo, base_row + q0n, hoff, T - q0n, d.d, don);
+    }
     stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
     stage_rows(Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
     for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
@@ -32,11 +39,17 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const uint64_t kbits = key_bits<NKT>(kv, T);
     const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
-    float* Qw = Qs + wave * 16 * g.PA;
-    const int nwaves = gridDim.y * nw;
-    for (int qi = wave * gridDim.y + blockIdx.y; qi < g.nkt; qi += nwaves) {   // interleaved: every workgroup gets heavy and light tiles
+    for (; qi < g.nkt; qi += nwaves) {
         const int qt = g.nkt - 1 - qi;
         const int q0 = 16 * qt, q = q0 + li;
+        float qf[NDS], dof[NDS];
+        frag_finish<NDS>(qn, T - q0, d.d, qf);
+        frag_finish<NDS>(don, T - q0, d.d, dof);
+        if (qi + nwaves < g.nkt) {                      // prefetch the next tile's fragments behind this tile's work
+            const int q0n = 16 * (g.nkt - 1 - (qi + nwaves));
+            frag_issue<NDS>(d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, qn);
+            frag_issue<NDS>(bd.dout, bd.lddo, base_row + q0n, hoff, T - q0n, d.d, don);
+        }
         const bool is_dead = dead[q] != 0.0f;
         if (__all(is_dead ? 1 : 0)) {                  // whole tile dead: dQ = 0, flag 2
             for (int rr = 0; rr < 16; ++rr) {
@@ -49,11 +62,6 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
             }
             continue;
         }
-        float qf[NDS], dof[NDS];
-        stage_rows(Qw, g.PA, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
-        load_frag<NDS>(Qw, g.PA, qf);
-        stage_rows(Qw, g.PA, bd.dout, bd.lddo, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
-        load_frag<NDS>(Qw, g.PA, dof);
         float nz = 0.0f;                               // does this query's incoming gradient row vanish?
 #pragma unroll
         for (int s = 0; s < NDS; ++s)
@@ -124,8 +132,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int nw = blockDim.x >> 6;
     float* Qs = smem;                                   // [T16][PA]  A- and B-pattern reads
     float* Os = Qs + g.T16 * g.PA + A_TAIL;             // [T16][PA]  dOut
-    float* KVs = Os + g.T16 * g.PA + A_TAIL;            // [nw][16][PA]: slot for the wave's K tile, then its V tile
-    float* smx = KVs + nw * 16 * g.PA;                  // [T16] each
+    float* smx = Os + g.T16 * g.PA + A_TAIL;            // [T16] each
     float* sinv = smx + g.T16;
     float* sdel = sinv + g.T16;
     float* sflag = sdel + g.T16;
@@ -136,6 +143,13 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int nwaves = gridDim.y * nw;
+    int kt = wave * gridDim.y + blockIdx.y;
+    float kn[NDS], vn[NDS];                             // K / V fragments of the wave's next key tile (in flight during the staging)
+    if (kt < g.nkt) {
+        frag_issue<NDS>(d.K, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, kn);
+        frag_issue<NDS>(d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, vn);
+    }
     stage_rows(Qs, g.PA, d.Q, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
     stage_rows(Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16, wave, nw);
     for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
@@ -158,15 +172,16 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     }
     __syncthreads();
     const DropCtx dc = drop_ctx(d.drop);
-    float* Kw = KVs + wave * 16 * g.PA;
-    const int nwaves = gridDim.y * nw;
-    for (int kt = wave * gridDim.y + blockIdx.y; kt < g.nkt; kt += nwaves) {
+    for (; kt < g.nkt; kt += nwaves) {
         const int key = 16 * kt + li;
         float kf[NDS], vf[NDS];
-        stage_rows(Kw, g.PA, d.K, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, 16, 0, 1);
-        load_frag<NDS>(Kw, g.PA, kf);
-        stage_rows(Kw, g.PA, d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, 16, 0, 1);
-        load_frag<NDS>(Kw, g.PA, vf);
+        frag_finish<NDS>(kn, T - 16 * kt, d.d, kf);
+        frag_finish<NDS>(vn, T - 16 * kt, d.d, vf);
+        if (kt + nwaves < g.nkt) {
+            const int ktn = kt + nwaves;
+            frag_issue<NDS>(d.K, d.ld, base_row + 16 * ktn, hoff, T - 16 * ktn, d.d, kn);
+            frag_issue<NDS>(d.V, d.ld, base_row + 16 * ktn, hoff, T - 16 * ktn, d.d, vn);
+        }
         const bool kvk = (key < T) && (d.k_valid[base_row + (key < T ? key : 0)] != 0.0f);
         const bool tile_has_key = __any(kvk ? 1 : 0) != 0;      // all-padding key tile: only uniform rows reach it
         f32x4 dk[NDT], dv[NDT];
@@ -231,10 +246,10 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
 }
 
 static size_t lds_bwd_q(const AttnGeom& g, int w) {
-    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + A_TAIL + (size_t)w * 16 * g.PA + 3 * g.T16);
+    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + A_TAIL + 3 * g.T16) + 0 * (size_t)w;
 }
 static size_t lds_bwd_kv(const AttnGeom& g, int w) {
-    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + 2 * A_TAIL + (size_t)w * 16 * g.PA + 5 * g.T16 + 2 * g.nkt);
+    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + 2 * A_TAIL + 5 * g.T16 + 2 * g.nkt) + 0 * (size_t)w;
 }
 
 template <int NKT, int NDS, int NDT>

@@ -84,12 +84,80 @@ __device__ __forceinline__ void load_frag(const float* tile, int pa, float (&fra
     for (int s = 0; s < NDS; ++s) frag[s] = tile[li * pa + 4 * s + lg];
 }
 
+// Register fragment straight from global memory, in two halves so the loads stay in flight behind other
+// work: frag_issue starts the NDS loads of element s = M[row0 + li][hoff + 4s + lg] (addresses clamped
+// instead of predicated: no branches; a wave touches 16 rows x 16 B per load, L2-resident activations);
+// frag_finish zeroes what lies outside the valid rows / columns (first use = the wait).
+template <int NDS>
+__device__ __forceinline__ void frag_issue(const float* src, int ld, int row0, int hoff, int nrows_valid, int d, float (&raw)[NDS]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const float* p = src + (size_t)(row0 + (li < nrows_valid ? li : 0)) * ld + hoff;
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) {
+        const int c = 4 * s + lg;
+        raw[s] = p[c < d ? c : 0];
+    }
+}
+template <int NDS>
+__device__ __forceinline__ void frag_finish(const float (&raw)[NDS], int nrows_valid, int d, float (&frag)[NDS]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const bool rok = li < nrows_valid;
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) frag[s] = (rok && 4 * s + lg < d) ? raw[s] : 0.0f;
+}
+
 // stage rows [0,nrows_valid) x [hoff, hoff+d) of a [M, ld] matrix into LDS with pitch P <= 68; everything
 // outside (rows >= nrows_valid, columns >= d up to the pitch) is zero so padded k-steps contribute 0.
-// A wave copies one row per pass (coalesced 4*d-byte segments), 8 rows in flight.
+// `nw` waves take part, `tr` is the calling wave's index among them.
+// Fast path (single head, ld == d, 16-byte aligned): the rows are one contiguous stream, read as float4
+// with 4 loads in flight per lane and scattered into the pitched rows.  Otherwise a wave copies one row
+// per pass (4*d-byte segments), 8 rows in flight.
 __device__ __forceinline__ void stage_rows(float* dst, int P, const float* src, int ld, int row0, int hoff,
                                            int nrows_valid, int d, int nrows, int tr, int nw) {
     const int tc = threadIdx.x & 63;
+    const float* base = src + (size_t)row0 * ld + hoff;
+    if (ld == d && ((reinterpret_cast<uintptr_t>(base) & 15) == 0)) {
+        const int tid = tr * 64 + tc, nth = nw * 64;
+        const int nv = nrows_valid < 0 ? 0 : (nrows_valid < nrows ? nrows_valid : nrows);
+        const int total = nv * d, n4 = total >> 2;
+        const float inv_d = 1.0f / (float)d;
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        constexpr int U4 = 4;
+        for (int i0 = tid; i0 < n4; i0 += nth * U4) {
+            float4 v[U4];
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                const int i = i0 + u * nth;
+                v[u] = b4[i < n4 ? i : n4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                const int i = i0 + u * nth;
+                if (i < n4) {
+                    const int idx = 4 * i;
+                    int r = (int)(((float)idx + 0.5f) * inv_d);      // exact: idx < 2^16, |(idx+.5)/d - integer| >= 1/(2d)
+                    int c = idx - r * d;
+                    const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dst[r * P + c] = e[k];
+                        if (++c == d) { c = 0; ++r; }
+                    }
+                }
+            }
+        }
+        for (int i = 4 * n4 + tid; i < total; i += nth) {                // at most 3 elements
+            const int r = i / d;
+            dst[r * P + (i - r * d)] = base[i];
+        }
+        const int npad = P - d;
+        for (int i = tid; i < nv * npad; i += nth) {
+            const int r = i / npad;
+            dst[r * P + d + (i - r * npad)] = 0.0f;
+        }
+        for (int i = nv * P + tid; i < nrows * P; i += nth) dst[i] = 0.0f;
+        return;
+    }
     constexpr int U = 8;
     for (int t0 = tr; t0 < nrows; t0 += nw * U) {
         float v[U];

@@ -7,14 +7,17 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const int nw = blockDim.x >> 6;
     float* Ks = smem;                                   // [T16][PA]  A-pattern reads
     float* Vs = Ks + g.T16 * g.PA;                      // [T16][PB]  B-pattern reads (+ tail)
-    float* Qs = Vs + g.T16 * g.PB + A_TAIL;             // [nw][16][PA] per-wave query tile slot
-    float* kv = Qs + nw * 16 * g.PA;                    // [T16]
+    float* kv = Vs + g.T16 * g.PB + A_TAIL;             // [T16]
     float* qv = kv + g.T16;                             // [T16]
     float* dead = qv + g.T16;                           // [T16]
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int nwaves = gridDim.y * nw;
+    int qi = wave * gridDim.y + blockIdx.y;             // interleaved: every workgroup gets heavy and light tiles
+    float qn[NDS];                                      // Q fragment of the wave's next tile, in flight during the staging
+    if (qi < g.nkt) frag_issue<NDS>(d.Q, d.ld, base_row + 16 * (g.nkt - 1 - qi), hoff, T - 16 * (g.nkt - 1 - qi), d.d, qn);
     stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
     stage_rows(Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
     for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
@@ -26,11 +29,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const uint64_t kbits = key_bits<NKT>(kv, T);
     const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
-    float* Qw = Qs + wave * 16 * g.PA;
-    const int nwaves = gridDim.y * nw;
-    for (int qi = wave * gridDim.y + blockIdx.y; qi < g.nkt; qi += nwaves) {   // interleaved: every workgroup gets heavy and light tiles
+    for (; qi < g.nkt; qi += nwaves) {
         const int qt = g.nkt - 1 - qi;                  // heaviest tiles first
         const int q0 = 16 * qt, q = q0 + li;
+        float qf[NDS];
+        frag_finish<NDS>(qn, T - q0, d.d, qf);
+        if (qi + nwaves < g.nkt) {                      // prefetch the next tile's fragment behind this tile's work
+            const int qtn = g.nkt - 1 - (qi + nwaves);
+            frag_issue<NDS>(d.Q, d.ld, base_row + 16 * qtn, hoff, T - 16 * qtn, d.d, qn);
+        }
         const bool is_dead = dead[q] != 0.0f;
         if (__all(is_dead ? 1 : 0) && d.attn_weights == nullptr) {
             // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
@@ -43,9 +50,6 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
             }
             continue;
         }
-        stage_rows(Qw, g.PA, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, 16, 0, 1);
-        float qf[NDS];
-        load_frag<NDS>(Qw, g.PA, qf);
         f32x4 st[NKT];
         float m2, inv;
         bool uniform;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
 }
 
 static size_t lds_fwd(const AttnGeom& g, int w) {
-    return sizeof(float) * ((size_t)g.T16 * (g.PA + g.PB) + A_TAIL + (size_t)w * 16 * g.PA + 3 * g.T16);
+    return sizeof(float) * ((size_t)g.T16 * (g.PA + g.PB) + A_TAIL + 3 * g.T16) + 0 * (size_t)w;
 }
 
 template <int NKT, int NDS, int NDT>

@@ -4,7 +4,7 @@
 //
 // Tile shapes: workgroup = 4 waves = 64 rows (wave w owns rows [16w, 16w+16)), all D (<= 64) columns.
 // MFMA v_mfma_f32_16x16x4_f32.  LDS pitches: row tiles / row-read weights P = 4*ceil(D/4) + 2 (A-pattern
-// conflict-free, % 4 == 2); column-read weights PW = 80 (B-pattern conflict-free).  All LDS is dynamic and
+// conflict-free, % 4 == 2); column-read weights are stored packed (see BK_WROW).  All LDS is dynamic and
 // sized by D, so the forward kernels fit two workgroups per CU.
 //
 // Latency structure (profiles/r01_d_*): forward kernels stage the row tile and ALL their weights with one
@@ -15,7 +15,15 @@
 
 #include "cr_common.hpp"
 
-#define BK_PW 80
+// Column-read weights (B operand of x @ W) are stored PACKED: element (k, n) at
+//   (k >> 1) * 128 + (n >> 4) * 32 + (k & 1) * 16 + (n & 15)
+// so the 32 lanes of a ds_read_b32 half (li = n & 15, lg in {0,1} or {2,3}: k = 4kk + lg) hit 32 distinct banks
+// with no padding at all: 64 floats per k-row instead of the 80-float pitch a plain row layout needs.  At D = 50
+// that takes the QKV kernel from 85 KB to 75 KB of LDS -- two workgroups per CU instead of one, which the
+// per-wave timeline (tools/block_ts.py) showed to be the difference between one and two serial rounds.
+#define BK_WROW 64
+#define F3_P 66          // row-tile pitch of the pad-tolerant kernels (64 columns + 2, % 4 == 2)
+__device__ __forceinline__ int bk_waddr(int k, int n) { return (k >> 1) * 128 + (n >> 4) * 32 + (k & 1) * 16 + (n & 15); }
 
 struct BlockGeom {
     int P;        // row-tile pitch
@@ -23,7 +31,19 @@ struct BlockGeom {
     int ones;     // column holding 1.0 for the bias-gradient trick, or -1 (D == 64)
     int dbg;      // timing-only ablation switches (env CR_BLOCK_DBG); 0 in production
     uint32_t invD;  // floor(2^32 / D) + 1: e / D == umulhi(e, invD) for e < 2^16
+    unsigned long long* ts;   // debug: per-wave phase timestamps [n_wg][4 waves][16] (tools/block_ts.py); NULL in production
 };
+
+// debug-only phase stamps: slots 0 / 15 = wall clock (100 MHz, comparable across the chip), others = s_memtime
+#define BK_TSG(geom, slot)                                                                                   \
+    do {                                                                                                     \
+        if ((geom).ts && (threadIdx.x & 63) == 0)                                                            \
+            (geom).ts[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] =                         \
+                ((slot) == 0 || (slot) == 15) ? wall_clock64() : clock64();                                  \
+    } while (0)
+#define BK_TS(slot) BK_TSG(g, slot)
+static unsigned long long* g_block_ts = nullptr;
+extern "C" void cr_debug_block_ts(void* p) { g_block_ts = static_cast<unsigned long long*>(p); }
 
 // ---- small helpers ---------------------------------------------------------------------------------
 // 16 elements per thread of a [64 x 64] window of a row-major matrix: rows m0 + tr + 4i, column c0 + tc
@@ -53,7 +73,7 @@ __device__ __forceinline__ void load_tile(float* dst, const float* src, int ld, 
 }
 
 // weight [K=D rows][N=D cols] (row pitch ldw, column offset c0) -> Ws[k][pitch]; zero padded to 64 x 64.
-// pitch = BK_PW: B operand of x @ W (column-read).  pitch = P: read by rows it is the B operand of g @ W^T.
+// Read by rows (pitch P) it is the B operand of g @ W^T.
 __device__ __forceinline__ void load_w(float* Ws, int pitch, const float* W, int ldw, int c0, int D, int rows = 64) {
     const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63;
     float v[16];
@@ -69,17 +89,76 @@ __device__ __forceinline__ void load_w(float* Ws, int pitch, const float* W, int
     }
 }
 
-// acc[j] (+)= As[rows 16w..][k] * Ws[k][16j..]   (x @ W), ks k-steps
+// Weight [K=D rows][N=D cols] (row pitch ldw, column offset c0) -> packed LDS image of 4*ks k-rows x 64, zero padded.
+// The vector-memory pipe of a CU retires one wave-instruction per ~16 clocks whatever its width (per-wave
+// timelines, tools/block_ts.py), so the weights are fetched as 16-byte chunks -- 4 loads per thread instead of
+// 16 dword loads; gfx950 global loads need only dword alignment.  Item (k, q) = row k, columns [4q, 4q+4);
+// a chunk that would cross column D is read shifted back to [D-4, D) and rotated, so nothing outside the
+// weight is touched.  Two halves: fetch_w (loads) ... put_w_packed / put_wt_packed (LDS writes); the latter
+// stores the TRANSPOSED weight, B(k = n, col = k') = W[k'][n], which makes g @ W^T a plain tile_mma.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+struct WFrag { f4u v[4]; };
+__device__ __forceinline__ void fetch_w(WFrag& w, const float* W, int ldw, int c0, int D) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+        const bool valid = (k < D) && (4 * q < D);
+        const int col = valid ? min(4 * q, D - 4) : 0;
+        w.v[it] = *reinterpret_cast<const f4u*>(W + (size_t)(valid ? k : 0) * ldw + c0 + col);
+    }
+}
+// element t of item `it` after the zero padding / back-shift fix-up
+__device__ __forceinline__ void wfrag_item(const WFrag& w, int it, int D, float (&e)[4]) {
+    const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+    const bool valid = (k < D) && (4 * q < D);
+    const int shift = valid ? 4 * q - min(4 * q, D - 4) : 0;
+    const float x0 = w.v[it].x, x1 = w.v[it].y, x2 = w.v[it].z, x3 = w.v[it].w;
+    const float r0 = shift == 0 ? x0 : (shift == 1 ? x1 : (shift == 2 ? x2 : x3));
+    const float r1 = shift == 0 ? x1 : (shift == 1 ? x2 : (shift == 2 ? x3 : 0.0f));
+    const float r2 = shift == 0 ? x2 : (shift == 1 ? x3 : 0.0f);
+    const float r3 = shift == 0 ? x3 : 0.0f;
+    e[0] = (valid && 4 * q + 0 < D) ? r0 : 0.0f;
+    e[1] = (valid && 4 * q + 1 < D) ? r1 : 0.0f;
+    e[2] = (valid && 4 * q + 2 < D) ? r2 : 0.0f;
+    e[3] = (valid && 4 * q + 3 < D) ? r3 : 0.0f;
+}
+__device__ __forceinline__ void put_w_packed(float* Ws, const WFrag& w, int D, int nrows) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+        float e[4];
+        wfrag_item(w, it, D, e);
+        if (k < nrows) *reinterpret_cast<float4*>(Ws + bk_waddr(k, 4 * q)) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+__device__ __forceinline__ void put_wt_packed(float* Ws, const WFrag& w, int D, int nrows) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+        float e[4];
+        wfrag_item(w, it, D, e);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q + t < nrows) Ws[bk_waddr(4 * q + t, k)] = e[t];
+    }
+}
+__device__ __forceinline__ void load_w_packed(float* Ws, const float* W, int ldw, int c0, int D, int rows) {
+    WFrag w;
+    fetch_w(w, W, ldw, c0, D);
+    put_w_packed(Ws, w, D, rows);
+}
+
+// acc[j] (+)= As[rows 16w..][k] * W[k][16j..]   (x @ W), ks k-steps, W in the packed layout
 __device__ __forceinline__ void tile_mma(f32x4 (&acc)[4], const float* As, int P, const float* Ws, int ks, int wave) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const float* ap = As + (16 * wave + li) * P + lg;
-    const float* bp = Ws + lg * BK_PW + li;
+    const float* bp = Ws + (lg >> 1) * 128 + (lg & 1) * 16 + li;
 #pragma unroll 2
     for (int kk = 0; kk < ks; ++kk) {
         const float a = ap[4 * kk];
         float b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = bp[4 * kk * BK_PW + 16 * j];
+        for (int j = 0; j < 4; ++j) b[j] = bp[kk * 256 + 32 * j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = mfma16(a, b[j], acc[j]);
     }
@@ -211,12 +290,46 @@ __device__ __forceinline__ void ln_rows(const float* Xs, float* Ys, int P, const
     }
 }
 
+// A wave's 16 rows x D floats as <= 4 float4 per lane (D <= 64): fetched early, placed into LDS later.
+struct Stream4 { float4 v[4]; };
+__device__ __forceinline__ void stream_fetch(Stream4& s, const float* gsrc, int total) {
+    const int lane = threadIdx.x & 63;
+    const bool vec = (reinterpret_cast<uintptr_t>(gsrc) & 15) == 0;     // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = lane + 64 * i;
+        s.v[i] = (vec && 4 * f + 3 < total) ? reinterpret_cast<const float4*>(gsrc)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * f < total && (!vec || 4 * f + 3 >= total)) {   // unaligned base or ragged tail: element-wise
+            float* pv = reinterpret_cast<float*>(&s.v[i]);
+            for (int u = 0; u < 4; ++u) pv[u] = (4 * f + u < total) ? gsrc[4 * f + u] : 0.0f;
+        }
+    }
+}
+// place the stream into the wave's rows of a pitch-66 tile; `scale_fn(e, v)` maps flat element e -> value
+template <class F>
+__device__ __forceinline__ void stream_put(float* Ts, const Stream4& s, int D, int total, uint32_t invD, F fn) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e0 = 4 * (lane + 64 * i);
+        if (e0 < total) {
+            int r = (int)__umulhi((uint32_t)e0, invD), c = e0 - r * D;
+            const float* pv = reinterpret_cast<const float*>(&s.v[i]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + u < total) Ts[r * F3_P + c] = fn(e0 + u, r, pv[u]);
+                if (++c == D) { c = 0; ++r; }
+            }
+        }
+    }
+}
+struct PutPlain { __device__ __forceinline__ float operator()(int, int, float v) const { return v; } };
+
 // ---- F3: LN2 + point-wise feed-forward + residual + mask -----------------------------------------------
 // Pad-tolerant, branch-free element code: tiles have pitch 66 and ALL 64 columns are computed and written to
 // LDS unconditionally -- weights, biases and inputs are zero beyond D, so pad columns come out as exact zeros
 // (relu(0) = 0, dropout(0) = 0) without a single per-lane condition.  Global traffic goes through the
 // wave-contiguous row streams, which know the valid row count.
-#define F3_P 66
 __device__ __forceinline__ void ln_rows_fast(const float* Xs, float* Ys, const float* gam, const float* bet, int D, int wave) {
     // LayerNorm (modules.py:74-78) of the wave's 16 rows; gam/bet are zero-padded LDS arrays of 64 floats
     const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
@@ -245,9 +358,9 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     const int D = d.D;
     float* Os = smem;                       // [64][66] input tile, reused for the hidden tile and the output tile
     float* Fs = Os + 64 * F3_P;             // [64][66]
-    float* W1s = Fs + 64 * F3_P;            // [4*ks][PW]
-    float* W2s = W1s + 4 * g.ks * BK_PW;    // [4*ks][PW]
-    float* vec = W2s + 4 * g.ks * BK_PW;    // 4 x [64]: gamma2, beta2, b1, b2 (zero padded)
+    float* W1s = Fs + 64 * F3_P;            // packed [4*ks][64]
+    float* W2s = W1s + 4 * g.ks * BK_WROW;  // packed [4*ks][64]
+    float* vec = W2s + 4 * g.ks * BK_WROW;  // 4 x [64]: gamma2, beta2, b1, b2 (zero padded)
     float* msk = vec + 256;                 // [64] row mask (sasrec.py:83)
     float* Hs = Os;
     const int m0 = blockIdx.x * 64;
@@ -256,8 +369,13 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     const int nr = max(0, min(16, d.M - mw));                       // its valid rows
     for (int e = lane; e < 16 * F3_P; e += 64) Os[16 * wave * F3_P + e] = 0.0f;
     if (nr > 0) wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
-    load_w(W1s, BK_PW, d.w1, D, 0, D, 4 * g.ks);
-    load_w(W2s, BK_PW, d.w2, D, 0, D, 4 * g.ks);
+    {
+        WFrag wa, wb;
+        fetch_w(wa, d.w1, D, 0, D);
+        fetch_w(wb, d.w2, D, 0, D);
+        put_w_packed(W1s, wa, D, 4 * g.ks);
+        put_w_packed(W2s, wb, D, 4 * g.ks);
+    }
     {
         const int t = threadIdx.x, c = t & 63, which = t >> 6;
         const float* src = which == 0 ? d.ln2_g : (which == 1 ? d.ln2_b : (which == 2 ? d.b1 : d.b2));
@@ -311,23 +429,31 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
     const int D = d.D;
     float* Xs = smem;                       // [64][66]
     float* Qs = Xs + 64 * F3_P;             // [64][66] LN1 output, then staging of each projection's result
-    float* Ws = Qs + 64 * F3_P;             // 3 x [4*ks][PW]: Wq, Wk, Wv
-    const int wsz = 4 * g.ks * BK_PW;
+    float* Ws = Qs + 64 * F3_P;             // 3 x packed [4*ks][64]: Wq, Wk, Wv
+    const int wsz = 4 * g.ks * BK_WROW;
     float* vec = Ws + 3 * wsz;              // 5 x [64]: gamma1, beta1, bq, bk, bv (zero padded)
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;
     const int nr = max(0, min(16, d.M - mw));
+    BK_TS(0); BK_TS(1);
     for (int e = lane; e < 16 * F3_P; e += 64) Xs[16 * wave * F3_P + e] = 0.0f;
     if (nr > 0) wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
-#pragma unroll 1
-    for (int part = 0; part < 3; ++part) load_w(Ws + part * wsz, BK_PW, d.wqkv, 3 * D, part * D, D, 4 * g.ks);
+    {
+        WFrag w3[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fetch_w(w3[part], d.wqkv, 3 * D, part * D, D);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) put_w_packed(Ws + part * wsz, w3[part], D, 4 * g.ks);
+    }
     for (int t = threadIdx.x; t < 320; t += 256) {
         const int c = t & 63, which = t >> 6;
         const float* src = which == 0 ? d.ln1_g : (which == 1 ? d.ln1_b : d.bqkv + (which - 2) * D);
         vec[t] = (c < D) ? src[c] : 0.0f;
     }
+    BK_TS(2);
     __syncthreads();                        // the only barrier
+    BK_TS(3);
     // LN1 with the data-dependent key / query masks (modules.py:222,248-249)
     {
         const int l = lane & 15, sub = lane >> 4;
@@ -358,6 +484,7 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
         }
     }
     if (nr > 0) wave_store_rows(d.q_in + (size_t)mw * D, Qs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    BK_TS(4);
 #pragma unroll 1
     for (int part = 0; part < 3; ++part) {                                                  // modules.py:203-205
         f32x4 acc[4];
@@ -370,46 +497,14 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
             for (int r = 0; r < 4; ++r) Qs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = acc[j][r] + bias;
         }
         if (nr > 0) wave_store_rows(d.qkv + ((size_t)part * d.M + mw) * D, Qs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+        if (part == 0) BK_TS(5);
     }
+    BK_TS(6); BK_TS(15);
 }
 
 // =====================================================================================================
 // backward
 // =====================================================================================================
-// A wave's 16 rows x D floats as <= 4 float4 per lane (D <= 64): fetched early, placed into LDS later.
-struct Stream4 { float4 v[4]; };
-__device__ __forceinline__ void stream_fetch(Stream4& s, const float* gsrc, int total) {
-    const int lane = threadIdx.x & 63;
-    const bool vec = (reinterpret_cast<uintptr_t>(gsrc) & 15) == 0;     // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = lane + 64 * i;
-        s.v[i] = (vec && 4 * f + 3 < total) ? reinterpret_cast<const float4*>(gsrc)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (4 * f < total && (!vec || 4 * f + 3 >= total)) {   // unaligned base or ragged tail: element-wise
-            float* pv = reinterpret_cast<float*>(&s.v[i]);
-            for (int u = 0; u < 4; ++u) pv[u] = (4 * f + u < total) ? gsrc[4 * f + u] : 0.0f;
-        }
-    }
-}
-// place the stream into the wave's rows of a pitch-66 tile; `scale_fn(e, v)` maps flat element e -> value
-template <class F>
-__device__ __forceinline__ void stream_put(float* Ts, const Stream4& s, int D, int total, uint32_t invD, F fn) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e0 = 4 * (lane + 64 * i);
-        if (e0 < total) {
-            int r = (int)__umulhi((uint32_t)e0, invD), c = e0 - r * D;
-            const float* pv = reinterpret_cast<const float*>(&s.v[i]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (e0 + u < total) Ts[r * F3_P + c] = fn(e0 + u, r, pv[u]);
-                if (++c == D) { c = 0; ++r; }
-            }
-        }
-    }
-}
-struct PutPlain { __device__ __forceinline__ float operator()(int, int, float v) const { return v; } };
 
 // zero the wave's 16 rows of a tile (pad columns / rows beyond the valid count must read as 0)
 __device__ __forceinline__ void zero_rows(float* Ts) {
@@ -519,19 +614,20 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
     float* T1 = smem;                      // g2                             -> later df -> d_o
     float* T2 = T1 + 64 * F3_P;            // hid (+ ones column)            -> later g1
     float* T3 = T2 + 64 * F3_P;            // f_in (+ ones column)           -> later o
-    float* T4 = T3 + 64 * F3_P;            // dy * mask (residual branch)
-    float* W1r = T4 + 64 * F3_P;           // W1 [k][66], read by rows
-    float* W2r = W1r + 64 * F3_P;          // W2 [k][66]
-    float* gam = W2r + 64 * F3_P;          // [64] gamma2, zero padded
+    float* W1t = T3 + 64 * F3_P;           // W1^T, packed [4*ks][64]
+    float* W2t = W1t + 4 * ks * BK_WROW;   // W2^T, packed
+    float* gam = W2t + 4 * ks * BK_WROW;   // [64] gamma2, zero padded
     float* msk = gam + 64;                 // [64] row mask of the current tile
     float* sg = msk + 64;                  // [4][64] + [4][64]
     float* sb = sg + 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int rps = rows_per_wg(d.M, gridDim.x);
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
-    load_w(W1r, F3_P, d.w1, D, 0, D);
-    load_w(W2r, F3_P, d.w2, D, 0, D);
-    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? d.ln2_g[threadIdx.x] : 0.0f;
+    // one burst of loads (weights, gamma, the first tile's streams below) before any of them is consumed
+    WFrag vw1, vw2;
+    fetch_w(vw1, d.w1, D, 0, D);
+    fetch_w(vw2, d.w2, D, 0, D);
+    const float gam_v = d.ln2_g[threadIdx.x < D ? threadIdx.x : 0];
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
     f32x4 aw1[4], aw2[4];
@@ -539,6 +635,7 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
     float b1s = 0.0f, b2s = 0.0f;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     Stream4 sdy, shid, sfin;
+    BK_TSG(gm, 0); BK_TSG(gm, 1);
     auto fetch = [&](int m0) {
         const int mw = m0 + 16 * wave;
         const int tot = max(0, min(16, me - mw)) * D;
@@ -547,39 +644,47 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
         stream_fetch(sfin, d.f_in + (size_t)mw * D, tot);
     };
     if (mb < me) fetch(mb);
+    BK_TSG(gm, 2);
+    put_wt_packed(W1t, vw1, D, 4 * ks);
+    put_wt_packed(W2t, vw2, D, 4 * ks);
+    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? gam_v : 0.0f;
+    BK_TSG(gm, 3);
     for (int m0 = mb; m0 < me; m0 += 64) {
         const int mw = m0 + 16 * wave;
         const int nr = max(0, min(16, me - mw)), tot = nr * D;
         float* t1 = T1 + 16 * wave * F3_P; float* t2 = T2 + 16 * wave * F3_P;
-        float* t3 = T3 + 16 * wave * F3_P; float* t4 = T4 + 16 * wave * F3_P;
+        float* t3 = T3 + 16 * wave * F3_P;
         if (lane < 16) msk[16 * wave + lane] = (lane < nr && d.mask_ids[mw + lane] != 0) ? 1.0f : 0.0f;
-        zero_rows(t1); zero_rows(t2); zero_rows(t3); zero_rows(t4);
-        // g2 = dy * mask * keep2/(1-rate) (sasrec.py:83, modules.py:309-310); T4 = dy * mask
+        zero_rows(t1); zero_rows(t2); zero_rows(t3);
+        if (m0 == mb) BK_TSG(gm, 4);
+        // g2 = dy * mask * keep2/(1-rate) (sasrec.py:83, modules.py:309-310)
         {
             const float* mrow = msk + 16 * wave;
             const uint32_t base = (d.drop_ffn2.row_offset + (uint32_t)mw) * (uint32_t)D;
-            stream_put(t4, sdy, D, tot, gm.invD, [&](int, int r, float v) { return v * mrow[r]; });
             stream_put(t1, sdy, D, tot, gm.invD, [&](int e, int r, float v) {
                 float x = v * mrow[r];
                 if (d2.on) x *= (cr_fmix32((base + (uint32_t)e) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;
                 return x;
             });
         }
+        if (m0 == mb) BK_TSG(gm, 5);
         stream_put(t2, shid, D, tot, gm.invD, PutPlain());
         stream_put(t3, sfin, D, tot, gm.invD, PutPlain());
         plant_ones(t2, ones, nr);
         plant_ones(t3, ones, nr);
+        if (m0 == mb) BK_TSG(gm, 6);
         __syncthreads();
         if (m0 + 64 < me) fetch(m0 + 64);                          // next tile's loads fly under this tile's MFMAs
         // dW2 (+ db2 in row `ones`) += hid^T g2
         tile_wgrad(aw2, T2, T1, F3_P, wave);
         if (ones < 0 && threadIdx.x < 64) b2s += colsum64(T1);
         __syncthreads();
+        if (m0 == mb) BK_TSG(gm, 7);
         // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (in place over hid, own rows)
         {
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma_t(acc, T1, W2r, F3_P, ks, wave);
+            tile_mma(acc, T1, F3_P, W2t, ks, wave);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -590,30 +695,44 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
                 }
         }
         __syncthreads();
+        if (m0 == mb) BK_TSG(gm, 8);
         // dW1 (+ db1) += f_in^T g1
         tile_wgrad(aw1, T3, T2, F3_P, wave);
         if (ones < 0 && threadIdx.x < 64) b1s += colsum64(T2);
         // df = g1 W1^T + dy*mask  (residual of modules.py:313; g1 rows of masked positions are 0) -> T1 (own rows)
         {
-            f32x4 acc[4];
-            zero_acc(acc);
-            tile_mma_t(acc, T2, W1r, F3_P, ks, wave);
+            // residual dy * mask in the accumulator layout, re-read from L2 (this tile's dy was streamed a moment ago)
+            float res[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int o = (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
-                    T1[o] = acc[j][r] + T4[o];
+                    const bool ok = (4 * lg + r < nr) && (16 * j + li < D);
+                    res[j][r] = bd.dy[ok ? (size_t)(mw + 4 * lg + r) * D + 16 * j + li : (size_t)mb * D];
+                }
+            f32x4 acc[4];
+            zero_acc(acc);
+            tile_mma(acc, T2, F3_P, W1t, ks, wave);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + 4 * lg + r;
+                    const bool ok = (4 * lg + r < nr) && (16 * j + li < D);
+                    T1[row * F3_P + 16 * j + li] = acc[j][r] + (ok ? res[j][r] * msk[row] : 0.0f);
                 }
         }
         __syncthreads();                                           // all waves are done with every row of T3
+        if (m0 == mb) BK_TSG(gm, 9);
         // LN2 backward in place on own rows: x = o (streamed into T3), dy = df (T1) -> d_o (T1)
         zero_rows(t3);
         if (nr > 0) wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
         ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, wave);
         if (nr > 0) wave_store_rows(bd.d_o + (size_t)mw * D, t1, F3_P, D, nr, gm.invD);
         __syncthreads();
+        if (m0 == mb) BK_TSG(gm, 10);
     }
+    BK_TSG(gm, 15);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     store_wgrad(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, ones, wave);
     store_wgrad(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, ones, wave);
@@ -723,13 +842,15 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, 
 static int block_check(const cr_block_desc* d, BlockGeom* g, const char* who) {
     CR_REQUIRE(d != nullptr, "%s: NULL desc", who);
     CR_REQUIRE(d->M > 0 && d->D > 0, "%s: bad shape", who);
-    if (d->D > 64) return cr_set_error(CR_ERR_UNSUPPORTED, "%s: D=%d > 64 (use the unfused kernels)", who, d->D);
+    if (d->D > 64 || d->D < 4)
+        return cr_set_error(CR_ERR_UNSUPPORTED, "%s: D=%d outside [4, 64] (use the unfused kernels)", who, d->D);
     g->ks = (d->D + 3) / 4;
     g->P = 4 * g->ks + 2;
     g->ones = d->D < 64 ? d->D : -1;
     g->invD = (uint32_t)(4294967296.0 / d->D) + 1u;
     const char* e = getenv("CR_BLOCK_DBG");
     g->dbg = e ? atoi(e) : 0;
+    g->ts = g_block_ts;
     return CR_OK;
 }
 
@@ -751,7 +872,7 @@ extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 3 * 4 * g.ks * BK_PW + 320);
+    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 3 * 4 * g.ks * BK_WROW + 320);
     hipLaunchKernelGGL(k_block_ln_qkv_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
     return cr_check_launch("cr_block_ln_qkv_fwd");
 }
@@ -765,7 +886,7 @@ extern "C" int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 2 * 4 * g.ks * BK_PW + 256 + 64);
+    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 2 * 4 * g.ks * BK_WROW + 256 + 64);
     hipLaunchKernelGGL(k_block_ln_ffn_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
     return cr_check_launch("cr_block_ln_ffn_fwd");
 }
@@ -781,7 +902,7 @@ extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {
     static bool attr = false;
     rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd), &attr);
     if (rc) return rc;
-    const size_t lds = sizeof(float) * (6 * 64 * F3_P + 128 + 512);
+    const size_t lds = sizeof(float) * (3 * 64 * F3_P + 2 * 4 * g.ks * BK_WROW + 128 + 512);
     hipLaunchKernelGGL(k_block_ln_ffn_bwd, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
     return cr_check_launch("cr_block_ln_ffn_bwd");
 }

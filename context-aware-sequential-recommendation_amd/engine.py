@@ -172,9 +172,9 @@ class Engine:
         self.usernum, self.itemnum = usernum, itemnum
         self.training = training
         # fused row-phase kernels (cr_block_*) need the hidden size to fit one 64-column tile
-        self.fused = (hp.hidden_units <= 64) if fused is None else bool(fused)
-        if self.fused and hp.hidden_units > 64:
-            raise ValueError("fused block kernels need hidden_units <= 64")
+        self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
+        if self.fused and not 4 <= hp.hidden_units <= 64:
+            raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
         self.dev = torch.device(device)
         self.seed = hp.seed if seed is None else seed
         self.layout = share.layout if share is not None else ParamLayout(model, usernum, itemnum, hp)
