@@ -38,7 +38,7 @@ struct BlockGeom {
 #define BK_TSG(geom, slot)                                                                                   \
     do {                                                                                                     \
         if ((geom).ts && (threadIdx.x & 63) == 0)                                                            \
-            (geom).ts[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] =                         \
+            (geom).ts[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] =        \
                 ((slot) == 0 || (slot) == 15) ? wall_clock64() : clock64();                                  \
     } while (0)
 #define BK_TS(slot) BK_TSG(g, slot)
@@ -97,19 +97,23 @@ __device__ __forceinline__ void load_w(float* Ws, int pitch, const float* W, int
 // weight is touched.  Two halves: fetch_w (loads) ... put_w_packed / put_wt_packed (LDS writes); the latter
 // stores the TRANSPOSED weight, B(k = n, col = k') = W[k'][n], which makes g @ W^T a plain tile_mma.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-struct WFrag { f4u v[4]; };
-__device__ __forceinline__ void fetch_w(WFrag& w, const float* W, int ldw, int c0, int D) {
+// NT = threads of the workgroup (256 or 512): 1024 items, 1024 / NT per thread
+template <int NT> struct WFragT { f4u v[1024 / NT]; };
+typedef WFragT<256> WFrag;
+template <int NT>
+__device__ __forceinline__ void fetch_w(WFragT<NT>& w, const float* W, int ldw, int c0, int D) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
         const bool valid = (k < D) && (4 * q < D);
         const int col = valid ? min(4 * q, D - 4) : 0;
         w.v[it] = *reinterpret_cast<const f4u*>(W + (size_t)(valid ? k : 0) * ldw + c0 + col);
     }
 }
 // element t of item `it` after the zero padding / back-shift fix-up
-__device__ __forceinline__ void wfrag_item(const WFrag& w, int it, int D, float (&e)[4]) {
-    const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+template <int NT>
+__device__ __forceinline__ void wfrag_item(const WFragT<NT>& w, int it, int D, float (&e)[4]) {
+    const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
     const bool valid = (k < D) && (4 * q < D);
     const int shift = valid ? 4 * q - min(4 * q, D - 4) : 0;
     const float x0 = w.v[it].x, x1 = w.v[it].y, x2 = w.v[it].z, x3 = w.v[it].w;
@@ -122,19 +126,21 @@ __device__ __forceinline__ void wfrag_item(const WFrag& w, int it, int D, float 
     e[2] = (valid && 4 * q + 2 < D) ? r2 : 0.0f;
     e[3] = (valid && 4 * q + 3 < D) ? r3 : 0.0f;
 }
-__device__ __forceinline__ void put_w_packed(float* Ws, const WFrag& w, int D, int nrows) {
+template <int NT>
+__device__ __forceinline__ void put_w_packed(float* Ws, const WFragT<NT>& w, int D, int nrows) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
         float e[4];
         wfrag_item(w, it, D, e);
         if (k < nrows) *reinterpret_cast<float4*>(Ws + bk_waddr(k, 4 * q)) = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
-__device__ __forceinline__ void put_wt_packed(float* Ws, const WFrag& w, int D, int nrows) {
+template <int NT>
+__device__ __forceinline__ void put_wt_packed(float* Ws, const WFragT<NT>& w, int D, int nrows) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int item = threadIdx.x + 256 * it, k = item >> 4, q = item & 15;
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
         float e[4];
         wfrag_item(w, it, D, e);
 #pragma unroll
@@ -530,10 +536,10 @@ __device__ __forceinline__ void store_wgrad(float* dst, int ldw, float* bias_dst
     }
 }
 
-__device__ __forceinline__ float colsum64(const float* Ts) {     // D == 64 fallback: thread tid < 64 sums column tid
+__device__ __forceinline__ float colsum64(const float* Ts, int col) {   // D == 64 fallback: one thread sums one column
     float s = 0.0f;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += Ts[r * F3_P + threadIdx.x];
+    for (int r = 0; r < 64; ++r) s += Ts[r * F3_P + col];
     return s;
 }
 
@@ -578,6 +584,7 @@ __device__ __forceinline__ void ln_bwd_rows(const float* Xs, float* DYs, const f
 
 // fold the per-lane LayerNorm partials (4 row groups per wave via shuffles, then the 4 waves through
 // per-wave LDS slots summed in a fixed order: bitwise reproducible) and write the slab entries
+template <int NW = 4>
 __device__ __forceinline__ void store_ln_grads(float* sg, float* sb, float (&ag)[4], float (&ab)[4], float* dg, float* db, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 15, sub = lane >> 4;
     __syncthreads();
@@ -589,9 +596,15 @@ __device__ __forceinline__ void store_ln_grads(float* sg, float* sb, float (&ag)
         if (sub == 0) { sg[wave * 64 + c] = ag[i]; sb[wave * 64 + c] = ab[i]; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        dg[c] = (sg[c] + sg[64 + c]) + (sg[128 + c] + sg[192 + c]);
-        db[c] = (sb[c] + sb[64 + c]) + (sb[128 + c] + sb[192 + c]);
+    for (int c = threadIdx.x; c < D; c += 64 * NW) {
+        float g = (sg[c] + sg[64 + c]) + (sg[128 + c] + sg[192 + c]);
+        float b = (sb[c] + sb[64 + c]) + (sb[128 + c] + sb[192 + c]);
+        if (NW == 8) {
+            g += (sg[256 + c] + sg[320 + c]) + (sg[384 + c] + sg[448 + c]);
+            b += (sb[256 + c] + sb[320 + c]) + (sb[384 + c] + sb[448 + c]);
+        }
+        dg[c] = g;
+        db[c] = b;
     }
 }
 
@@ -607,26 +620,35 @@ __device__ __forceinline__ void plant_ones(float* Ts, int ones, int nr) {
 }
 
 // ---- B3: backward of LN2 + FFN --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
+// NG groups of 4 waves per workgroup; each group works on its own 64-row tile (own T1..T3, own row mask), all
+// share one copy of the weights.  NG = 2 puts two waves on every SIMD (the kernel is a chain of dependent
+// load -> LDS -> MFMA -> LDS steps; a single wave per SIMD leaves each of them exposed) without doubling the
+// number of gradient slabs.  Barriers are workgroup-wide; a group whose tile lies beyond the workgroup's rows
+// runs the phases on zero rows.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
+    constexpr int NT = 256 * NG;
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = d.D, ks = gm.ks, ones = gm.ones;
-    float* T1 = smem;                      // g2                             -> later df -> d_o
-    float* T2 = T1 + 64 * F3_P;            // hid (+ ones column)            -> later g1
-    float* T3 = T2 + 64 * F3_P;            // f_in (+ ones column)           -> later o
-    float* W1t = T3 + 64 * F3_P;           // W1^T, packed [4*ks][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int grp = wave >> 2, w4 = wave & 3, gtid = threadIdx.x & 255;
+    float* W1t = smem;                     // W1^T, packed [4*ks][64]
     float* W2t = W1t + 4 * ks * BK_WROW;   // W2^T, packed
     float* gam = W2t + 4 * ks * BK_WROW;   // [64] gamma2, zero padded
-    float* msk = gam + 64;                 // [64] row mask of the current tile
-    float* sg = msk + 64;                  // [4][64] + [4][64]
-    float* sb = sg + 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int rps = rows_per_wg(d.M, gridDim.x);
+    float* sg = gam + 64;                  // [4*NG][64] + [4*NG][64]
+    float* sb = sg + 256 * NG;
+    float* Tg = sb + 256 * NG + grp * (3 * 64 * F3_P + 64);
+    float* T1 = Tg;                        // g2                             -> later df -> d_o
+    float* T2 = T1 + 64 * F3_P;            // hid (+ ones column)            -> later g1
+    float* T3 = T2 + 64 * F3_P;            // f_in (+ ones column)           -> later o
+    float* msk = T3 + 64 * F3_P;           // [64] row mask of the group's tile
+    const int rps = (d.M + gridDim.x - 1) / gridDim.x;             // rows of this workgroup (any count)
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
-    // one burst of loads (weights, gamma, the first tile's streams below) before any of them is consumed
-    WFrag vw1, vw2;
-    fetch_w(vw1, d.w1, D, 0, D);
-    fetch_w(vw2, d.w2, D, 0, D);
+    // loads first (weights, gamma, the first tile's streams), LDS writes after
+    WFragT<NT> vw1, vw2;
+    fetch_w<NT>(vw1, d.w1, D, 0, D);
+    fetch_w<NT>(vw2, d.w2, D, 0, D);
     const float gam_v = d.ln2_g[threadIdx.x < D ? threadIdx.x : 0];
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
@@ -637,68 +659,69 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
     Stream4 sdy, shid, sfin;
     BK_TSG(gm, 0); BK_TSG(gm, 1);
     auto fetch = [&](int m0) {
-        const int mw = m0 + 16 * wave;
+        const int mw = m0 + 16 * w4;
         const int tot = max(0, min(16, me - mw)) * D;
         stream_fetch(sdy, bd.dy + (size_t)mw * D, tot);
         stream_fetch(shid, d.hid + (size_t)mw * D, tot);
         stream_fetch(sfin, d.f_in + (size_t)mw * D, tot);
     };
-    if (mb < me) fetch(mb);
+    if (mb < me) fetch(mb + 64 * grp);
     BK_TSG(gm, 2);
-    put_wt_packed(W1t, vw1, D, 4 * ks);
-    put_wt_packed(W2t, vw2, D, 4 * ks);
+    put_wt_packed<NT>(W1t, vw1, D, 4 * ks);
+    put_wt_packed<NT>(W2t, vw2, D, 4 * ks);
     if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? gam_v : 0.0f;
     BK_TSG(gm, 3);
-    for (int m0 = mb; m0 < me; m0 += 64) {
-        const int mw = m0 + 16 * wave;
+    for (int base = mb; base < me; base += 64 * NG) {
+        const int m0 = base + 64 * grp;
+        const int mw = m0 + 16 * w4;
         const int nr = max(0, min(16, me - mw)), tot = nr * D;
-        float* t1 = T1 + 16 * wave * F3_P; float* t2 = T2 + 16 * wave * F3_P;
-        float* t3 = T3 + 16 * wave * F3_P;
-        if (lane < 16) msk[16 * wave + lane] = (lane < nr && d.mask_ids[mw + lane] != 0) ? 1.0f : 0.0f;
+        float* t1 = T1 + 16 * w4 * F3_P; float* t2 = T2 + 16 * w4 * F3_P;
+        float* t3 = T3 + 16 * w4 * F3_P;
+        if (lane < 16) msk[16 * w4 + lane] = (lane < nr && d.mask_ids[mw + lane] != 0) ? 1.0f : 0.0f;
         zero_rows(t1); zero_rows(t2); zero_rows(t3);
-        if (m0 == mb) BK_TSG(gm, 4);
+        if (base == mb) BK_TSG(gm, 4);
         // g2 = dy * mask * keep2/(1-rate) (sasrec.py:83, modules.py:309-310)
         {
-            const float* mrow = msk + 16 * wave;
-            const uint32_t base = (d.drop_ffn2.row_offset + (uint32_t)mw) * (uint32_t)D;
+            const float* mrow = msk + 16 * w4;
+            const uint32_t hb = (d.drop_ffn2.row_offset + (uint32_t)mw) * (uint32_t)D;
             stream_put(t1, sdy, D, tot, gm.invD, [&](int e, int r, float v) {
                 float x = v * mrow[r];
-                if (d2.on) x *= (cr_fmix32((base + (uint32_t)e) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;
+                if (d2.on) x *= (cr_fmix32((hb + (uint32_t)e) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;
                 return x;
             });
         }
-        if (m0 == mb) BK_TSG(gm, 5);
+        if (base == mb) BK_TSG(gm, 5);
         stream_put(t2, shid, D, tot, gm.invD, PutPlain());
         stream_put(t3, sfin, D, tot, gm.invD, PutPlain());
         plant_ones(t2, ones, nr);
         plant_ones(t3, ones, nr);
-        if (m0 == mb) BK_TSG(gm, 6);
+        if (base == mb) BK_TSG(gm, 6);
         __syncthreads();
-        if (m0 + 64 < me) fetch(m0 + 64);                          // next tile's loads fly under this tile's MFMAs
+        if (base + 64 * NG < me) fetch(m0 + 64 * NG);              // next tile's loads fly under this tile's MFMAs
         // dW2 (+ db2 in row `ones`) += hid^T g2
-        tile_wgrad(aw2, T2, T1, F3_P, wave);
-        if (ones < 0 && threadIdx.x < 64) b2s += colsum64(T1);
+        tile_wgrad(aw2, T2, T1, F3_P, w4);
+        if (ones < 0 && gtid < 64) b2s += colsum64(T1, gtid);
         __syncthreads();
-        if (m0 == mb) BK_TSG(gm, 7);
+        if (base == mb) BK_TSG(gm, 7);
         // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (in place over hid, own rows)
         {
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma(acc, T1, F3_P, W2t, ks, wave);
+            tile_mma(acc, T1, F3_P, W2t, ks, w4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* ph = T2 + (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
+                    float* ph = T2 + (16 * w4 + 4 * lg + r) * F3_P + 16 * j + li;
                     const bool gate = (*ph > 0.0f) && (16 * j + li != ones);
                     *ph = gate ? acc[j][r] * scale1 : 0.0f;                                 // modules.py:300-304
                 }
         }
         __syncthreads();
-        if (m0 == mb) BK_TSG(gm, 8);
+        if (base == mb) BK_TSG(gm, 8);
         // dW1 (+ db1) += f_in^T g1
-        tile_wgrad(aw1, T3, T2, F3_P, wave);
-        if (ones < 0 && threadIdx.x < 64) b1s += colsum64(T2);
+        tile_wgrad(aw1, T3, T2, F3_P, w4);
+        if (ones < 0 && gtid < 64) b1s += colsum64(T2, gtid);
         // df = g1 W1^T + dy*mask  (residual of modules.py:313; g1 rows of masked positions are 0) -> T1 (own rows)
         {
             // residual dy * mask in the accumulator layout, re-read from L2 (this tile's dy was streamed a moment ago)
@@ -712,130 +735,241 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_bwd(cr_block_bwd_desc bd, 
                 }
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma(acc, T2, F3_P, W1t, ks, wave);
+            tile_mma(acc, T2, F3_P, W1t, ks, w4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + 4 * lg + r;
+                    const int row = 16 * w4 + 4 * lg + r;
                     const bool ok = (4 * lg + r < nr) && (16 * j + li < D);
                     T1[row * F3_P + 16 * j + li] = acc[j][r] + (ok ? res[j][r] * msk[row] : 0.0f);
                 }
         }
         __syncthreads();                                           // all waves are done with every row of T3
-        if (m0 == mb) BK_TSG(gm, 9);
+        if (base == mb) BK_TSG(gm, 9);
         // LN2 backward in place on own rows: x = o (streamed into T3), dy = df (T1) -> d_o (T1)
         zero_rows(t3);
         if (nr > 0) wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
-        ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, wave);
+        ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, w4);
         if (nr > 0) wave_store_rows(bd.d_o + (size_t)mw * D, t1, F3_P, D, nr, gm.invD);
         __syncthreads();
-        if (m0 == mb) BK_TSG(gm, 10);
+        if (base == mb) BK_TSG(gm, 10);
     }
     BK_TSG(gm, 15);
+    // fold the groups' weight-gradient strips through LDS (group 1's tile area is free now), fixed order
+    if (NG == 2) {
+        float* xch = sb + 256 * NG + (3 * 64 * F3_P + 64);         // group 1's tiles: 12736 floats >= 4 * 34 * 64
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xch[((w4 * 34 + 4 * j + r) * 64) + lane] = aw1[j][r];
+                    xch[((w4 * 34 + 16 + 4 * j + r) * 64) + lane] = aw2[j][r];
+                }
+            xch[(w4 * 34 + 32) * 64 + lane] = b1s;
+            xch[(w4 * 34 + 33) * 64 + lane] = b2s;
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    aw1[j][r] += xch[((w4 * 34 + 4 * j + r) * 64) + lane];
+                    aw2[j][r] += xch[((w4 * 34 + 16 + 4 * j + r) * 64) + lane];
+                }
+            b1s += xch[(w4 * 34 + 32) * 64 + lane];
+            b2s += xch[(w4 * 34 + 33) * 64 + lane];
+        }
+    }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    store_wgrad(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, ones, wave);
-    store_wgrad(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, ones, wave);
-    if (ones < 0 && threadIdx.x < D) { bd.g_b1[so + threadIdx.x] = b1s; bd.g_b2[so + threadIdx.x] = b2s; }
-    store_ln_grads(sg, sb, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
+    if (grp == 0) {
+        store_wgrad(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, ones, w4);
+        store_wgrad(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, ones, w4);
+        if (ones < 0 && threadIdx.x < D) { bd.g_b1[so + threadIdx.x] = b1s; bd.g_b2[so + threadIdx.x] = b2s; }
+    }
+    store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
 }
 
 // ---- B1: backward of LN1 + Q/K/V projections --------------------------------------------------------------
 // dqkv is [3, M, D] (dQ rows, dK rows, dV rows), like qkv.
-__global__ __launch_bounds__(256) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
+// NG groups of 4 waves per workgroup (see B3), three 64-row tiles per group, reused phase by phase:
+//   TG: dQ -> dK -> dV -> dq_in -> dx      TA: q_in -> x      TB: dK Wk^T + dV Wv^T
+// so that two groups and the three packed transposed weights fit the 160 KB of a CU (two waves per SIMD).
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
+    constexpr int NT = 256 * NG;
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = d.D, ks = gm.ks, ones = gm.ones;
-    float* TA = smem;                      // dQ                 -> later dq_in -> dx
-    float* TB = TA + 64 * F3_P;            // dK                 -> later dx part (dK Wk^T + dV Wv^T)
-    float* TC = TB + 64 * F3_P;            // dV
-    float* TQ = TC + 64 * F3_P;            // q_in (+ ones column)
-    float* TX = TQ + 64 * F3_P;            // x    (+ ones column)
-    float* Wqr = TX + 64 * F3_P;           // Wq, Wk, Wv as [k][66], read by rows
-    float* Wkr = Wqr + 64 * F3_P;
-    float* Wvr = Wkr + 64 * F3_P;
-    float* gam = Wvr + 64 * F3_P;          // [64] gamma1
-    float* sg = gam + 64;
-    float* sb = sg + 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int rps = rows_per_wg(d.M, gridDim.x);
+    const int grp = wave >> 2, w4 = wave & 3, gtid = threadIdx.x & 255;
+    float* Wqt = smem;                     // Wq^T, Wk^T, Wv^T packed [4*ks][64]
+    float* Wkt = Wqt + 4 * ks * BK_WROW;
+    float* Wvt = Wkt + 4 * ks * BK_WROW;
+    float* gam = Wvt + 4 * ks * BK_WROW;   // [64] gamma1
+    float* sg = gam + 64;                  // [4*NG][64] x 2
+    float* sb = sg + 256 * NG;
+    float* TG = sb + 256 * NG + grp * (3 * 64 * F3_P);
+    float* TA = TG + 64 * F3_P;
+    float* TB = TA + 64 * F3_P;
+    const int rps = (d.M + gridDim.x - 1) / gridDim.x;
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
-    load_w(Wqr, F3_P, d.wqkv, 3 * D, 0, D);
-    load_w(Wkr, F3_P, d.wqkv, 3 * D, D, D);
-    load_w(Wvr, F3_P, d.wqkv, 3 * D, 2 * D, D);
-    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? d.ln1_g[threadIdx.x] : 0.0f;
+    const size_t MD = (size_t)d.M * D;
+    WFragT<NT> vq, vk, vv;
+    fetch_w<NT>(vq, d.wqkv, 3 * D, 0, D);
+    fetch_w<NT>(vk, d.wqkv, 3 * D, D, D);
+    fetch_w<NT>(vv, d.wqkv, 3 * D, 2 * D, D);
+    const float gam_v = d.ln1_g[threadIdx.x < D ? threadIdx.x : 0];
     f32x4 awq[4], awk[4], awv[4];
     zero_acc(awq); zero_acc(awk); zero_acc(awv);
     float bqs = 0.0f, bks = 0.0f, bvs = 0.0f;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-    const size_t MD = (size_t)d.M * D;
-    for (int m0 = mb; m0 < me; m0 += 64) {
-        const int mw = m0 + 16 * wave;
+    Stream4 s0, s1, s2, s3;                 // dQ, q_in, dK, x  (then s0, s1 again: dV, d_o)
+    auto fetch4 = [&](int m0) {
+        const int mw = m0 + 16 * w4;
+        const int tot = max(0, min(16, me - mw)) * D;
+        stream_fetch(s0, bd.dqkv + (size_t)mw * D, tot);
+        stream_fetch(s1, d.q_in + (size_t)mw * D, tot);
+        stream_fetch(s2, bd.dqkv + MD + (size_t)mw * D, tot);
+        stream_fetch(s3, d.x + (size_t)mw * D, tot);
+    };
+    if (mb < me) fetch4(mb + 64 * grp);
+    put_wt_packed<NT>(Wqt, vq, D, 4 * ks);
+    put_wt_packed<NT>(Wkt, vk, D, 4 * ks);
+    put_wt_packed<NT>(Wvt, vv, D, 4 * ks);
+    if (threadIdx.x < 64) gam[threadIdx.x] = (threadIdx.x < D) ? gam_v : 0.0f;
+    for (int base = mb; base < me; base += 64 * NG) {
+        const int m0 = base + 64 * grp;
+        const int mw = m0 + 16 * w4;
         const int nr = max(0, min(16, me - mw)), tot = nr * D;
-        float* ta = TA + 16 * wave * F3_P; float* tb = TB + 16 * wave * F3_P; float* tc = TC + 16 * wave * F3_P;
-        float* tq = TQ + 16 * wave * F3_P; float* tx = TX + 16 * wave * F3_P;
-        {   // one burst of five contiguous streams per wave, then one barrier
-            Stream4 s0, s1, s2, s3, s4;
-            stream_fetch(s0, bd.dqkv + (size_t)mw * D, tot);
-            stream_fetch(s1, bd.dqkv + MD + (size_t)mw * D, tot);
-            stream_fetch(s2, bd.dqkv + 2 * MD + (size_t)mw * D, tot);
-            stream_fetch(s3, d.q_in + (size_t)mw * D, tot);
-            stream_fetch(s4, d.x + (size_t)mw * D, tot);
-            zero_rows(ta); zero_rows(tb); zero_rows(tc); zero_rows(tq); zero_rows(tx);
-            stream_put(ta, s0, D, tot, gm.invD, PutPlain());
-            stream_put(tb, s1, D, tot, gm.invD, PutPlain());
-            stream_put(tc, s2, D, tot, gm.invD, PutPlain());
-            stream_put(tq, s3, D, tot, gm.invD, PutPlain());
-            stream_put(tx, s4, D, tot, gm.invD, PutPlain());
-            plant_ones(tq, ones, nr);
-            plant_ones(tx, ones, nr);
-        }
+        float* tg = TG + 16 * w4 * F3_P; float* ta = TA + 16 * w4 * F3_P; float* tb = TB + 16 * w4 * F3_P;
+        if (base != mb) fetch4(m0);
+        // ---- phase 1: dQ, q_in -> dWq (+ dbq), dq_in = dQ Wq^T
+        zero_rows(tg); zero_rows(ta);
+        stream_put(tg, s0, D, tot, gm.invD, PutPlain());
+        stream_put(ta, s1, D, tot, gm.invD, PutPlain());
+        plant_ones(ta, ones, nr);
+        stream_fetch(s0, bd.dqkv + 2 * MD + (size_t)mw * D, tot);      // dV and the residual gradient d_o, for later phases
+        stream_fetch(s1, bd.d_o + (size_t)mw * D, tot);
         __syncthreads();
-        // weight (+ bias) gradients: reductions over all 64 rows of the tiles
-        tile_wgrad(awq, TQ, TA, F3_P, wave);
-        tile_wgrad(awk, TX, TB, F3_P, wave);
-        tile_wgrad(awv, TX, TC, F3_P, wave);
-        if (ones < 0 && threadIdx.x < 64) { bqs += colsum64(TA); bks += colsum64(TB); bvs += colsum64(TC); }
-        // data gradients on own rows: dx_part = dK Wk^T + dV Wv^T ; dq_in = dQ Wq^T + d_o (modules.py:269)
-        f32x4 dxa[4], acc[4];
-        zero_acc(dxa); zero_acc(acc);
-        tile_mma_t(dxa, TB, Wkr, F3_P, ks, wave);
-        tile_mma_t(dxa, TC, Wvr, F3_P, ks, wave);
-        tile_mma_t(acc, TA, Wqr, F3_P, ks, wave);
-        __syncthreads();                                           // every wave is done reading all rows of TA / TB / TC
-        zero_rows(tc);
-        if (nr > 0) wave_load_rows(tc, bd.d_o + (size_t)mw * D, F3_P, D, nr, gm.invD);      // residual branch
+        tile_wgrad(awq, TA, TG, F3_P, w4);
+        if (ones < 0 && gtid < 64) bqs += colsum64(TG, gtid);
+        f32x4 acc[4], dxa[4];
+        zero_acc(acc); zero_acc(dxa);
+        tile_mma(acc, TG, F3_P, Wqt, ks, w4);
+        __syncthreads();                                           // all rows of TG (dQ) and TA (q_in) have been read
+        // ---- phase 2: dK, x -> dWk (+ dbk), dx_part = dK Wk^T
+        zero_rows(tg); zero_rows(ta);
+        stream_put(tg, s2, D, tot, gm.invD, PutPlain());
+        stream_put(ta, s3, D, tot, gm.invD, PutPlain());
+        plant_ones(ta, ones, nr);
+        __syncthreads();
+        tile_wgrad(awk, TA, TG, F3_P, w4);
+        if (ones < 0 && gtid < 64) bks += colsum64(TG, gtid);
+        tile_mma(dxa, TG, F3_P, Wkt, ks, w4);
+        __syncthreads();                                           // all rows of TG (dK) have been read
+        // ---- phase 3: dV -> dWv (+ dbv), dx_part += dV Wv^T
+        zero_rows(tg);
+        stream_put(tg, s0, D, tot, gm.invD, PutPlain());
+        __syncthreads();
+        tile_wgrad(awv, TA, TG, F3_P, w4);
+        if (ones < 0 && gtid < 64) bvs += colsum64(TG, gtid);
+        tile_mma(dxa, TG, F3_P, Wvt, ks, w4);
+        __syncthreads();                                           // all rows of TG (dV) and TA (x) have been read
+        // ---- phase 4 (own rows): dq_in = dQ Wq^T + d_o (modules.py:269); dx = dx_part + LN1bwd(dq_in; x)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (16 * wave + 4 * lg + r) * F3_P + 16 * j + li;
-                TA[o] = acc[j][r] + TC[o];
+                const int o = (16 * w4 + 4 * lg + r) * F3_P + 16 * j + li;
+                TG[o] = acc[j][r];
                 TB[o] = dxa[j][r];
             }
-        if (ones >= 0 && lane < 16) tx[lane * F3_P + ones] = 0.0f;     // remove the ones column before LN reads x
-        // LN1 backward in place on own rows: dx = dx_part + LNbwd(dq_in; x)  -> TA
-        ln_bwd_rows(TX, TA, TB, gam, ag, ab, D, wave);
+        {
+            const int lane_ = lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                            // tg += d_o (row stream)
+                const int e0 = 4 * (lane_ + 64 * i);
+                if (e0 < tot) {
+                    int r = (int)__umulhi((uint32_t)e0, gm.invD), c = e0 - r * D;
+                    const float* pv = reinterpret_cast<const float*>(&s1.v[i]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (e0 + u < tot) tg[r * F3_P + c] += pv[u];
+                        if (++c == D) { c = 0; ++r; }
+                    }
+                }
+            }
+        }
+        if (ones >= 0 && lane < 16) ta[lane * F3_P + ones] = 0.0f;     // remove the ones column before LN reads x
+        ln_bwd_rows(TA, TG, TB, gam, ag, ab, D, w4);
         if (nr > 0) {
             float* gdx = bd.dx + (size_t)mw * D;
             if (bd.dx_accumulate) {
                 wave_load_rows(tb, gdx, F3_P, D, nr, gm.invD);
-                for (int e = lane; e < 16 * F3_P; e += 64) ta[e] += tb[e];
+                for (int e = lane; e < 16 * F3_P; e += 64) tg[e] += tb[e];
             }
-            wave_store_rows(gdx, ta, F3_P, D, nr, gm.invD);
+            wave_store_rows(gdx, tg, F3_P, D, nr, gm.invD);
+        }
+    }
+    // fold the groups' weight-gradient strips through LDS (group 1's tile area), fixed order, two rounds
+    if (NG == 2) {
+        __syncthreads();
+        float* xch = sb + 256 * NG + (3 * 64 * F3_P);              // 12672 floats >= 4 * 35 * 64
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xch[((w4 * 35 + 4 * j + r) * 64) + lane] = awq[j][r];
+                    xch[((w4 * 35 + 16 + 4 * j + r) * 64) + lane] = awk[j][r];
+                }
+            xch[(w4 * 35 + 32) * 64 + lane] = bqs;
+            xch[(w4 * 35 + 33) * 64 + lane] = bks;
+            xch[(w4 * 35 + 34) * 64 + lane] = bvs;
         }
         __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    awq[j][r] += xch[((w4 * 35 + 4 * j + r) * 64) + lane];
+                    awk[j][r] += xch[((w4 * 35 + 16 + 4 * j + r) * 64) + lane];
+                }
+            bqs += xch[(w4 * 35 + 32) * 64 + lane];
+            bks += xch[(w4 * 35 + 33) * 64 + lane];
+            bvs += xch[(w4 * 35 + 34) * 64 + lane];
+        }
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[((w4 * 16 + 4 * j + r) * 64) + lane] = awv[j][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) awv[j][r] += xch[((w4 * 16 + 4 * j + r) * 64) + lane];
+        }
     }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    store_wgrad(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, ones, wave);
-    store_wgrad(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, ones, wave);
-    store_wgrad(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, ones, wave);
-    if (ones < 0 && threadIdx.x < D) {
-        bd.g_bqkv[so + threadIdx.x] = bqs;
-        bd.g_bqkv[so + D + threadIdx.x] = bks;
-        bd.g_bqkv[so + 2 * D + threadIdx.x] = bvs;
+    if (grp == 0) {
+        store_wgrad(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, ones, w4);
+        store_wgrad(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, ones, w4);
+        store_wgrad(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, ones, w4);
+        if (ones < 0 && threadIdx.x < D) {
+            bd.g_bqkv[so + threadIdx.x] = bqs;
+            bd.g_bqkv[so + D + threadIdx.x] = bks;
+            bd.g_bqkv[so + 2 * D + threadIdx.x] = bvs;
+        }
     }
-    store_ln_grads(sg, sb, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
+    store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -899,11 +1033,20 @@ extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {
     const cr_block_desc* d = &bd->f;
     CR_REQUIRE(bd->dy && bd->d_o && d->hid && d->f_in && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_block_ln_ffn_bwd: NULL pointer");
     CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b && bd->n_slabs > 0, "cr_block_ln_ffn_bwd: NULL gradient pointer");
-    static bool attr = false;
-    rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd), &attr);
-    if (rc) return rc;
-    const size_t lds = sizeof(float) * (3 * 64 * F3_P + 2 * 4 * g.ks * BK_WROW + 128 + 512);
-    hipLaunchKernelGGL(k_block_ln_ffn_bwd, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
+    // two 64-row tile groups per workgroup unless the workgroups have a single tile's worth of rows anyway
+    const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
+    const int ng = (rps > 64 && !(g.dbg & 1)) ? 2 : 1;
+    const size_t lds = sizeof(float) * (2 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P + 64));
+    static bool attr1 = false, attr2 = false;
+    if (ng == 2) {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<2>), &attr2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_ffn_bwd<2>, dim3(bd->n_slabs), dim3(512), lds, cr_stream(stream), *bd, g);
+    } else {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<1>), &attr1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_ffn_bwd<1>, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
+    }
     return cr_check_launch("cr_block_ln_ffn_bwd");
 }
 
@@ -915,10 +1058,18 @@ extern "C" int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* bd, void* stream) {
     const cr_block_desc* d = &bd->f;
     CR_REQUIRE(bd->dqkv && bd->d_o && bd->dx && d->q_in && d->x && d->wqkv && d->ln1_g, "cr_block_ln_qkv_bwd: NULL pointer");
     CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b && bd->n_slabs > 0, "cr_block_ln_qkv_bwd: NULL gradient pointer");
-    static bool attr = false;
-    rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd), &attr);
-    if (rc) return rc;
-    const size_t lds = sizeof(float) * (8 * 64 * F3_P + 64 + 512);
-    hipLaunchKernelGGL(k_block_ln_qkv_bwd, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
+    const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
+    const int ng = (rps > 64 && !(g.dbg & 2)) ? 2 : 1;
+    const size_t lds = sizeof(float) * (3 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P));
+    static bool attr1 = false, attr2 = false;
+    if (ng == 2) {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2>), &attr2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_qkv_bwd<2>, dim3(bd->n_slabs), dim3(512), lds, cr_stream(stream), *bd, g);
+    } else {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1>), &attr1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_qkv_bwd<1>, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
+    }
     return cr_check_launch("cr_block_ln_qkv_bwd");
 }

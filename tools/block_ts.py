@@ -32,14 +32,14 @@ fn = getattr(dll, "cr_debug_block_ts")
 fn.argtypes = [C.c_void_p]; fn.restype = None
 
 def timeline(entry, desc, nwg, names):
-    ts = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device="cuda")
+    ts = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device="cuda")
     for _ in range(3): L.call(entry, C.byref(desc), s)
     torch.cuda.synchronize()
     fn(ts.data_ptr())
     L.call(entry, C.byref(desc), s)
     torch.cuda.synchronize()
     fn(None)
-    t = ts.cpu().numpy().reshape(nwg, 4, 16).astype(np.float64)
+    t = ts.cpu().numpy().reshape(-1, 1, 16).astype(np.float64)
     live = t[:, :, 15] > 0
     w0 = t[:, :, 0][live].min()
     start = (t[:, :, 0][live] - w0) * 10.0          # ns (100 MHz)
