@@ -20,33 +20,45 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int nwaves = gridDim.y * nw;
-    int qi = wave * gridDim.y + blockIdx.y;             // interleaved: every workgroup gets heavy and light tiles
+    AT_TS(0); AT_TS(1);
+    TileSched sch = sched_init(nw, wave);
+    int qi = sched_rank(sch);                           // rank of the wave's first tile (0 = heaviest)
     float qn[NDS], don[NDS];                            // Q / dOut fragments of the wave's next tile (in flight during the staging)
     if (qi < g.nkt) {
         const int q0n = 16 * (g.nkt - 1 - qi);
         frag_issue<NDS>(d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, qn);
         frag_issue<NDS>(bd.dout, bd.lddo, base_row + q0n, hoff, T - q0n, d.d, don);
     }
-    stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
-    stage_rows(Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
-    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+    const int t0 = threadIdx.x;
+    const int t0c = (t0 < T) ? base_row + t0 : base_row;
+    const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
+    const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
+    stage_rows2(Ks, g.PA, d.K, d.ld, Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    if (t0 < g.T16) {
+        kv[t0] = (t0 < T) ? kv0 : 0.0f;
+        qv[t0] = (t0 < T) ? qv0 : 0.0f;
+        dead[t0] = (t0 >= T || id0 == 0) ? 1.0f : 0.0f;
+    }
+    for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {
         kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
         qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
         dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
     }
+    AT_TS(2);
     __syncthreads();
+    AT_TS(3);
+    const int qi_first = qi;
     const uint64_t kbits = key_bits<NKT>(kv, T);
     const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
-    for (; qi < g.nkt; qi += nwaves) {
+    for (; qi < g.nkt; qi = sched_next(sch)) {
         const int qt = g.nkt - 1 - qi;
         const int q0 = 16 * qt, q = q0 + li;
         float qf[NDS], dof[NDS];
         frag_finish<NDS>(qn, T - q0, d.d, qf);
         frag_finish<NDS>(don, T - q0, d.d, dof);
-        if (qi + nwaves < g.nkt) {                      // prefetch the next tile's fragments behind this tile's work
-            const int q0n = 16 * (g.nkt - 1 - (qi + nwaves));
+        if (sched_peek(sch) < g.nkt) {                  // prefetch the next tile's fragments behind this tile's work
+            const int q0n = 16 * (g.nkt - 1 - sched_peek(sch));
             frag_issue<NDS>(d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, qn);
             frag_issue<NDS>(bd.dout, bd.lddo, base_row + q0n, hoff, T - q0n, d.d, don);
         }
@@ -71,6 +83,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         float m2, inv;
         bool uniform;
         score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        if (qi == qi_first) AT_TS(4);
         const float qvq = qv[q];
         const bool live = !uniform && !is_dead && (q < T);
         const float wq = live ? qvq : 0.0f;
@@ -96,6 +109,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
             dps[kt] = acc;
         }
         delta = grp_sum(delta);
+        if (qi == qi_first) AT_TS(5);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -107,6 +121,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mma_prob_rows<NKT, NDT>(st, Ks, g.PA, kt_first, qt + 1, acc);
+        if (qi == qi_first) AT_TS(6);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
 #pragma unroll
@@ -122,7 +137,9 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
             else if (uniform) flag = 1.0f;
             sp[0] = m2; sp[1] = inv; sp[2] = delta; sp[3] = flag;
         }
+        if (qi == qi_first) AT_TS(7);
     }
+    AT_TS(15);
 }
 
 template <int NDS, int NDT>
@@ -143,16 +160,29 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int nwaves = gridDim.y * nw;
-    int kt = wave * gridDim.y + blockIdx.y;
+    AT_TS(0); AT_TS(1);
+    TileSched sch = sched_init(nw, wave);
+    int kt = sched_rank(sch);                           // key tile 0 meets every query tile: rank == kt
+    const int kt_first_ = kt;
     float kn[NDS], vn[NDS];                             // K / V fragments of the wave's next key tile (in flight during the staging)
     if (kt < g.nkt) {
         frag_issue<NDS>(d.K, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, kn);
         frag_issue<NDS>(d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, vn);
     }
-    stage_rows(Qs, g.PA, d.Q, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
-    stage_rows(Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16, wave, nw);
-    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+    // per-row statistics of pass 1: requested before the Q / dOut streams, written to LDS after them
+    typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+    const int t0 = threadIdx.x;
+    const f4s st0 = *reinterpret_cast<const f4s*>(bd.stats + ((size_t)blockIdx.x * T + (t0 < T ? t0 : 0)) * 4);
+    const float qv0 = d.q_valid[base_row + (t0 < T ? t0 : 0)];
+    stage_rows2(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16, wave, nw);
+    if (t0 < g.T16) {
+        smx[t0] = (t0 < T) ? st0.x : 0.0f;
+        sinv[t0] = (t0 < T) ? st0.y : 0.0f;
+        sdel[t0] = (t0 < T) ? st0.z : 0.0f;
+        sflag[t0] = (t0 < T) ? st0.w : 2.0f;
+        qv[t0] = (t0 < T) ? qv0 : 0.0f;
+    }
+    for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {
         const float* sp = bd.stats + ((size_t)blockIdx.x * T + (t < T ? t : 0)) * 4;
         smx[t] = (t < T) ? sp[0] : 0.0f;
         sinv[t] = (t < T) ? sp[1] : 0.0f;
@@ -160,7 +190,9 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
         sflag[t] = (t < T) ? sp[3] : 2.0f;
         qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
     }
+    AT_TS(2);
     __syncthreads();
+    AT_TS(3);
     for (int t = threadIdx.x; t < g.nkt; t += blockDim.x) {
         float u = 0.0f, lv = 0.0f;
         for (int i = 0; i < 16; ++i) {
@@ -171,14 +203,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
         tile_live[t] = lv;
     }
     __syncthreads();
+    AT_TS(4);
     const DropCtx dc = drop_ctx(d.drop);
-    for (; kt < g.nkt; kt += nwaves) {
+    for (; kt < g.nkt; kt = sched_next(sch)) {
         const int key = 16 * kt + li;
         float kf[NDS], vf[NDS];
         frag_finish<NDS>(kn, T - 16 * kt, d.d, kf);
         frag_finish<NDS>(vn, T - 16 * kt, d.d, vf);
-        if (kt + nwaves < g.nkt) {
-            const int ktn = kt + nwaves;
+        if (sched_peek(sch) < g.nkt) {
+            const int ktn = sched_peek(sch);
             frag_issue<NDS>(d.K, d.ld, base_row + 16 * ktn, hoff, T - 16 * ktn, d.d, kn);
             frag_issue<NDS>(d.V, d.ld, base_row + 16 * ktn, hoff, T - 16 * ktn, d.d, vn);
         }
@@ -231,6 +264,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
                     dk[jt] = mfma16(pd[r], bq[r][jt], dk[jt]);
                 }
         }
+        if (kt == kt_first_) AT_TS(5);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
 #pragma unroll
@@ -242,7 +276,9 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
                 }
             }
         }
+        if (kt == kt_first_) AT_TS(6);
     }
+    AT_TS(15);
 }
 
 static size_t lds_bwd_q(const AttnGeom& g, int w) {
@@ -260,8 +296,10 @@ static int launch_bwd_q(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves
         if (rc) return rc;
         attr_set = true;
     }
+    AttnGeom gg = g;
+    if (g_attn_ts_which != 1) gg.ts = nullptr;
     hipLaunchKernelGGL((k_attn_bwd_q<NKT, NDS, NDT>), dim3(bd->f.B * bd->f.H, attn_nsplit(&bd->f, g, waves)), dim3(64 * waves),
-                       lds_bwd_q(g, waves), s, *bd, g);
+                       lds_bwd_q(g, waves), s, *bd, gg);
     return cr_check_launch("cr_attn_bwd(q)");
 }
 
@@ -280,8 +318,10 @@ static int launch_bwd_kv(const cr_attn_bwd_desc* bd, const AttnGeom& g, int wave
         if (rc) return rc;
         attr_set = true;
     }
+    AttnGeom gg = g;
+    if (g_attn_ts_which != 2) gg.ts = nullptr;
     hipLaunchKernelGGL((k_attn_bwd_kv<NDS, NDT>), dim3(bd->f.B * bd->f.H, attn_nsplit(&bd->f, g, waves)), dim3(64 * waves),
-                       lds_bwd_kv(g, waves), s, *bd, g);
+                       lds_bwd_kv(g, waves), s, *bd, gg);
     return cr_check_launch("cr_attn_bwd(kv)");
 }
 

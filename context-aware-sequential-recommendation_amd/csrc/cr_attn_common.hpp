@@ -37,7 +37,17 @@ struct AttnGeom {
     float isd;               // 1/sqrt(d)   (modules.py:219)
     float isd_log2e;         // isd * log2(e): softmax exponent in base 2 (v_exp_f32)
     float invT;
+    unsigned long long* ts;  // debug: per-wave phase stamps [waves][16] (tools/attn_ts.py); NULL in production
 };
+// debug-only phase stamps: slots 0 / 15 = wall clock (100 MHz), others = s_memtime; first tile of a wave only
+#define AT_TS(slot)                                                                                          \
+    do {                                                                                                     \
+        if (g.ts && (threadIdx.x & 63) == 0)                                                                 \
+            g.ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = \
+                ((slot) == 0 || (slot) == 15) ? wall_clock64() : clock64();                                  \
+    } while (0)
+extern unsigned long long* g_attn_ts;
+extern int g_attn_ts_which;   // 0 = forward, 1 = backward (query-owner), 2 = backward (key-owner)
 
 __device__ __forceinline__ float grp_max(float v) {   // over the 4 lanes that share (lane & 15)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -83,6 +93,25 @@ __device__ __forceinline__ void load_frag(const float* tile, int pa, float (&fra
 #pragma unroll
     for (int s = 0; s < NDS; ++s) frag[s] = tile[li * pa + 4 * s + lg];
 }
+
+// Tile schedule.  Tiles are ranked by weight (rank 0 = heaviest: the causal triangle makes query tile qt cost
+// ~qt + 1 key tiles) and dealt in serpentine rounds over P = nsplit * nw/2 SIMD slots: waves w and w + nw/2 of
+// a workgroup share a SIMD, the first takes the even rounds, the second the odd ones (reversed), so every SIMD
+// gets a heavy and a light tile.  T = 200 (13 tiles, 2 x 8 waves): worst SIMD 13 units instead of 18.
+struct TileSched { int P, p, r, R; };
+__device__ __forceinline__ TileSched sched_init(int nw, int wave) {
+    TileSched s;
+    s.R = nw >= 2 ? 2 : 1;
+    const int half = nw / s.R;
+    s.P = (int)gridDim.y * half;
+    s.p = (wave % half) * (int)gridDim.y + (int)blockIdx.y;
+    s.r = wave / half;
+    return s;
+}
+__device__ __forceinline__ int sched_rank_at(const TileSched& s, int r) { return r * s.P + ((r & 1) ? s.P - 1 - s.p : s.p); }
+__device__ __forceinline__ int sched_rank(const TileSched& s) { return sched_rank_at(s, s.r); }
+__device__ __forceinline__ int sched_peek(const TileSched& s) { return sched_rank_at(s, s.r + s.R); }
+__device__ __forceinline__ int sched_next(TileSched& s) { s.r += s.R; return sched_rank(s); }
 
 // Register fragment straight from global memory, in two halves so the loads stay in flight behind other
 // work: frag_issue starts the NDS loads of element s = M[row0 + li][hoff + 4s + lg] (addresses clamped
@@ -175,6 +204,75 @@ __device__ __forceinline__ void stage_rows(float* dst, int P, const float* src, 
             }
         }
     }
+}
+
+// Two matrices of the same shape at once (K and V, or Q and dOut): when both take the flat float4 path all
+// their loads are issued before the first LDS write, so the staging costs one memory latency instead of one
+// per matrix and per round (per-wave timelines, tools/attn_ts.py: 5-6 us -> the dominant start-up cost).
+__device__ __forceinline__ void stage_rows2(float* dstA, int PA_, const float* srcA, int ldA, float* dstB, int PB_,
+                                            const float* srcB, int ldB, int row0, int hoff, int nrows_valid, int d,
+                                            int nrows, int tr, int nw) {
+    const float* baseA = srcA + (size_t)row0 * ldA + hoff;
+    const float* baseB = srcB + (size_t)row0 * ldB + hoff;
+    const bool flat = ldA == d && ldB == d && ((reinterpret_cast<uintptr_t>(baseA) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(baseB) & 15) == 0);
+    if (!flat) {
+        stage_rows(dstA, PA_, srcA, ldA, row0, hoff, nrows_valid, d, nrows, tr, nw);
+        stage_rows(dstB, PB_, srcB, ldB, row0, hoff, nrows_valid, d, nrows, tr, nw);
+        return;
+    }
+    const int tc = threadIdx.x & 63, tid = tr * 64 + tc, nth = nw * 64;
+    const int nv = nrows_valid < 0 ? 0 : (nrows_valid < nrows ? nrows_valid : nrows);
+    const int total = nv * d, n4 = total >> 2;
+    const float inv_d = 1.0f / (float)d;
+    const float4* a4 = reinterpret_cast<const float4*>(baseA);
+    const float4* b4 = reinterpret_cast<const float4*>(baseB);
+    constexpr int U4 = 8;
+    for (int i0 = tid; i0 < n4; i0 += nth * U4) {
+        float4 va[U4], vb[U4];
+#pragma unroll
+        for (int u = 0; u < U4; ++u) {
+            const int i = i0 + u * nth;
+            va[u] = a4[i < n4 ? i : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U4; ++u) {
+            const int i = i0 + u * nth;
+            vb[u] = b4[i < n4 ? i : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U4; ++u) {
+            const int i = i0 + u * nth;
+            if (i < n4) {
+                const int idx = 4 * i;
+                int r = (int)(((float)idx + 0.5f) * inv_d);
+                int c = idx - r * d;
+                const float ea[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+                const float eb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dstA[r * PA_ + c] = ea[k];
+                    dstB[r * PB_ + c] = eb[k];
+                    if (++c == d) { c = 0; ++r; }
+                }
+            }
+        }
+    }
+    for (int i = 4 * n4 + tid; i < total; i += nth) {                // at most 3 elements
+        const int r = i / d;
+        dstA[r * PA_ + (i - r * d)] = baseA[i];
+        dstB[r * PB_ + (i - r * d)] = baseB[i];
+    }
+    for (int i = tid; i < nv * (PA_ - d); i += nth) {
+        const int r = i / (PA_ - d);
+        dstA[r * PA_ + d + (i - r * (PA_ - d))] = 0.0f;
+    }
+    for (int i = tid; i < nv * (PB_ - d); i += nth) {
+        const int r = i / (PB_ - d);
+        dstB[r * PB_ + d + (i - r * (PB_ - d))] = 0.0f;
+    }
+    for (int i = nv * PA_ + tid; i < nrows * PA_; i += nth) dstA[i] = 0.0f;
+    for (int i = nv * PB_ + tid; i < nrows * PB_; i += nth) dstB[i] = 0.0f;
 }
 
 // per-lane key-validity bits: bit (4*kt + r) <=> key 16*kt + 4*lg + r is a valid key (< T, k_valid != 0)
@@ -323,6 +421,7 @@ static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
     g->isd = (float)(1.0 / sqrt((double)d->d));
     g->isd_log2e = (float)(1.4426950408889634 / sqrt((double)d->d));
     g->invT = 1.0f / (float)d->T;
+    g->ts = g_attn_ts;
     return CR_OK;
 }
 

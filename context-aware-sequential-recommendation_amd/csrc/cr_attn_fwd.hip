@@ -1,6 +1,10 @@
 // Attention forward (modules.py:208-269); see cr_attn_common.hpp for the design.
 #include "cr_attn_common.hpp"
 
+unsigned long long* g_attn_ts = nullptr;
+int g_attn_ts_which = 0;
+extern "C" void cr_debug_attn_ts(void* p, int which) { g_attn_ts = static_cast<unsigned long long*>(p); g_attn_ts_which = which; }
+
 template <int NKT, int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, AttnGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -14,28 +18,41 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int nwaves = gridDim.y * nw;
-    int qi = wave * gridDim.y + blockIdx.y;             // interleaved: every workgroup gets heavy and light tiles
+    AT_TS(0); AT_TS(1);
+    TileSched sch = sched_init(nw, wave);
+    int qi = sched_rank(sch);                           // rank of the wave's first tile (0 = heaviest)
     float qn[NDS];                                      // Q fragment of the wave's next tile, in flight during the staging
     if (qi < g.nkt) frag_issue<NDS>(d.Q, d.ld, base_row + 16 * (g.nkt - 1 - qi), hoff, T - 16 * (g.nkt - 1 - qi), d.d, qn);
-    stage_rows(Ks, g.PA, d.K, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
-    stage_rows(Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
-    for (int t = threadIdx.x; t < g.T16; t += blockDim.x) {
+    // per-row flags: requested before the K/V streams, written to LDS after them (one latency for everything)
+    const int t0 = threadIdx.x;
+    const int t0c = (t0 < T) ? base_row + t0 : base_row;
+    const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
+    const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
+    stage_rows2(Ks, g.PA, d.K, d.ld, Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    if (t0 < g.T16) {
+        kv[t0] = (t0 < T) ? kv0 : 0.0f;
+        qv[t0] = (t0 < T) ? qv0 : 0.0f;
+        dead[t0] = (t0 >= T || id0 == 0) ? 1.0f : 0.0f;
+    }
+    for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {     // fewer threads than rows (small workgroups)
         kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
         qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
         dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
     }
+    AT_TS(2);
     __syncthreads();
+    AT_TS(3);
     const uint64_t kbits = key_bits<NKT>(kv, T);
     const int kt_first = first_valid_tile<NKT>(kbits);
     const DropCtx dc = drop_ctx(d.drop);
-    for (; qi < g.nkt; qi += nwaves) {
+    const int qi_first = qi;
+    for (; qi < g.nkt; qi = sched_next(sch)) {
         const int qt = g.nkt - 1 - qi;                  // heaviest tiles first
         const int q0 = 16 * qt, q = q0 + li;
         float qf[NDS];
         frag_finish<NDS>(qn, T - q0, d.d, qf);
-        if (qi + nwaves < g.nkt) {                      // prefetch the next tile's fragment behind this tile's work
-            const int qtn = g.nkt - 1 - (qi + nwaves);
+        if (sched_peek(sch) < g.nkt) {                  // prefetch the next tile's fragment behind this tile's work
+            const int qtn = g.nkt - 1 - sched_peek(sch);
             frag_issue<NDS>(d.Q, d.ld, base_row + 16 * qtn, hoff, T - 16 * qtn, d.d, qn);
         }
         const bool is_dead = dead[q] != 0.0f;
@@ -54,6 +71,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         float m2, inv;
         bool uniform;
         score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        if (qi == qi_first) AT_TS(4);
         const float qvq = qv[q];
         const bool any_uni = __any(uniform ? 1 : 0) != 0;
         const uint32_t ridx = attn_row_idx(d, head, n, q);
@@ -78,10 +96,22 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
                 }
             }
         }
+        if (qi == qi_first) AT_TS(5);
+        // residual (modules.py:265-269) requested ahead of the P V MFMAs that hide its latency
+        float resid[NDT][4];
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + 4 * lg + r, c = 16 * jt + li;
+                const bool ok = qq < T && c < d.d;
+                resid[jt][r] = d.residual[ok ? (size_t)(base_row + qq) * d.ldr + hoff + c : (size_t)base_row * d.ldr + hoff];
+            }
         f32x4 acc[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mma_prob_rows<NKT, NDT>(st, Vs, g.PB, any_uni ? 0 : kt_first, any_uni ? g.nkt : qt + 1, acc);   // modules.py:262
+        if (qi == qi_first) AT_TS(6);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
 #pragma unroll
@@ -89,11 +119,13 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
                 const int qq = q0 + 4 * lg + r, c = 16 * jt + li;
                 if (qq < T && c < d.d) {
                     const size_t row = (size_t)(base_row + qq);
-                    d.out[row * d.ldo + hoff + c] = acc[jt][r] + d.residual[row * d.ldr + hoff + c];   // modules.py:265-269
+                    d.out[row * d.ldo + hoff + c] = acc[jt][r] + resid[jt][r];   // modules.py:265-269
                 }
             }
         }
+        if (qi == qi_first) AT_TS(7);
     }
+    AT_TS(15);
 }
 
 static size_t lds_fwd(const AttnGeom& g, int w) {
@@ -108,8 +140,10 @@ static int launch_fwd(const cr_attn_desc* d, const AttnGeom& g, int waves, hipSt
         if (rc) return rc;
         attr_set = true;
     }
+    AttnGeom gg = g;
+    if (g_attn_ts_which != 0) gg.ts = nullptr;
     hipLaunchKernelGGL((k_attn_fwd<NKT, NDS, NDT>), dim3(d->B * d->H, attn_nsplit(d, g, waves)), dim3(64 * waves),
-                       lds_fwd(g, waves), s, *d, g);
+                       lds_fwd(g, waves), s, *d, gg);
     return cr_check_launch("cr_attn_fwd");
 }
 
