@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     AT_TS(0); AT_TS(1);
+    const DropCtx dc = drop_ctx(d.drop);                // reads the step counter: requested first, needed late
     TileSched sch = sched_init(nw, wave);
     int qi = sched_rank(sch);                           // rank of the wave's first tile (0 = heaviest)
     float qn[NDS], don[NDS];                            // Q / dOut fragments of the wave's next tile (in flight during the staging)
@@ -33,14 +34,14 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const int t0c = (t0 < T) ? base_row + t0 : base_row;
     const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
     const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
-    stage_rows2(Ks, g.PA, d.K, d.ld, Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_pair<NDS>(Ks, g.PA, d.K, d.ld, Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
     if (t0 < g.T16) {
-        kv[t0] = (t0 < T) ? kv0 : 0.0f;
+        kv[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;      // additive key bias
         qv[t0] = (t0 < T) ? qv0 : 0.0f;
         dead[t0] = (t0 >= T || id0 == 0) ? 1.0f : 0.0f;
     }
     for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {
-        kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
+        kv[t] = (t < T && d.k_valid[base_row + t] != 0.0f) ? 0.0f : -INFINITY;
         qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
         dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
     }
@@ -48,9 +49,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     __syncthreads();
     AT_TS(3);
     const int qi_first = qi;
-    const uint64_t kbits = key_bits<NKT>(kv, T);
-    const int kt_first = first_valid_tile<NKT>(kbits);
-    const DropCtx dc = drop_ctx(d.drop);
+    const int kt_first = first_valid_tile<NKT>(kv, g.nkt);
     for (; qi < g.nkt; qi = sched_next(sch)) {
         const int qt = g.nkt - 1 - qi;
         const int q0 = 16 * qt, q = q0 + li;
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         f32x4 st[NKT];
         float m2, inv;
         bool uniform;
-        score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        score_rows<NKT, NDS>(g, Ks, qf, kv, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
         if (qi == qi_first) AT_TS(4);
         const float qvq = qv[q];
         const bool live = !uniform && !is_dead && (q < T);
@@ -91,22 +90,35 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         // dP^T[key][q] = V dO^T, then softmax backward (delta = sum_k dPsm * Psm)
         f32x4 dps[NKT];
         float delta = 0.0f;
+        auto dp_finish = [&](int kt, f32x4 acc) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kt >= kt_first && kt <= qt) {                // below kt_first every probability is 0 (uniform rows have dS = 0)
-                acc = mma_tile_frag<NDS>(Vs + 16 * kt * g.PA, g.PA, dof);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float psm = st[kt][r];
-                    float w = wq;                                             // query mask (* dropout keep / (1-rate))
-                    if (dc.on) w *= drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
-                    const float dpsm = acc[r] * w;
-                    delta += dpsm * psm;
-                    acc[r] = dpsm;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float psm = st[kt][r];
+                float w = wq;                                                 // query mask (* dropout keep / (1-rate))
+                if (dc.on) w *= drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
+                const float dpsm = acc[r] * w;
+                delta += dpsm * psm;
+                acc[r] = dpsm;
             }
-            dps[kt] = acc;
+            return acc;
+        };
+        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt += 2) {                                 // two interleaved MFMA chains at a time
+            const bool c0 = kt >= kt_first && kt <= qt;                       // below kt_first every probability is 0 (uniform rows have dS = 0)
+            const bool c1 = (kt + 1 < NKT) && kt + 1 >= kt_first && kt + 1 <= qt;
+            f32x4 acc0 = zero4, acc1 = zero4;
+            if (c0 && c1) {
+                mma_tile_frag2<NDS>(Vs + 16 * kt * g.PA, Vs + 16 * (kt + 1) * g.PA, g.PA, dof, dof, acc0, acc1);
+                acc0 = dp_finish(kt, acc0);
+                acc1 = dp_finish(kt + 1, acc1);
+            } else if (c0) {
+                acc0 = dp_finish(kt, mma_tile_frag<NDS>(Vs + 16 * kt * g.PA, g.PA, dof));
+            } else if (c1) {
+                acc1 = dp_finish(kt + 1, mma_tile_frag<NDS>(Vs + 16 * (kt + 1) * g.PA, g.PA, dof));
+            }
+            dps[kt] = acc0;
+            if (kt + 1 < NKT) dps[kt + 1] = acc1;
         }
         delta = grp_sum(delta);
         if (qi == qi_first) AT_TS(5);
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     AT_TS(0); AT_TS(1);
+    const DropCtx dc = drop_ctx(d.drop);                // reads the step counter: requested first, needed late
     TileSched sch = sched_init(nw, wave);
     int kt = sched_rank(sch);                           // key tile 0 meets every query tile: rank == kt
     const int kt_first_ = kt;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int t0 = threadIdx.x;
     const f4s st0 = *reinterpret_cast<const f4s*>(bd.stats + ((size_t)blockIdx.x * T + (t0 < T ? t0 : 0)) * 4);
     const float qv0 = d.q_valid[base_row + (t0 < T ? t0 : 0)];
-    stage_rows2(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_pair<NDS>(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
     if (t0 < g.T16) {
         smx[t0] = (t0 < T) ? st0.x : 0.0f;
         sinv[t0] = (t0 < T) ? st0.y : 0.0f;
@@ -204,7 +217,6 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     }
     __syncthreads();
     AT_TS(4);
-    const DropCtx dc = drop_ctx(d.drop);
     for (; kt < g.nkt; kt = sched_next(sch)) {
         const int key = 16 * kt + li;
         float kf[NDS], vf[NDS];
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
         for (int qt = 0; qt < g.nkt; ++qt) {
             if (tile_live[qt] == 0.0f) continue;                          // nothing flows through dead query tiles
             if ((qt < kt || !tile_has_key) && tile_uni[qt] == 0.0f) continue;   // causal / padding skip (uniform rows see all keys)
-            const f32x4 s_acc = mma_tile_frag<NDS>(Qs + 16 * qt * g.PA, g.PA, kf);   // S[q][key]
-            const f32x4 p_acc = mma_tile_frag<NDS>(Os + 16 * qt * g.PA, g.PA, vf);   // dP[q][key]
+            f32x4 s_acc, p_acc;                                                      // S[q][key], dP[q][key]: two interleaved chains
+            mma_tile_frag2<NDS>(Qs + 16 * qt * g.PA, Os + 16 * qt * g.PA, g.PA, kf, vf, s_acc, p_acc);
             float pa[4], pd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

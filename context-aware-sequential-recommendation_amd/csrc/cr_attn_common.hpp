@@ -27,6 +27,7 @@
 
 #include "cr_common.hpp"
 
+#define AT_FINE 1
 #define A_MAX_WAVES 8        // two waves per SIMD hide each other's LDS / MFMA latencies
 #define A_TAIL 64            // floats of slack after a B-pattern-read LDS array (reads of padded columns)
 
@@ -83,7 +84,32 @@ __device__ __forceinline__ f32x4 mma_tile_frag(const float* a_tile, int pa, cons
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NDS; ++s) acc = mfma16(a[s], frag[s], acc);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);      // keep the operand reads one batch ahead of the chain
+    __builtin_amdgcn_sched_group_barrier(0x008, NDS, 0);
     return acc;
+}
+
+// Two independent products of that kind with their MFMA chains interleaved: a dependent accumulate chain of
+// v_mfma_f32_16x16x4_f32 issues every 40 cycles, two alternating chains every 32 (the pipe rate), and the
+// 2 * NDS LDS operand reads go out as one batch.
+template <int NDS>
+__device__ __forceinline__ void mma_tile_frag2(const float* a_tile0, const float* a_tile1, int pa, const float (&frag0)[NDS],
+                                               const float (&frag1)[NDS], f32x4& acc0, f32x4& acc1) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const float* ap0 = a_tile0 + li * pa + lg;
+    const float* ap1 = a_tile1 + li * pa + lg;
+    float a0[NDS], a1[NDS];
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) { a0[s] = ap0[4 * s]; a1[s] = ap1[4 * s]; }
+    acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) {
+        acc0 = mfma16(a0[s], frag0[s], acc0);
+        acc1 = mfma16(a1[s], frag1[s], acc1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NDS, 0);  // all operand reads first, then the two interleaved chains
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NDS, 0);
 }
 
 // register fragment of a 16-row LDS tile: element s = tile[li][4s + lg]
@@ -135,204 +161,130 @@ __device__ __forceinline__ void frag_finish(const float (&raw)[NDS], int nrows_v
     for (int s = 0; s < NDS; ++s) frag[s] = (rok && 4 * s + lg < d) ? raw[s] : 0.0f;
 }
 
-// stage rows [0,nrows_valid) x [hoff, hoff+d) of a [M, ld] matrix into LDS with pitch P <= 68; everything
-// outside (rows >= nrows_valid, columns >= d up to the pitch) is zero so padded k-steps contribute 0.
-// `nw` waves take part, `tr` is the calling wave's index among them.
-// Fast path (single head, ld == d, 16-byte aligned): the rows are one contiguous stream, read as float4
-// with 4 loads in flight per lane and scattered into the pitched rows.  Otherwise a wave copies one row
-// per pass (4*d-byte segments), 8 rows in flight.
-__device__ __forceinline__ void stage_rows(float* dst, int P, const float* src, int ld, int row0, int hoff,
-                                           int nrows_valid, int d, int nrows, int tr, int nw) {
-    const int tc = threadIdx.x & 63;
-    const float* base = src + (size_t)row0 * ld + hoff;
-    if (ld == d && ((reinterpret_cast<uintptr_t>(base) & 15) == 0)) {
-        const int tid = tr * 64 + tc, nth = nw * 64;
-        const int nv = nrows_valid < 0 ? 0 : (nrows_valid < nrows ? nrows_valid : nrows);
-        const int total = nv * d, n4 = total >> 2;
-        const float inv_d = 1.0f / (float)d;
-        const float4* b4 = reinterpret_cast<const float4*>(base);
-        constexpr int U4 = 4;
-        for (int i0 = tid; i0 < n4; i0 += nth * U4) {
-            float4 v[U4];
-#pragma unroll
-            for (int u = 0; u < U4; ++u) {
-                const int i = i0 + u * nth;
-                v[u] = b4[i < n4 ? i : n4 - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < U4; ++u) {
-                const int i = i0 + u * nth;
-                if (i < n4) {
-                    const int idx = 4 * i;
-                    int r = (int)(((float)idx + 0.5f) * inv_d);      // exact: idx < 2^16, |(idx+.5)/d - integer| >= 1/(2d)
-                    int c = idx - r * d;
-                    const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        dst[r * P + c] = e[k];
-                        if (++c == d) { c = 0; ++r; }
-                    }
-                }
-            }
-        }
-        for (int i = 4 * n4 + tid; i < total; i += nth) {                // at most 3 elements
-            const int r = i / d;
-            dst[r * P + (i - r * d)] = base[i];
-        }
-        const int npad = P - d;
-        for (int i = tid; i < nv * npad; i += nth) {
-            const int r = i / npad;
-            dst[r * P + d + (i - r * npad)] = 0.0f;
-        }
-        for (int i = nv * P + tid; i < nrows * P; i += nth) dst[i] = 0.0f;
-        return;
-    }
-    constexpr int U = 8;
-    for (int t0 = tr; t0 < nrows; t0 += nw * U) {
-        float v[U];
+// Row-chunk staging of a PAIR of [T, d] matrices (K and V, or Q and dOut) into pitched LDS tiles.  An item is
+// (row r, 4-column chunk q), NDS chunks per row; its 16 bytes are one dword-aligned global load (gfx950 needs
+// no more) and two 8-byte LDS writes, so the address arithmetic is a couple of multiply-adds per 4 elements --
+// the element-wise scatter of a flat stream cost ~40 VALU instructions per float4 and made the staging the
+// most expensive phase of every attention kernel (ISA census: 3200 VALU instructions per wave).
+// All loads of a batch (U per matrix) are issued before the first LDS write.  The chunk that crosses column d
+// is read shifted back to [d-4, d) and rotated, so nothing outside the matrices is touched (needs d >= 4).
+typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
+template <int NDS>
+__device__ __forceinline__ void stage_pair(float* dstA, int PA_, const float* srcA, int ldA, float* dstB, int PB_,
+                                           const float* srcB, int ldB, int row0, int hoff, int T, int d, int T16) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int total = T16 * NDS;
+    constexpr int U = 6;
+    for (int i0 = tid; i0 < total; i0 += nth * U) {
+        f4v va[U], vb[U];
+        int rr[U], qq[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + nw * u;
-            v[u] = (t < nrows_valid && tc < d) ? src[(size_t)(row0 + t) * ld + hoff + tc] : 0.0f;
+            const int item = min(i0 + u * nth, total - 1);
+            const int r = item / NDS, q = item - r * NDS;
+            rr[u] = r; qq[u] = q;
+            const int rc = r < T ? r : T - 1;
+            const int col0 = min(4 * q, d - 4);
+            va[u] = *reinterpret_cast<const f4v*>(srcA + (size_t)(row0 + rc) * ldA + hoff + col0);
+            vb[u] = *reinterpret_cast<const f4v*>(srcB + (size_t)(row0 + rc) * ldB + hoff + col0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + nw * u;
-            if (t < nrows) {
-                if (tc < P) dst[t * P + tc] = v[u];
-                if (tc + 64 < P) dst[t * P + tc + 64] = 0.0f;   // d <= 64: always padding
-            }
-        }
-    }
-}
-
-// Two matrices of the same shape at once (K and V, or Q and dOut): when both take the flat float4 path all
-// their loads are issued before the first LDS write, so the staging costs one memory latency instead of one
-// per matrix and per round (per-wave timelines, tools/attn_ts.py: 5-6 us -> the dominant start-up cost).
-__device__ __forceinline__ void stage_rows2(float* dstA, int PA_, const float* srcA, int ldA, float* dstB, int PB_,
-                                            const float* srcB, int ldB, int row0, int hoff, int nrows_valid, int d,
-                                            int nrows, int tr, int nw) {
-    const float* baseA = srcA + (size_t)row0 * ldA + hoff;
-    const float* baseB = srcB + (size_t)row0 * ldB + hoff;
-    const bool flat = ldA == d && ldB == d && ((reinterpret_cast<uintptr_t>(baseA) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(baseB) & 15) == 0);
-    if (!flat) {
-        stage_rows(dstA, PA_, srcA, ldA, row0, hoff, nrows_valid, d, nrows, tr, nw);
-        stage_rows(dstB, PB_, srcB, ldB, row0, hoff, nrows_valid, d, nrows, tr, nw);
-        return;
-    }
-    const int tc = threadIdx.x & 63, tid = tr * 64 + tc, nth = nw * 64;
-    const int nv = nrows_valid < 0 ? 0 : (nrows_valid < nrows ? nrows_valid : nrows);
-    const int total = nv * d, n4 = total >> 2;
-    const float inv_d = 1.0f / (float)d;
-    const float4* a4 = reinterpret_cast<const float4*>(baseA);
-    const float4* b4 = reinterpret_cast<const float4*>(baseB);
-    constexpr int U4 = 8;
-    for (int i0 = tid; i0 < n4; i0 += nth * U4) {
-        float4 va[U4], vb[U4];
+            if (i0 + u * nth < total) {
+                const int r = rr[u], q = qq[u];
+                const int shift = 4 * q - min(4 * q, d - 4);
+                const bool rok = r < T;
+                float ea[4], eb[4];
+                const float a0 = va[u].x, a1 = va[u].y, a2 = va[u].z, a3 = va[u].w;
+                const float b0 = vb[u].x, b1 = vb[u].y, b2 = vb[u].z, b3 = vb[u].w;
+                ea[0] = shift == 0 ? a0 : (shift == 1 ? a1 : (shift == 2 ? a2 : a3));
+                ea[1] = shift == 0 ? a1 : (shift == 1 ? a2 : (shift == 2 ? a3 : 0.0f));
+                ea[2] = shift == 0 ? a2 : (shift == 1 ? a3 : 0.0f);
+                ea[3] = shift == 0 ? a3 : 0.0f;
+                eb[0] = shift == 0 ? b0 : (shift == 1 ? b1 : (shift == 2 ? b2 : b3));
+                eb[1] = shift == 0 ? b1 : (shift == 1 ? b2 : (shift == 2 ? b3 : 0.0f));
+                eb[2] = shift == 0 ? b2 : (shift == 1 ? b3 : 0.0f);
+                eb[3] = shift == 0 ? b3 : 0.0f;
 #pragma unroll
-        for (int u = 0; u < U4; ++u) {
-            const int i = i0 + u * nth;
-            va[u] = a4[i < n4 ? i : n4 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U4; ++u) {
-            const int i = i0 + u * nth;
-            vb[u] = b4[i < n4 ? i : n4 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U4; ++u) {
-            const int i = i0 + u * nth;
-            if (i < n4) {
-                const int idx = 4 * i;
-                int r = (int)(((float)idx + 0.5f) * inv_d);
-                int c = idx - r * d;
-                const float ea[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
-                const float eb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    dstA[r * PA_ + c] = ea[k];
-                    dstB[r * PB_ + c] = eb[k];
-                    if (++c == d) { c = 0; ++r; }
+                for (int t = 0; t < 4; ++t) {
+                    const bool ok = rok && (4 * q + t < d);
+                    ea[t] = ok ? ea[t] : 0.0f;
+                    eb[t] = ok ? eb[t] : 0.0f;
                 }
+                float2* pa = reinterpret_cast<float2*>(dstA + r * PA_ + 4 * q);
+                float2* pb = reinterpret_cast<float2*>(dstB + r * PB_ + 4 * q);
+                pa[0] = make_float2(ea[0], ea[1]); pa[1] = make_float2(ea[2], ea[3]);
+                pb[0] = make_float2(eb[0], eb[1]); pb[1] = make_float2(eb[2], eb[3]);
             }
         }
     }
-    for (int i = 4 * n4 + tid; i < total; i += nth) {                // at most 3 elements
-        const int r = i / d;
-        dstA[r * PA_ + (i - r * d)] = baseA[i];
-        dstB[r * PB_ + (i - r * d)] = baseB[i];
-    }
-    for (int i = tid; i < nv * (PA_ - d); i += nth) {
-        const int r = i / (PA_ - d);
-        dstA[r * PA_ + d + (i - r * (PA_ - d))] = 0.0f;
-    }
-    for (int i = tid; i < nv * (PB_ - d); i += nth) {
-        const int r = i / (PB_ - d);
-        dstB[r * PB_ + d + (i - r * (PB_ - d))] = 0.0f;
-    }
-    for (int i = nv * PA_ + tid; i < nrows * PA_; i += nth) dstA[i] = 0.0f;
-    for (int i = nv * PB_ + tid; i < nrows * PB_; i += nth) dstB[i] = 0.0f;
 }
 
-// per-lane key-validity bits: bit (4*kt + r) <=> key 16*kt + 4*lg + r is a valid key (< T, k_valid != 0)
+// First 16-key tile that holds a valid key (wave-uniform); NKT if none.  Left-padded sequences make the first
+// tiles all-invalid: their probabilities are exactly 0, so their MFMAs are skipped.  `kb` is the additive key
+// bias in LDS (0 = valid).  Lane kt inspects tile kt with four 16-byte reads and the wave takes the lowest set
+// bit of the ballot.  (The first version built a 64-bit validity mask per lane with 52 guarded LDS reads; the
+// compiler serialised them -- read, wait, branch -- and the per-wave timeline showed 7 us between the staging
+// barrier and the first MFMA.)
 template <int NKT>
-__device__ __forceinline__ uint64_t key_bits(const float* kv, int T) {
-    const int lg = (threadIdx.x & 63) >> 4;
-    uint64_t bits = 0;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * lg + r;
-            if (key < T && kv[key] != 0.0f) bits |= (1ull << (4 * kt + r));
-        }
-    }
-    return bits;
-}
-
-// first 16-key tile that holds a valid key (wave-uniform); NKT if none.  Left-padded sequences make the
-// first tiles all-invalid: their probabilities are exactly 0, so their MFMAs are skipped.
-template <int NKT>
-__device__ __forceinline__ int first_valid_tile(uint64_t kbits) {
-    // a tile's 16 keys are spread over the 4 lane groups: OR the per-lane bits across lg with two shuffles
-    uint32_t lo = (uint32_t)kbits, hi = (uint32_t)(kbits >> 32);
-    lo |= __shfl_xor(lo, 16, 64); lo |= __shfl_xor(lo, 32, 64);
-    hi |= __shfl_xor(hi, 16, 64); hi |= __shfl_xor(hi, 32, 64);
-    const uint64_t all = ((uint64_t)hi << 32) | lo;
-    int t = NKT;
-#pragma unroll
-    for (int kt = NKT - 1; kt >= 0; --kt)
-        if ((all >> (4 * kt)) & 0xFull) t = kt;
-    return __builtin_amdgcn_readfirstlane(t);
+__device__ __forceinline__ int first_valid_tile(const float* kb, int nkt) {
+    const int lane = threadIdx.x & 63;
+    const int kt = lane < nkt ? lane : nkt - 1;
+    const float4* p = reinterpret_cast<const float4*>(kb + 16 * kt);
+    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    const float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+    const float n = fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(e.x, e.y), fmaxf(e.z, e.w)));
+    const bool has = (fmaxf(m, n) == 0.0f) && lane < nkt;                        // max over {0, -inf} biases
+    const unsigned long long mask = __ballot(has ? 1 : 0);
+    return mask ? (int)__builtin_ctzll(mask) : NKT;
 }
 
 // Score row block of one 16-query tile.  On return st[kt][r] = SOFTMAX probability (before query mask /
 // dropout) of key 16*kt + 4*lg + r for query q0 + li; m2 = row max in base-2 exponent units,
 // inv = 1/sum; `uniform` marks rows with no valid key.
+// `kb` is the additive key bias in LDS (0 = valid key, -inf = masked or beyond T), read 4 keys at a time: the
+// mask costs one fused multiply-add per score; only the diagonal tile adds the causal compare.  (The first
+// version derived every element's validity from bit tests and boolean logic: 34 VALU + 22 SALU instructions per
+// score, more issue time than the MFMAs.)  Rows whose item id is 0 ("dead") are computed like any other and
+// forced to probability 0 at the end.
 template <int NKT, int NDS>
-__device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, const float (&qf)[NDS], uint64_t kbits,
+__device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, const float (&qf)[NDS], const float* kb,
                                            int kt_lo, int qt, int T, bool is_dead, bool q_in_range, f32x4 (&st)[NKT],
-                                           float& m2, float& inv, bool& uniform) {
+                                           float& m2, float& inv, bool& uniform, bool fine = false) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     float mx = -INFINITY;
-    const float c2 = is_dead ? 0.0f : g.isd_log2e;
+    const float c2 = g.isd_log2e;                                                // scale (modules.py:219), base 2
+    auto finish = [&](int kt, f32x4 acc) {                                       // mask + running max of one key tile
+        const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);   // key mask (modules.py:222-229)
+        acc[0] = fmaf(acc[0], c2, b4.x); acc[1] = fmaf(acc[1], c2, b4.y);
+        acc[2] = fmaf(acc[2], c2, b4.z); acc[3] = fmaf(acc[3], c2, b4.w);
+        if (kt == qt) {                                                          // causal mask on the diagonal tile (modules.py:232-241)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        f32x4 acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (kt >= kt_lo && kt <= qt) {                                           // wave-uniform; tiles below kt_lo hold no valid key
-            acc = mma_tile_frag<NDS>(Ks + 16 * kt * g.PA, g.PA, qf);             // St tile (modules.py:216)
-            const bool below_diag = kt < qt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool valid = (((kbits >> (4 * kt + r)) & 1ull) != 0) && !is_dead &&
-                                   (below_diag || (4 * lg + r <= li));           // key mask + causal (modules.py:222-241)
-                const float sv = valid ? acc[r] * c2 : -INFINITY;               // scale (modules.py:219), base 2
-                acc[r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+            for (int r = 0; r < 4; ++r) acc[r] = (4 * lg + r <= li) ? acc[r] : -INFINITY;
         }
-        st[kt] = acc;
+        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+        return acc;
+    };
+    const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {                                        // St tiles (modules.py:216), two chains at a time
+        const bool c0 = kt >= kt_lo && kt <= qt;                                 // wave-uniform; tiles below kt_lo hold no valid key
+        const bool c1 = (kt + 1 < NKT) && kt + 1 >= kt_lo && kt + 1 <= qt;
+        f32x4 acc0 = ninf, acc1 = ninf;
+        if (c0 && c1) {
+            mma_tile_frag2<NDS>(Ks + 16 * kt * g.PA, Ks + 16 * (kt + 1) * g.PA, g.PA, qf, qf, acc0, acc1);
+            acc0 = finish(kt, acc0);
+            acc1 = finish(kt + 1, acc1);
+        } else if (c0) {
+            acc0 = finish(kt, mma_tile_frag<NDS>(Ks + 16 * kt * g.PA, g.PA, qf));
+        } else if (c1) {
+            acc1 = finish(kt + 1, mma_tile_frag<NDS>(Ks + 16 * (kt + 1) * g.PA, g.PA, qf));
+        }
+        st[kt] = acc0;
+        if (kt + 1 < NKT) st[kt + 1] = acc1;
+#ifdef AT_FINE
+        if (fine) AT_TS(8 + kt / 2);
+#endif
     }
     mx = grp_max(mx);
     uniform = (mx == -INFINITY) && !is_dead && q_in_range;
@@ -354,15 +306,21 @@ __device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, c
     sum = grp_sum(sum);
     inv = sum > 0.0f ? 1.0f / sum : 0.0f;
     m2 = mx;
-    const float uni = uniform ? g.invT : 0.0f;                                   // modules.py:227-244
-    const float sc = uniform ? 0.0f : inv;                                       // modules.py:244
+    if (is_dead) inv = 0.0f;                                                     // dead rows: every probability 0
+    if (__any(uniform ? 1 : 0)) {                                                // rare: a row with no valid key at all
+        const float uni = uniform ? g.invT : 0.0f;                               // modules.py:227-244
+        const float sc = uniform ? 0.0f : inv;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float u = (16 * kt + 4 * lg + r < T) ? uni : 0.0f;
-            st[kt][r] = st[kt][r] * sc + u;
+            for (int r = 0; r < 4; ++r) {
+                const float u = (16 * kt + 4 * lg + r < T) ? uni : 0.0f;
+                st[kt][r] = st[kt][r] * sc + u;
+            }
         }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) st[kt] *= inv;                          // modules.py:244
     }
 }
 
@@ -407,7 +365,7 @@ static int attn_validate(const cr_attn_desc* d, const char* who) {
     return CR_OK;
 }
 // the MFMA kernels keep K and V of one (sample, head) resident in LDS: T <= 256, head dim <= 64
-static inline bool attn_lds_envelope(const cr_attn_desc* d) { return d->T <= 256 && d->d <= 64; }
+static inline bool attn_lds_envelope(const cr_attn_desc* d) { return d->T <= 256 && d->d <= 64 && d->d >= 4; }
 
 static int attn_geom(const cr_attn_desc* d, AttnGeom* g, const char* who) {
     int rc = attn_validate(d, who);

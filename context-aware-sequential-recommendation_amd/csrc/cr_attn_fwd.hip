@@ -19,6 +19,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     AT_TS(0); AT_TS(1);
+    const DropCtx dc = drop_ctx(d.drop);                // reads the step counter: requested first, needed late
     TileSched sch = sched_init(nw, wave);
     int qi = sched_rank(sch);                           // rank of the wave's first tile (0 = heaviest)
     float qn[NDS];                                      // Q fragment of the wave's next tile, in flight during the staging
@@ -28,23 +29,21 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const int t0c = (t0 < T) ? base_row + t0 : base_row;
     const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
     const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
-    stage_rows2(Ks, g.PA, d.K, d.ld, Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16, wave, nw);
+    stage_pair<NDS>(Ks, g.PA, d.K, d.ld, Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
     if (t0 < g.T16) {
-        kv[t0] = (t0 < T) ? kv0 : 0.0f;
+        kv[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;      // additive key bias
         qv[t0] = (t0 < T) ? qv0 : 0.0f;
         dead[t0] = (t0 >= T || id0 == 0) ? 1.0f : 0.0f;
     }
     for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {     // fewer threads than rows (small workgroups)
-        kv[t] = (t < T) ? d.k_valid[base_row + t] : 0.0f;
+        kv[t] = (t < T && d.k_valid[base_row + t] != 0.0f) ? 0.0f : -INFINITY;
         qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
         dead[t] = (t >= T || (d.dead_ids && d.dead_ids[base_row + t] == 0)) ? 1.0f : 0.0f;
     }
     AT_TS(2);
     __syncthreads();
     AT_TS(3);
-    const uint64_t kbits = key_bits<NKT>(kv, T);
-    const int kt_first = first_valid_tile<NKT>(kbits);
-    const DropCtx dc = drop_ctx(d.drop);
+    const int kt_first = first_valid_tile<NKT>(kv, g.nkt);
     const int qi_first = qi;
     for (; qi < g.nkt; qi = sched_next(sch)) {
         const int qt = g.nkt - 1 - qi;                  // heaviest tiles first
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         f32x4 st[NKT];
         float m2, inv;
         bool uniform;
-        score_rows<NKT, NDS>(g, Ks, qf, kbits, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform);
+        score_rows<NKT, NDS>(g, Ks, qf, kv, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform, qi == qi_first);
         if (qi == qi_first) AT_TS(4);
         const float qvq = qv[q];
         const bool any_uni = __any(uniform ? 1 : 0) != 0;

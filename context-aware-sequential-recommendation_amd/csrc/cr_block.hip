@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     float* vec = W2s + 4 * g.ks * BK_WROW;  // 4 x [64]: gamma2, beta2, b1, b2 (zero padded)
     float* msk = vec + 256;                 // [64] row mask (sasrec.py:83)
     float* Hs = Os;
+    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);   // step counter load: requested first, needed late
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;                                  // first row of this wave
@@ -391,7 +392,6 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     __syncthreads();                        // the only barrier
     ln_rows_fast(Os, Fs, vec, vec + 64, D, wave);                                           // sasrec.py:81
     if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
-    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
     // per-lane hashing bases: idx = (row_offset + m) * D + col
     uint32_t rb[4];
 #pragma unroll

@@ -50,6 +50,21 @@ def timeline(which, title, names):
         dlt = (t[:, b] - t[:, a])[ok]
         print("  stamp %2d -> %2d  %-36s median %6.0f ticks (%.2f us)  p90 %6.0f" % (a, b, names.get((a, b), ""), np.median(dlt), np.median(dlt) * 0.46e-3, np.percentile(dlt, 90)))
 
+FINE = os.environ.get("FINE") == "1"
+def fine_fwd():
+    ts = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    for _ in range(3): run()
+    torch.cuda.synchronize(); fn(ts.data_ptr(), 0); run(); torch.cuda.synchronize(); fn(None, 0)
+    t = ts.cpu().numpy().reshape(-1, 16).astype(np.float64)
+    t = t[t[:, 15] > 0]
+    heavy = t[(t[:, 14] > 0)]            # waves whose first tile reaches the 7th key-tile pair
+    print("waves with a 13-key-tile first tile:", len(heavy))
+    seq = [3, 8, 9, 10, 11, 12, 13, 14, 4, 5, 6, 7]
+    for a, b in zip(seq[:-1], seq[1:]):
+        dlt = heavy[:, b] - heavy[:, a]
+        print("  stamp %2d -> %2d median %6.0f ticks  min %6.0f" % (a, b, np.median(dlt), dlt.min()))
+if FINE:
+    fine_fwd(); sys.exit(0)
 timeline(0, "attn fwd", {(1, 2): "issue frag + K/V staging", (2, 3): "barrier", (3, 4): "scores + softmax (tile 0)", (4, 5): "mask/dropout", (5, 6): "P V", (6, 7): "store"})
 timeline(1, "attn bwd (query-owner)", {(1, 2): "issue frags + K/V staging", (2, 3): "barrier", (3, 4): "scores + softmax (tile 0)", (4, 5): "dP + softmax bwd", (5, 6): "dS scale + dQ mma", (6, 7): "stores"})
 timeline(2, "attn bwd (key-owner)", {(1, 2): "issue frags + Q/dO staging", (2, 3): "barrier", (3, 4): "tile flags + barrier", (4, 5): "q-tile loop (key tile 0)", (5, 6): "stores"})
