@@ -161,12 +161,17 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int nw = blockDim.x >> 6;
     float* Qs = smem;                                   // [T16][PA]  A- and B-pattern reads
     float* Os = Qs + g.T16 * g.PA + A_TAIL;             // [T16][PA]  dOut
+    // per-row statistics, stored so that the inner loop is branch-free (16-byte reads of 4 consecutive rows):
+    //   P[q][key] = valid * exp2(s*c - smx) * sinv + (key < T ? suni : 0)
+    // normal row: smx = max, sinv = 1/sum, suni = 0; uniform row: sinv = 0, suni = 1/T; dead row: both 0
+    // (smx = +1e30 wherever sinv = 0, so the exponential is exactly 0 instead of a possible inf * 0)
     float* smx = Os + g.T16 * g.PA + A_TAIL;            // [T16] each
     float* sinv = smx + g.T16;
     float* sdel = sinv + g.T16;
     float* sflag = sdel + g.T16;
     float* qv = sflag + g.T16;
-    float* tile_uni = qv + g.T16;                       // [nkt]: tile holds a flag==1 row
+    float* suni = qv + g.T16;
+    float* tile_uni = suni + g.T16;                     // [nkt]: tile holds a flag==1 row
     float* tile_live = tile_uni + g.nkt;                // [nkt]: tile holds a row with flag != 2
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
@@ -188,20 +193,20 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const f4s st0 = *reinterpret_cast<const f4s*>(bd.stats + ((size_t)blockIdx.x * T + (t0 < T ? t0 : 0)) * 4);
     const float qv0 = d.q_valid[base_row + (t0 < T ? t0 : 0)];
     stage_pair<NDS>(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
-    if (t0 < g.T16) {
-        smx[t0] = (t0 < T) ? st0.x : 0.0f;
-        sinv[t0] = (t0 < T) ? st0.y : 0.0f;
-        sdel[t0] = (t0 < T) ? st0.z : 0.0f;
-        sflag[t0] = (t0 < T) ? st0.w : 2.0f;
-        qv[t0] = (t0 < T) ? qv0 : 0.0f;
-    }
+    auto put_stats = [&](int t, float mx_, float inv_, float del_, float flag_, float qv_) {
+        const float flag = (t < T) ? flag_ : 2.0f;
+        const bool normal = flag == 0.0f;
+        smx[t] = normal ? mx_ : 1e30f;
+        sinv[t] = normal ? inv_ : 0.0f;
+        sdel[t] = normal ? del_ : 0.0f;
+        suni[t] = (flag == 1.0f) ? g.invT : 0.0f;
+        sflag[t] = flag;
+        qv[t] = (t < T) ? qv_ : 0.0f;
+    };
+    if (t0 < g.T16) put_stats(t0, st0.x, st0.y, st0.z, st0.w, qv0);
     for (int t = t0 + blockDim.x; t < g.T16; t += blockDim.x) {
         const float* sp = bd.stats + ((size_t)blockIdx.x * T + (t < T ? t : 0)) * 4;
-        smx[t] = (t < T) ? sp[0] : 0.0f;
-        sinv[t] = (t < T) ? sp[1] : 0.0f;
-        sdel[t] = (t < T) ? sp[2] : 0.0f;
-        sflag[t] = (t < T) ? sp[3] : 2.0f;
-        qv[t] = (t < T) ? d.q_valid[base_row + t] : 0.0f;
+        put_stats(t, sp[0], sp[1], sp[2], sp[3], d.q_valid[base_row + (t < T ? t : 0)]);
     }
     AT_TS(2);
     __syncthreads();
@@ -219,6 +224,8 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     AT_TS(4);
     for (; kt < g.nkt; kt = sched_next(sch)) {
         const int key = 16 * kt + li;
+        const float key_in_T = key < T ? 1.0f : 0.0f;
+        const uint32_t drop_base = attn_row_idx(d, head, n, 0) + (uint32_t)key;
         float kf[NDS], vf[NDS];
         frag_finish<NDS>(kn, T - 16 * kt, d.d, kf);
         frag_finish<NDS>(vn, T - 16 * kt, d.d, vf);
@@ -242,21 +249,25 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
             f32x4 s_acc, p_acc;                                                      // S[q][key], dP[q][key]: two interleaved chains
             mma_tile_frag2<NDS>(Qs + 16 * qt * g.PA, Os + 16 * qt * g.PA, g.PA, kf, vf, s_acc, p_acc);
             float pa[4], pd[4];
+            {
+                const int q4 = 16 * qt + 4 * lg;                                          // this lane's 4 query rows
+                const float4 m4 = *reinterpret_cast<const float4*>(smx + q4), i4 = *reinterpret_cast<const float4*>(sinv + q4);
+                const float4 d4 = *reinterpret_cast<const float4*>(sdel + q4), u4 = *reinterpret_cast<const float4*>(suni + q4);
+                const float4 w4 = *reinterpret_cast<const float4*>(qv + q4);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+                const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, uu[4] = {u4.x, u4.y, u4.z, u4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                const uint32_t idx0 = drop_base + (uint32_t)(q4 * T);                      // attention_weights[(j*B+n), q4, key]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 16 * qt + 4 * lg + r;
-                const float flag = sflag[q];
-                float psm = 0.0f;
-                if (flag == 0.0f) {
-                    const bool valid = (key <= q) && kvk;
-                    psm = valid ? __builtin_amdgcn_exp2f(s_acc[r] * g.isd_log2e - smx[q]) * sinv[q] : 0.0f;
-                } else if (flag == 1.0f) {
-                    psm = (key < T) ? g.invT : 0.0f;
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (key <= q4 + r) && kvk;                            // causal + key mask
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[r], g.isd_log2e, -mm[r])) * ii[r];
+                    const float pn = valid ? e : 0.0f;                                    // softmax probability of a normal row
+                    float w = ww[r];                                                      // query mask (* dropout keep / (1-rate))
+                    if (dc.on) w *= drop_factor(dc, idx0 + (uint32_t)(r * T));
+                    pa[r] = (pn + key_in_T * uu[r]) * w;                                  // A after mask + dropout
+                    pd[r] = pn * (p_acc[r] * w - dd[r]) * g.isd;                          // dS / sqrt(d)
                 }
-                float w = qv[q];
-                if (dc.on) w *= drop_factor(dc, attn_row_idx(d, head, n, q) + (uint32_t)key);
-                pa[r] = psm * w;                                                          // A after mask+dropout
-                pd[r] = (flag == 0.0f) ? psm * (p_acc[r] * w - sdel[q]) * g.isd : 0.0f;   // dS / sqrt(d)
             }
             const float* op = Os + (16 * qt + 4 * lg) * g.PA + li;
             const float* qp = Qs + (16 * qt + 4 * lg) * g.PA + li;
@@ -297,7 +308,7 @@ static size_t lds_bwd_q(const AttnGeom& g, int w) {
     return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + A_TAIL + 3 * g.T16) + 0 * (size_t)w;
 }
 static size_t lds_bwd_kv(const AttnGeom& g, int w) {
-    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + 2 * A_TAIL + 5 * g.T16 + 2 * g.nkt) + 0 * (size_t)w;
+    return sizeof(float) * ((size_t)g.T16 * (2 * g.PA) + 2 * A_TAIL + 6 * g.T16 + 2 * g.nkt) + 0 * (size_t)w;
 }
 
 template <int NKT, int NDS, int NDT>

@@ -203,47 +203,100 @@ __device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, co
     }
 }
 
-// The wave's 16 rows of a DENSE [M, D] matrix (ld == D) are one contiguous 16*D-float block: move it as
-// a 16-byte-per-lane stream (full cache lines) instead of 4-byte lanes on 4*D-byte row segments.
-__device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, int P, int D, int nrows, uint32_t invD) {
-    const int lane = threadIdx.x & 63;
-    const int total = nrows * D;
-    const int nf4 = ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) ? (total >> 2) : 0;   // vector path needs 16-B alignment
-    for (int f = lane; f < nf4; f += 64) {
-        const int e = 4 * f;
-        int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
-        float4 v;
-        float* pv = reinterpret_cast<float*>(&v);
+// Row I/O of a wave's 16-row strip of a DENSE [M, D] matrix (ld == D) <-> its rows of a pitch-66 LDS tile.
+// An item is (row r, 4-column chunk q): lane -> q = lane & 15, r = (lane >> 4) + 4 i, i = 0..3, so one wave
+// instruction moves four 4*D-byte rows (contiguous in memory) as 16-byte pieces, dword aligned (all gfx950
+// needs), and the address arithmetic is a multiply-add per 4 elements.  The chunk that crosses column D is
+// accessed shifted back to [D-4, D) and rotated (D >= 4), so nothing outside the rows is touched; on the LDS
+// side ALL 64 columns of all 16 rows are written (zeros outside the valid rows / columns).
+// (The first version walked a flat element stream and recovered (row, col) per element: 5x the VALU work and
+//  a branch per element, which the instruction census showed to dominate these kernels.)
+typedef float f4r __attribute__((ext_vector_type(4), aligned(4)));
+struct Stream4 { f4r v[4]; };
+__device__ __forceinline__ void stream_fetch(Stream4& s, const float* gsrc, int D, int total) {
+    const int lane = threadIdx.x & 63, q = lane & 15, r0 = lane >> 4;
+    const int col0 = min(4 * q, D - 4);
+    if (total <= 0) {                                   // wave-uniform: a strip beyond the matrix must not be touched at all
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pv[u] = Ts[r * P + c];
-            if (++c == D) { c = 0; ++r; }
-        }
-        reinterpret_cast<float4*>(gdst)[f] = v;
+        for (int i = 0; i < 4; ++i) s.v[i] = (f4r){0.f, 0.f, 0.f, 0.f};
+        return;
     }
-    for (int e = 4 * nf4 + lane; e < total; e += 64) {
-        const int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
-        gdst[e] = Ts[r * P + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * i;
+        const bool valid = (r * D < total) && (4 * q < D);
+        s.v[i] = *reinterpret_cast<const f4r*>(gsrc + (valid ? r * D + col0 : 0));
     }
 }
-__device__ __forceinline__ void wave_load_rows(float* Ts, const float* gsrc, int P, int D, int nrows, uint32_t invD) {
-    const int lane = threadIdx.x & 63;
-    const int total = nrows * D;
-    const int nf4 = ((reinterpret_cast<uintptr_t>(gsrc) & 15) == 0) ? (total >> 2) : 0;
-    for (int f = lane; f < nf4; f += 64) {
-        const int e = 4 * f;
-        int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
-        const float4 v = reinterpret_cast<const float4*>(gsrc)[f];
-        const float* pv = reinterpret_cast<const float*>(&v);
+// place the strip into the wave's rows of a pitch-66 tile; fn(e, r, v) maps (flat element e = r*D + c, row r) -> value
+template <class F>
+__device__ __forceinline__ void stream_put(float* Ts, const Stream4& s, int D, int total, uint32_t, F fn) {
+    const int lane = threadIdx.x & 63, q = lane & 15, r0 = lane >> 4;
+    const int shift = 4 * q - min(4 * q, D - 4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            Ts[r * P + c] = pv[u];
-            if (++c == D) { c = 0; ++r; }
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * i;
+        const bool valid = (r * D < total) && (4 * q < D);
+        const float x0 = s.v[i].x, x1 = s.v[i].y, x2 = s.v[i].z, x3 = s.v[i].w;
+        float e[4];
+        e[0] = shift == 0 ? x0 : (shift == 1 ? x1 : (shift == 2 ? x2 : x3));
+        e[1] = shift == 0 ? x1 : (shift == 1 ? x2 : (shift == 2 ? x3 : 0.0f));
+        e[2] = shift == 0 ? x2 : (shift == 1 ? x3 : 0.0f);
+        e[3] = shift == 0 ? x3 : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = (valid && 4 * q + t < D) ? fn(r * D + 4 * q + t, r, e[t]) : 0.0f;
+        float2* pt = reinterpret_cast<float2*>(Ts + r * F3_P + 4 * q);
+        pt[0] = make_float2(e[0], e[1]);
+        pt[1] = make_float2(e[2], e[3]);
     }
-    for (int e = 4 * nf4 + lane; e < total; e += 64) {
-        const int r = (int)__umulhi((uint32_t)e, invD), c = e - r * D;
-        Ts[r * P + c] = gsrc[e];
+}
+struct PutPlain { __device__ __forceinline__ float operator()(int, int, float v) const { return v; } };
+// Ts[valid elements] += strip
+__device__ __forceinline__ void stream_add(float* Ts, const Stream4& s, int D, int total) {
+    const int lane = threadIdx.x & 63, q = lane & 15, r0 = lane >> 4;
+    const int shift = 4 * q - min(4 * q, D - 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * i;
+        const bool valid = (r * D < total) && (4 * q < D);
+        const float x0 = s.v[i].x, x1 = s.v[i].y, x2 = s.v[i].z, x3 = s.v[i].w;
+        float e[4];
+        e[0] = shift == 0 ? x0 : (shift == 1 ? x1 : (shift == 2 ? x2 : x3));
+        e[1] = shift == 0 ? x1 : (shift == 1 ? x2 : (shift == 2 ? x3 : 0.0f));
+        e[2] = shift == 0 ? x2 : (shift == 1 ? x3 : 0.0f);
+        e[3] = shift == 0 ? x3 : 0.0f;
+        float2* pt = reinterpret_cast<float2*>(Ts + r * F3_P + 4 * q);
+        float2 a = pt[0], b = pt[1];
+        a.x += (valid && 4 * q + 0 < D) ? e[0] : 0.0f;
+        a.y += (valid && 4 * q + 1 < D) ? e[1] : 0.0f;
+        b.x += (valid && 4 * q + 2 < D) ? e[2] : 0.0f;
+        b.y += (valid && 4 * q + 3 < D) ? e[3] : 0.0f;
+        pt[0] = a;
+        pt[1] = b;
+    }
+}
+__device__ __forceinline__ void wave_load_rows(float* Ts, const float* gsrc, int, int D, int nrows, uint32_t invD) {
+    Stream4 s;
+    stream_fetch(s, gsrc, D, nrows * D);
+    stream_put(Ts, s, D, nrows * D, invD, PutPlain());
+}
+__device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, int, int D, int nrows, uint32_t) {
+    const int lane = threadIdx.x & 63, q = lane & 15, r0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * i;
+        if (r < nrows && 4 * q < D) {
+            const float2* pt = reinterpret_cast<const float2*>(Ts + r * F3_P + 4 * q);
+            const float2 a = pt[0], b = pt[1];
+            float* gp = gdst + r * D + 4 * q;
+            if (4 * q + 3 < D) {
+                *reinterpret_cast<f4r*>(gp) = (f4r){a.x, a.y, b.x, b.y};
+            } else {
+                gp[0] = a.x;
+                if (4 * q + 1 < D) gp[1] = a.y;
+                if (4 * q + 2 < D) gp[2] = b.x;
+            }
+        }
     }
 }
 
@@ -296,40 +349,6 @@ __device__ __forceinline__ void ln_rows(const float* Xs, float* Ys, int P, const
     }
 }
 
-// A wave's 16 rows x D floats as <= 4 float4 per lane (D <= 64): fetched early, placed into LDS later.
-struct Stream4 { float4 v[4]; };
-__device__ __forceinline__ void stream_fetch(Stream4& s, const float* gsrc, int total) {
-    const int lane = threadIdx.x & 63;
-    const bool vec = (reinterpret_cast<uintptr_t>(gsrc) & 15) == 0;     // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = lane + 64 * i;
-        s.v[i] = (vec && 4 * f + 3 < total) ? reinterpret_cast<const float4*>(gsrc)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (4 * f < total && (!vec || 4 * f + 3 >= total)) {   // unaligned base or ragged tail: element-wise
-            float* pv = reinterpret_cast<float*>(&s.v[i]);
-            for (int u = 0; u < 4; ++u) pv[u] = (4 * f + u < total) ? gsrc[4 * f + u] : 0.0f;
-        }
-    }
-}
-// place the stream into the wave's rows of a pitch-66 tile; `scale_fn(e, v)` maps flat element e -> value
-template <class F>
-__device__ __forceinline__ void stream_put(float* Ts, const Stream4& s, int D, int total, uint32_t invD, F fn) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e0 = 4 * (lane + 64 * i);
-        if (e0 < total) {
-            int r = (int)__umulhi((uint32_t)e0, invD), c = e0 - r * D;
-            const float* pv = reinterpret_cast<const float*>(&s.v[i]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (e0 + u < total) Ts[r * F3_P + c] = fn(e0 + u, r, pv[u]);
-                if (++c == D) { c = 0; ++r; }
-            }
-        }
-    }
-}
-struct PutPlain { __device__ __forceinline__ float operator()(int, int, float v) const { return v; } };
 
 // ---- F3: LN2 + point-wise feed-forward + residual + mask -----------------------------------------------
 // Pad-tolerant, branch-free element code: tiles have pitch 66 and ALL 64 columns are computed and written to
@@ -374,8 +393,7 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;                                  // first row of this wave
     const int nr = max(0, min(16, d.M - mw));                       // its valid rows
-    for (int e = lane; e < 16 * F3_P; e += 64) Os[16 * wave * F3_P + e] = 0.0f;
-    if (nr > 0) wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
+    wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
     {
         WFrag wa, wb;
         fetch_w(wa, d.w1, D, 0, D);
@@ -443,8 +461,7 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
     const int mw = m0 + 16 * wave;
     const int nr = max(0, min(16, d.M - mw));
     BK_TS(0); BK_TS(1);
-    for (int e = lane; e < 16 * F3_P; e += 64) Xs[16 * wave * F3_P + e] = 0.0f;
-    if (nr > 0) wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
+    wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
     {
         WFrag w3[3];
 #pragma unroll
@@ -661,9 +678,9 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
     auto fetch = [&](int m0) {
         const int mw = m0 + 16 * w4;
         const int tot = max(0, min(16, me - mw)) * D;
-        stream_fetch(sdy, bd.dy + (size_t)mw * D, tot);
-        stream_fetch(shid, d.hid + (size_t)mw * D, tot);
-        stream_fetch(sfin, d.f_in + (size_t)mw * D, tot);
+        stream_fetch(sdy, bd.dy + (size_t)mw * D, D, tot);
+        stream_fetch(shid, d.hid + (size_t)mw * D, D, tot);
+        stream_fetch(sfin, d.f_in + (size_t)mw * D, D, tot);
     };
     if (mb < me) fetch(mb + 64 * grp);
     BK_TSG(gm, 2);
@@ -678,7 +695,6 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         float* t1 = T1 + 16 * w4 * F3_P; float* t2 = T2 + 16 * w4 * F3_P;
         float* t3 = T3 + 16 * w4 * F3_P;
         if (lane < 16) msk[16 * w4 + lane] = (lane < nr && d.mask_ids[mw + lane] != 0) ? 1.0f : 0.0f;
-        zero_rows(t1); zero_rows(t2); zero_rows(t3);
         if (base == mb) BK_TSG(gm, 4);
         // g2 = dy * mask * keep2/(1-rate) (sasrec.py:83, modules.py:309-310)
         {
@@ -748,8 +764,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         __syncthreads();                                           // all waves are done with every row of T3
         if (base == mb) BK_TSG(gm, 9);
         // LN2 backward in place on own rows: x = o (streamed into T3), dy = df (T1) -> d_o (T1)
-        zero_rows(t3);
-        if (nr > 0) wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
+        wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
         ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, w4);
         if (nr > 0) wave_store_rows(bd.d_o + (size_t)mw * D, t1, F3_P, D, nr, gm.invD);
         __syncthreads();
@@ -830,10 +845,10 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
     auto fetch4 = [&](int m0) {
         const int mw = m0 + 16 * w4;
         const int tot = max(0, min(16, me - mw)) * D;
-        stream_fetch(s0, bd.dqkv + (size_t)mw * D, tot);
-        stream_fetch(s1, d.q_in + (size_t)mw * D, tot);
-        stream_fetch(s2, bd.dqkv + MD + (size_t)mw * D, tot);
-        stream_fetch(s3, d.x + (size_t)mw * D, tot);
+        stream_fetch(s0, bd.dqkv + (size_t)mw * D, D, tot);
+        stream_fetch(s1, d.q_in + (size_t)mw * D, D, tot);
+        stream_fetch(s2, bd.dqkv + MD + (size_t)mw * D, D, tot);
+        stream_fetch(s3, d.x + (size_t)mw * D, D, tot);
     };
     if (mb < me) fetch4(mb + 64 * grp);
     put_wt_packed<NT>(Wqt, vq, D, 4 * ks);
@@ -847,12 +862,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         float* tg = TG + 16 * w4 * F3_P; float* ta = TA + 16 * w4 * F3_P; float* tb = TB + 16 * w4 * F3_P;
         if (base != mb) fetch4(m0);
         // ---- phase 1: dQ, q_in -> dWq (+ dbq), dq_in = dQ Wq^T
-        zero_rows(tg); zero_rows(ta);
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
         stream_put(ta, s1, D, tot, gm.invD, PutPlain());
         plant_ones(ta, ones, nr);
-        stream_fetch(s0, bd.dqkv + 2 * MD + (size_t)mw * D, tot);      // dV and the residual gradient d_o, for later phases
-        stream_fetch(s1, bd.d_o + (size_t)mw * D, tot);
+        stream_fetch(s0, bd.dqkv + 2 * MD + (size_t)mw * D, D, tot);      // dV and the residual gradient d_o, for later phases
+        stream_fetch(s1, bd.d_o + (size_t)mw * D, D, tot);
         __syncthreads();
         tile_wgrad(awq, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bqs += colsum64(TG, gtid);
@@ -861,7 +875,6 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         tile_mma(acc, TG, F3_P, Wqt, ks, w4);
         __syncthreads();                                           // all rows of TG (dQ) and TA (q_in) have been read
         // ---- phase 2: dK, x -> dWk (+ dbk), dx_part = dK Wk^T
-        zero_rows(tg); zero_rows(ta);
         stream_put(tg, s2, D, tot, gm.invD, PutPlain());
         stream_put(ta, s3, D, tot, gm.invD, PutPlain());
         plant_ones(ta, ones, nr);
@@ -871,7 +884,6 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         tile_mma(dxa, TG, F3_P, Wkt, ks, w4);
         __syncthreads();                                           // all rows of TG (dK) have been read
         // ---- phase 3: dV -> dWv (+ dbv), dx_part += dV Wv^T
-        zero_rows(tg);
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
         __syncthreads();
         tile_wgrad(awv, TA, TG, F3_P, w4);
@@ -887,22 +899,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
                 TG[o] = acc[j][r];
                 TB[o] = dxa[j][r];
             }
-        {
-            const int lane_ = lane;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                            // tg += d_o (row stream)
-                const int e0 = 4 * (lane_ + 64 * i);
-                if (e0 < tot) {
-                    int r = (int)__umulhi((uint32_t)e0, gm.invD), c = e0 - r * D;
-                    const float* pv = reinterpret_cast<const float*>(&s1.v[i]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (e0 + u < tot) tg[r * F3_P + c] += pv[u];
-                        if (++c == D) { c = 0; ++r; }
-                    }
-                }
-            }
-        }
+        stream_add(tg, s1, D, tot);                                 // tg += d_o (residual branch)
         if (ones >= 0 && lane < 16) ta[lane * F3_P + ones] = 0.0f;     // remove the ones column before LN reads x
         ln_bwd_rows(TA, TG, TB, gam, ag, ab, D, w4);
         if (nr > 0) {
