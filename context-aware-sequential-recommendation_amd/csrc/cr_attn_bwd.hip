@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         const bool live = !uniform && !is_dead && (q < T);
         const float wq = live ? qvq : 0.0f;
         const uint32_t ridx = attn_row_idx(d, head, n, q);
+        const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;     // dropout counter of key 4*lg
         // dP^T[key][q] = V dO^T, then softmax backward (delta = sum_k dPsm * Psm)
         f32x4 dps[NKT];
         float delta = 0.0f;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
             for (int r = 0; r < 4; ++r) {
                 const float psm = st[kt][r];
                 float w = wq;                                                 // query mask (* dropout keep / (1-rate))
-                if (dc.on) w *= drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
+                if (dc.on) w *= drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
                 const float dpsm = acc[r] * w;
                 delta += dpsm * psm;
                 acc[r] = dpsm;
@@ -257,14 +258,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
                 const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
                 const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, uu[4] = {u4.x, u4.y, u4.z, u4.w};
                 const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
-                const uint32_t idx0 = drop_base + (uint32_t)(q4 * T);                      // attention_weights[(j*B+n), q4, key]
+                const uint32_t x0 = (drop_base + (uint32_t)(q4 * T)) * CR_PHI + dc.key;    // counter of attention_weights[(j*B+n), q4, key]
+                const uint32_t xT = (uint32_t)T * CR_PHI;                                 // next query row
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool valid = (key <= q4 + r) && kvk;                            // causal + key mask
                     const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[r], g.isd_log2e, -mm[r])) * ii[r];
                     const float pn = valid ? e : 0.0f;                                    // softmax probability of a normal row
                     float w = ww[r];                                                      // query mask (* dropout keep / (1-rate))
-                    if (dc.on) w *= drop_factor(dc, idx0 + (uint32_t)(r * T));
+                    if (dc.on) w *= drop_factor_x(dc, x0 + (uint32_t)r * xT);
                     pa[r] = (pn + key_in_T * uu[r]) * w;                                  // A after mask + dropout
                     pd[r] = pn * (p_acc[r] * w - dd[r]) * g.isd;                          // dS / sqrt(d)
                 }

@@ -67,8 +67,7 @@ __device__ __forceinline__ uint32_t attn_row_idx(const cr_attn_desc& d, int head
 
 // branch-free dropout factor: keep ? scale : 0  (all lanes hash; no divergent control flow)
 __device__ __forceinline__ float drop_factor(const DropCtx& c, uint32_t idx) {
-    const uint32_t h = cr_fmix32(idx * 0x9E3779B1u + c.key);
-    return (h >= c.thresh) ? c.scale : 0.0f;
+    return drop_factor_x(c, idx * CR_PHI + c.key);
 }
 
 // D[i][j] = sum_k A[i][k] * frag[k][j]: A = 16-row LDS tile read in the A-pattern (row li, column 4s+lg),

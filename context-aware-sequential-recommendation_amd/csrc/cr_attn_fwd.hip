@@ -74,12 +74,13 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         const float qvq = qv[q];
         const bool any_uni = __any(uniform ? 1 : 0) != 0;
         const uint32_t ridx = attn_row_idx(d, head, n, q);
+        const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;         // counter of key 4*lg; + (16kt + r) * PHI per element
         if (dc.on) {                                                                 // wave-uniform
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)                                          // modules.py:248-257
-                    st[kt][r] *= qvq * drop_factor(dc, ridx + (uint32_t)(16 * kt + 4 * lg + r));
+                    st[kt][r] *= qvq * drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
             }
         } else {
 #pragma unroll

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = fmaxf(acc[j][r] + bias, 0.0f);
-            if (d1.on) v *= (cr_fmix32((rb[r] + 16u * j) * 0x9E3779B1u + d1.key) >= d1.thresh) ? d1.scale : 0.0f;   // modules.py:303-304
+            if (d1.on) v *= drop_factor_x(d1, rb[r] * CR_PHI + d1.key + (16u * j) * CR_PHI);   // modules.py:303-304
             Hs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = v;
         }
     }
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * wave + 4 * lg + r;
             float v = acc[j][r] + bias;
-            if (d2.on) v *= (cr_fmix32((rb[r] + 16u * j) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;   // modules.py:309-310
+            if (d2.on) v *= drop_factor_x(d2, rb[r] * CR_PHI + d2.key + (16u * j) * CR_PHI);   // modules.py:309-310
             v = (v + Fs[row * F3_P + 16 * j + li]) * msk[row];                               // modules.py:313, sasrec.py:83
             Hs[row * F3_P + 16 * j + li] = v;              // the MFMAs above have consumed the wave's Hs rows
         }
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
             const uint32_t hb = (d.drop_ffn2.row_offset + (uint32_t)mw) * (uint32_t)D;
             stream_put(t1, sdy, D, tot, gm.invD, [&](int e, int r, float v) {
                 float x = v * mrow[r];
-                if (d2.on) x *= (cr_fmix32((hb + (uint32_t)e) * 0x9E3779B1u + d2.key) >= d2.thresh) ? d2.scale : 0.0f;
+                if (d2.on) x *= drop_factor_x(d2, (hb + (uint32_t)e) * CR_PHI + d2.key);
                 return x;
             });
         }

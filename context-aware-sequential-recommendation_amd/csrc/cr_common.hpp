@@ -45,8 +45,14 @@ __host__ __device__ __forceinline__ uint32_t cr_fmix32(uint32_t h) {
 __host__ __device__ __forceinline__ uint32_t cr_site_key(uint32_t seed, uint32_t step, uint32_t site) {
     return cr_fmix32(seed ^ cr_fmix32(step * 0x9E3779B9u + site * 0x85EBCA77u + 0x165667B1u));
 }
+// Element mixer: x = idx * PHI + key is a Weyl sequence in idx (already equidistributed in its high bits); one
+// xor-shift + one multiply decorrelates neighbours, and only the high bits matter for the threshold compare.
+// (v_mul_lo_u32 is quarter rate: the 3-multiply fmix32 form cost more issue time than the MFMAs of the
+// attention kernels.)  x is linear in idx, so kernels advance it with adds instead of recomputing idx * PHI.
+#define CR_PHI 0x9E3779B1u
+__host__ __device__ __forceinline__ uint32_t cr_mix(uint32_t x) { return (x ^ (x >> 16)) * 0xD168AAADu; }
 __host__ __device__ __forceinline__ bool cr_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
-    return cr_fmix32(idx * 0x9E3779B1u + key) >= thresh;
+    return cr_mix(idx * CR_PHI + key) >= thresh;
 }
 
 // device-side view of cr_rng, resolved once per kernel
@@ -70,6 +76,8 @@ __device__ __forceinline__ DropCtx drop_ctx(const cr_rng& r) {
 __device__ __forceinline__ float drop_apply(const DropCtx& c, uint32_t idx, float v) {
     return c.on ? (cr_keep(c.key, idx, c.thresh) ? v * c.scale : 0.0f) : v;
 }
+// branch-free factor from a pre-multiplied counter x = idx * CR_PHI + key: keep ? scale : 0
+__device__ __forceinline__ float drop_factor_x(const DropCtx& c, uint32_t x) { return (cr_mix(x) >= c.thresh) ? c.scale : 0.0f; }
 
 // Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15) with four DPP adds (quad xor 1, quad xor 2,
 // row_half_mirror, row_mirror) instead of four ds_bpermute round trips (__shfl_xor): every lane ends up

@@ -29,7 +29,8 @@ def keep_mask(seed, step, site, rate, idx):
     """idx: integer array of element indices -> bool keep mask."""
     key = site_key(seed, step, site)
     thresh, _ = thresh_scale(rate)
-    h = fmix32((np.asarray(idx, np.uint64) * np.uint64(0x9E3779B1) + key) & M32)
+    x = (np.asarray(idx, np.uint64) * np.uint64(0x9E3779B1) + key) & M32          # Weyl counter (cr_common.hpp CR_PHI)
+    h = ((x ^ (x >> np.uint64(16))) * np.uint64(0xD168AAAD)) & M32                # cr_mix
     return h >= thresh
 
 
