@@ -341,6 +341,8 @@ __device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const floa
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int jt = 0; jt < NDT; ++jt) acc[jt] = mfma16(st[kt][r], b[r][jt], acc[jt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NDT, 0);   // the key tile's operand reads as one batch,
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NDT, 0);   // then its MFMAs (NDT independent chains)
         }
     }
 }
