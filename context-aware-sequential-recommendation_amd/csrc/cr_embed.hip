@@ -22,20 +22,30 @@ __global__ __launch_bounds__(256) void k_embed_fwd(cr_embed_desc d) {
     }
 }
 
-// Vectorised gather for hidden sizes that are a multiple of 4 (configs 3-5: D = 64, 128, 256): a row is
-// D/4 float4 chunks, LPR = D/4 lanes per row (<= 64), 64/LPR rows per wave-instruction, and each wave keeps
-// R = 4 row groups in flight (independent 16-B loads issued before any store) -- the shape the HBM-bound
-// C5 gather (1 KiB rows out of a 10 GB table) needs.  16 B per lane, full 128-B lines.
+// Vectorised gather: a row is ceil(D/4) 16-byte chunks (dword aligned is all gfx950 global memory needs),
+// LPR lanes per row (the next power of two, <= 64), 64/LPR rows per wave-instruction, and each wave keeps
+// R = 4 row groups in flight (independent loads issued before any store) -- the shape the HBM-bound C5 gather
+// (1 KiB rows out of a 10 GB table) needs, and 4x fewer vector-memory instructions than one dword per lane at
+// the small hidden sizes.  The chunk that crosses column D is read shifted back to [D-4, D) and rotated, so
+// nothing outside a row is touched (D >= 4).
+typedef float f4e __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void rot4(f4e v, int shift, float (&e)[4]) {
+    e[0] = shift == 0 ? v.x : (shift == 1 ? v.y : (shift == 2 ? v.z : v.w));
+    e[1] = shift == 0 ? v.y : (shift == 1 ? v.z : (shift == 2 ? v.w : 0.0f));
+    e[2] = shift == 0 ? v.z : (shift == 1 ? v.w : 0.0f);
+    e[3] = shift == 0 ? v.w : 0.0f;
+}
 template <int LPR>
 __global__ __launch_bounds__(256) void k_embed_fwd_vec(cr_embed_desc d) {
     constexpr int RPW = 64 / LPR, R = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane / LPR, l = lane % LPR;          // row within the group, float4 chunk within the row
-    const int nchunk = d.D >> 2;
+    const int sub = lane / LPR, l = lane % LPR;          // row within the group, 4-column chunk within the row
+    const int nchunk = (d.D + 3) >> 2;
+    const int c = 4 * l, col0 = min(c, d.D - 4), shift = c - col0;
     const DropCtx dc = drop_ctx(d.drop);
     const int rows_per_iter = RPW * R;
     for (int mb = (blockIdx.x * 4 + wave) * rows_per_iter; mb < d.M; mb += gridDim.x * 4 * rows_per_iter) {
-        float4 v[R];
+        f4e v[R], pv[R];
         int mrow[R];
         bool act[R];
 #pragma unroll
@@ -43,49 +53,56 @@ __global__ __launch_bounds__(256) void k_embed_fwd_vec(cr_embed_desc d) {
             const int m = mb + u * RPW + sub;
             mrow[u] = m;
             act[u] = (m < d.M) && (l < nchunk);
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = (f4e){0.f, 0.f, 0.f, 0.f};
+            pv[u] = (f4e){0.f, 0.f, 0.f, 0.f};
             if (act[u]) {
                 const int id = d.ids[m];
-                if (!(d.zero_pad && id == 0)) v[u] = reinterpret_cast<const float4*>(d.table + (size_t)id * d.D)[l];
+                if (!(d.zero_pad && id == 0)) v[u] = *reinterpret_cast<const f4e*>(d.table + (size_t)id * d.D + col0);
+                if (d.pos_table) pv[u] = *reinterpret_cast<const f4e*>(d.pos_table + (size_t)(m % d.T) * d.D + col0);
             }
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if (!act[u]) continue;
-            const int m = mrow[u], c = 4 * l;
-            float4 x = v[u];
-            x.x *= d.scale; x.y *= d.scale; x.z *= d.scale; x.w *= d.scale;
-            if (d.pos_table) {
-                const float4 p = reinterpret_cast<const float4*>(d.pos_table + (size_t)(m % d.T) * d.D)[l];
-                x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+            const int m = mrow[u];
+            float x[4], p[4];
+            rot4(v[u], shift, x);
+            rot4(pv[u], shift, p);
+            const bool dead = d.mask_ids && d.mask_ids[m] == 0;
+            const uint32_t base = (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float y = x[t] * d.scale + p[t];
+                if (d.addend && c + t < d.D) y += d.addend[(size_t)m * d.ld_add + c + t];
+                if (dc.on) y = drop_apply(dc, base + (uint32_t)t, y);
+                x[t] = dead ? 0.0f : y;
             }
-            if (d.addend) {
-                const float* a = d.addend + (size_t)m * d.ld_add + c;
-                x.x += a[0]; x.y += a[1]; x.z += a[2]; x.w += a[3];
+            float* o = d.out + (size_t)m * d.ld_out + d.col_off + c;
+            if (c + 3 < d.D) {
+                *reinterpret_cast<f4e*>(o) = (f4e){x[0], x[1], x[2], x[3]};
+            } else {
+                o[0] = x[0];
+                if (c + 1 < d.D) o[1] = x[1];
+                if (c + 2 < d.D) o[2] = x[2];
             }
-            if (dc.on) {
-                const uint32_t base = (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c;
-                x.x = drop_apply(dc, base, x.x); x.y = drop_apply(dc, base + 1, x.y);
-                x.z = drop_apply(dc, base + 2, x.z); x.w = drop_apply(dc, base + 3, x.w);
-            }
-            if (d.mask_ids && d.mask_ids[m] == 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(d.out + (size_t)m * d.ld_out + d.col_off + c) = x;
         }
     }
 }
 
-static bool embed_vec_ok(const cr_embed_desc* d) {
-    return d->D % 4 == 0 && d->D / 4 <= 64 && ((d->D / 4) & (d->D / 4 - 1)) == 0 &&      // D/4 a power of two <= 64
-           d->ld_out % 4 == 0 && d->col_off % 4 == 0 && ((uintptr_t)d->table & 15) == 0 && ((uintptr_t)d->out & 15) == 0 &&
-           (!d->pos_table || ((uintptr_t)d->pos_table & 15) == 0);
+static int embed_lpr(int D) {                              // lanes per row: next power of two >= ceil(D/4)
+    const int nchunk = (D + 3) / 4;
+    int lpr = 1;
+    while (lpr < nchunk) lpr <<= 1;
+    return lpr;
 }
+static bool embed_vec_ok(const cr_embed_desc* d) { return d->D >= 4 && (d->D + 3) / 4 <= 64; }
 
 extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
     CR_REQUIRE(d && d->ids && d->table && d->out, "cr_embed_fwd: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->T > 0 && d->D > 0 && d->V > 0 && d->M % d->T == 0, "cr_embed_fwd: bad shape M=%d T=%d D=%d", d->M, d->T, d->D);
     CR_REQUIRE(d->ld_out >= d->col_off + d->D, "cr_embed_fwd: ld_out too small");
     if (embed_vec_ok(d)) {
-        const int lpr = d->D / 4;
+        const int lpr = embed_lpr(d->D);
         const int rows_per_block = 4 * (64 / lpr) * 4;
         int grid = cr_ceil_div(d->M, rows_per_block);
         if (grid > 8192) grid = 8192;
@@ -119,20 +136,39 @@ __global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
     float acc[EMB_MAXC];
 #pragma unroll
     for (int i = 0; i < EMB_MAXC; ++i) acc[i] = 0.0f;
-    for (int b = wave; b < B; b += 4) {
-        const int m = b * d.T + t;
-        const int id = d.ids[m];
-        const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
-        const bool skip_table = (d.zero_pad && id == 0) || bd.table_grad == nullptr;
+    // U rows per pass: their ids, masks and gradient rows are requested together (one latency for U rows),
+    // then scattered; the per-column accumulation order over b stays fixed
+    constexpr int U = 4;
+    for (int b0 = wave; b0 < B; b0 += 4 * U) {
+        int mm[U], id[U];
+        float keep[U], g[U][EMB_MAXC];
 #pragma unroll
-        for (int i = 0; i < EMB_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d.D) {
-                float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
-                g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
-                acc[i] += g;
-                if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
-                if (!skip_table) atomicAdd(bd.table_grad + (size_t)id * d.D + c, g * d.scale);
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + 4 * u;
+            mm[u] = (b < B ? b : b0) * d.T + t;
+            id[u] = d.ids[mm[u]];
+            keep[u] = (b < B && !(d.mask_ids && d.mask_ids[mm[u]] == 0)) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < EMB_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                g[u][i] = (c < d.D) ? d.out[(size_t)mm[u] * d.ld_out + d.col_off + c] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + 4 * u >= B) break;
+            const int m = mm[u];
+            const bool skip_table = (d.zero_pad && id[u] == 0) || bd.table_grad == nullptr;
+#pragma unroll
+            for (int i = 0; i < EMB_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < d.D) {
+                    float gv = g[u][i] * keep[u];
+                    gv = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, gv);
+                    acc[i] += gv;
+                    if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = gv;
+                    if (!skip_table) atomicAdd(bd.table_grad + (size_t)id[u] * d.D + c, gv * d.scale);
+                }
             }
         }
     }
