@@ -18,8 +18,15 @@ __device__ __forceinline__ float slab_sum64(const float* slabs, int n_slabs, int
     const int j = j0 + 4 * c4;
     f4a acc = (f4a){0.f, 0.f, 0.f, 0.f};
     if (j + 3 < n_dense) {
-#pragma unroll 4
-        for (int s = q; s < n_slabs; s += 16) acc += *reinterpret_cast<const f4a*>(slabs + (size_t)s * n_dense + j);
+        int s = q;
+        for (; s + 7 * 16 < n_slabs; s += 8 * 16) {              // 8 independent 16-byte loads in flight
+            f4a v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4a*>(slabs + (size_t)(s + 16 * u) * n_dense + j);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < n_slabs; s += 16) acc += *reinterpret_cast<const f4a*>(slabs + (size_t)s * n_dense + j);
     } else {
         for (int s = q; s < n_slabs; s += 16)
             for (int u = 0; u < 4; ++u)

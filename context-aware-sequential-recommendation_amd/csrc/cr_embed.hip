@@ -195,6 +195,45 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
     const DropCtx dc = drop_ctx(d.drop);
     const int rps = (d.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
+    if (d.D <= 64) {
+        // 16 lanes per row, 4 rows per wave-instruction, U = 4 such groups requested together: the serial
+        // id -> row -> LDS-atomic chain of one row per wave was pure latency (19 us for 5 MB)
+        const int sub = lane >> 4, l = lane & 15;
+        constexpr int U = 4;
+        for (int mb = m0 + wave * 4; mb < m1; mb += 16 * U) {
+            int mm[U], id[U];
+            float keep[U], g[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = mb + 16 * u + sub;
+                const bool act = m < m1;
+                mm[u] = act ? m : m0;
+                id[u] = d.ids[mm[u]];
+                keep[u] = (act && !(d.mask_ids && d.mask_ids[mm[u]] == 0)) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = l + 16 * i;
+                    g[u][i] = (c < d.D) ? d.out[(size_t)mm[u] * d.ld_out + d.col_off + c] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = mb + 16 * u + sub;
+                if (m >= m1) continue;
+                const bool skip_table = (d.zero_pad && id[u] == 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = l + 16 * i;
+                    if (c < d.D) {
+                        float gv = g[u][i] * keep[u];
+                        gv = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, gv);
+                        if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = gv;
+                        if (!skip_table) atomicAdd(&tab[id[u] * d.D + c], gv * d.scale);
+                    }
+                }
+            }
+        }
+    } else
     for (int m = m0 + wave; m < m1; m += 4) {
         const int id = d.ids[m];
         const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
