@@ -154,19 +154,32 @@ __device__ __forceinline__ void load_w_packed(float* Ws, const float* W, int ldw
     put_w_packed(Ws, w, D, rows);
 }
 
-// acc[j] (+)= As[rows 16w..][k] * W[k][16j..]   (x @ W), ks k-steps, W in the packed layout
+// acc[j] (+)= As[rows 16w..][k] * W[k][16j..]   (x @ W), ks k-steps, W in the packed layout.
+// The operands of CH k-steps (CH A values + 4*CH B values) are read as ONE batch with clamped addresses, then
+// the MFMAs of those steps issue back to back behind wave-uniform guards.  (The plain loop compiled to
+// read -> wait -> 2 MFMAs -> read -> wait -> 2 MFMAs: two exposed LDS latencies per k-step, 2.3x the MFMA time.)
+template <int CH = 8>
 __device__ __forceinline__ void tile_mma(f32x4 (&acc)[4], const float* As, int P, const float* Ws, int ks, int wave) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const float* ap = As + (16 * wave + li) * P + lg;
     const float* bp = Ws + (lg >> 1) * 128 + (lg & 1) * 16 + li;
-#pragma unroll 2
-    for (int kk = 0; kk < ks; ++kk) {
-        const float a = ap[4 * kk];
-        float b[4];
+#pragma unroll 1
+    for (int k0 = 0; k0 < ks; k0 += CH) {
+        float a[CH], b[CH][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = bp[kk * 256 + 32 * j];
+        for (int s = 0; s < CH; ++s) {
+            const int k = min(k0 + s, ks - 1);
+            a[s] = ap[4 * k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = mfma16(a, b[j], acc[j]);
+            for (int j = 0; j < 4; ++j) b[s][j] = bp[k * 256 + 32 * j];
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (k0 + s < ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[s], b[s][j], acc[j]);
+            }
+        }
     }
 }
 
@@ -187,19 +200,26 @@ __device__ __forceinline__ void tile_mma_t(f32x4 (&acc)[4], const float* As, con
 }
 
 // accw[j] += sum_m As[m][16w + li] * Gs[m][16j + li] over the 64 rows of the tile (A^T G: weight-gradient
-// strip of k-rows [16w, 16w+16) owned by wave w; with a ones column in As, row `ones` is the bias gradient)
+// strip of k-rows [16w, 16w+16) owned by wave w; with a ones column in As, row `ones` is the bias gradient).
+// Operand reads batched CH steps at a time like tile_mma.
+template <int CH = 4>
 __device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, const float* Gs, int P, int wave) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const float* ap = As + lg * P + 16 * wave + li;
     const float* gp = Gs + lg * P + li;
-#pragma unroll 4
-    for (int mm = 0; mm < 16; ++mm) {
-        const float a = ap[4 * mm * P];
-        float b[4];
+#pragma unroll 1
+    for (int m0 = 0; m0 < 16; m0 += CH) {
+        float a[CH], b[CH][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = gp[4 * mm * P + 16 * j];
+        for (int s = 0; s < CH; ++s) {
+            a[s] = ap[4 * (m0 + s) * P];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accw[j] = mfma16(a, b[j], accw[j]);
+            for (int j = 0; j < 4; ++j) b[s][j] = gp[4 * (m0 + s) * P + 16 * j];
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accw[j] = mfma16(a[s], b[s][j], accw[j]);
     }
 }
 
@@ -723,7 +743,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         {
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma(acc, T1, F3_P, W2t, ks, w4);
+            tile_mma<4>(acc, T1, F3_P, W2t, ks, w4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -751,7 +771,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
                 }
             f32x4 acc[4];
             zero_acc(acc);
-            tile_mma(acc, T2, F3_P, W1t, ks, w4);
+            tile_mma<4>(acc, T2, F3_P, W1t, ks, w4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -872,7 +892,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         if (ones < 0 && gtid < 64) bqs += colsum64(TG, gtid);
         f32x4 acc[4], dxa[4];
         zero_acc(acc); zero_acc(dxa);
-        tile_mma(acc, TG, F3_P, Wqt, ks, w4);
+        tile_mma<4>(acc, TG, F3_P, Wqt, ks, w4);
         __syncthreads();                                           // all rows of TG (dQ) and TA (q_in) have been read
         // ---- phase 2: dK, x -> dWk (+ dbk), dx_part = dK Wk^T
         stream_put(tg, s2, D, tot, gm.invD, PutPlain());
@@ -881,14 +901,14 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         __syncthreads();
         tile_wgrad(awk, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bks += colsum64(TG, gtid);
-        tile_mma(dxa, TG, F3_P, Wkt, ks, w4);
+        tile_mma<4>(dxa, TG, F3_P, Wkt, ks, w4);
         __syncthreads();                                           // all rows of TG (dK) have been read
         // ---- phase 3: dV -> dWv (+ dbv), dx_part += dV Wv^T
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
         __syncthreads();
         tile_wgrad(awv, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bvs += colsum64(TG, gtid);
-        tile_mma(dxa, TG, F3_P, Wvt, ks, w4);
+        tile_mma<4>(dxa, TG, F3_P, Wvt, ks, w4);
         __syncthreads();                                           // all rows of TG (dV) and TA (x) have been read
         // ---- phase 4 (own rows): dq_in = dQ Wq^T + d_o (modules.py:269); dx = dx_part + LN1bwd(dq_in; x)
 #pragma unroll
