@@ -11,6 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcastrec.so")
+LIB_TL = os.path.join(PKG, "libcastrec_tl.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
            "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_wide.hip", "cr_block.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
@@ -31,17 +32,22 @@ def _stale(obj, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, timeline=False):
+    """timeline=True builds libcastrec_tl.so with -DCR_TIMELINE=1: the per-wave phase stamps used by
+    tools/block_ts.py and tools/attn_ts.py (compiled out of the production library)."""
     hipcc = _hipcc()
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    bdir = "build_tl" if timeline else "build"
+    lib = LIB_TL if timeline else LIB
+    flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else [])
+    os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
     headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(ROOT, "include", "castrec.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, "build", s + ".o")
+        obj = os.path.join(CSRC, bdir, s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -53,10 +59,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

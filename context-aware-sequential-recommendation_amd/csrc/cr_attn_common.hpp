@@ -27,7 +27,6 @@
 
 #include "cr_common.hpp"
 
-#define AT_FINE 1
 #define A_MAX_WAVES 8        // two waves per SIMD hide each other's LDS / MFMA latencies
 #define A_TAIL 64            // floats of slack after a B-pattern-read LDS array (reads of padded columns)
 
@@ -40,6 +39,7 @@ struct AttnGeom {
     float invT;
     unsigned long long* ts;  // debug: per-wave phase stamps [waves][16] (tools/attn_ts.py); NULL in production
 };
+#ifdef CR_TIMELINE
 // debug-only phase stamps: slots 0 / 15 = wall clock (100 MHz), others = s_memtime; first tile of a wave only
 #define AT_TS(slot)                                                                                          \
     do {                                                                                                     \
@@ -49,6 +49,11 @@ struct AttnGeom {
     } while (0)
 extern unsigned long long* g_attn_ts;
 extern int g_attn_ts_which;   // 0 = forward, 1 = backward (query-owner), 2 = backward (key-owner)
+#else
+#define AT_TS(slot) do { } while (0)
+static unsigned long long* const g_attn_ts = nullptr;
+static const int g_attn_ts_which = 0;
+#endif
 
 __device__ __forceinline__ float grp_max(float v) {   // over the 4 lanes that share (lane & 15)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -281,7 +286,7 @@ __device__ __forceinline__ void score_rows(const AttnGeom& g, const float* Ks, c
         }
         st[kt] = acc0;
         if (kt + 1 < NKT) st[kt + 1] = acc1;
-#ifdef AT_FINE
+#ifdef CR_TIMELINE
         if (fine) AT_TS(8 + kt / 2);
 #endif
     }

@@ -1,9 +1,11 @@
 // Attention forward (modules.py:208-269); see cr_attn_common.hpp for the design.
 #include "cr_attn_common.hpp"
 
+#ifdef CR_TIMELINE
 unsigned long long* g_attn_ts = nullptr;
 int g_attn_ts_which = 0;
 extern "C" void cr_debug_attn_ts(void* p, int which) { g_attn_ts = static_cast<unsigned long long*>(p); g_attn_ts_which = which; }
+#endif
 
 template <int NKT, int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, AttnGeom g) {

@@ -34,6 +34,7 @@ struct BlockGeom {
     unsigned long long* ts;   // debug: per-wave phase timestamps [n_wg][4 waves][16] (tools/block_ts.py); NULL in production
 };
 
+#ifdef CR_TIMELINE
 // debug-only phase stamps: slots 0 / 15 = wall clock (100 MHz, comparable across the chip), others = s_memtime
 #define BK_TSG(geom, slot)                                                                                   \
     do {                                                                                                     \
@@ -44,6 +45,11 @@ struct BlockGeom {
 #define BK_TS(slot) BK_TSG(g, slot)
 static unsigned long long* g_block_ts = nullptr;
 extern "C" void cr_debug_block_ts(void* p) { g_block_ts = static_cast<unsigned long long*>(p); }
+#else
+#define BK_TSG(geom, slot) do { } while (0)
+#define BK_TS(slot) do { } while (0)
+static unsigned long long* const g_block_ts = nullptr;
+#endif
 
 // ---- small helpers ---------------------------------------------------------------------------------
 // 16 elements per thread of a [64 x 64] window of a row-major matrix: rows m0 + tr + 4i, column c0 + tc

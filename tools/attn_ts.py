@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Per-wave phase timeline of the attention kernels at the headline shape (debug stamps, cr_debug_attn_ts)."""
 import ctypes as C, os, sys
+os.environ["CASTREC_TIMELINE"] = "1"      # instrumented library: python -m castrec_amd.build --timeline
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+import importlib.util as _u
+_b = _u.spec_from_file_location("cr_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "context-aware-sequential-recommendation_amd", "build.py"))
+_m = _u.module_from_spec(_b); _b.loader.exec_module(_m); _m.build(timeline=True)
 import castrec_amd
 from castrec_amd import ops as O, lib as L
 
