@@ -143,7 +143,8 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
         P = {k: v.detach() for k, v in P.items()}
 
 
-@pytest.mark.parametrize("model,D,H,T,L", [("sasrec", 64, 2, 50, 2),      # BASELINE config 3 shape (Beauty: D=64, 2 heads)
+@pytest.mark.parametrize("model,D,H,T,L", [("cast_1", 50, 1, 40, 2),      # BASELINE configs 1-2 shape class (D=50, 1 head): the bench workload
+                                           ("sasrec", 64, 2, 50, 2),      # BASELINE config 3 shape (Beauty: D=64, 2 heads)
                                            ("cast_2", 64, 2, 24, 1),
                                            ("sasrec", 128, 4, 40, 2),     # config 4 shape (Books: D=128, 4 heads) -> unfused path
                                            ("cast_9", 128, 4, 24, 1),

@@ -240,7 +240,7 @@ def attn_core_ref(Q, K, V, kvalid, qvalid, resid, H, keep=None, rate=0.0):
 
 ATTN_CASES = [  # B, T, H, d, rate
     (3, 8, 1, 6, 0.0), (2, 50, 1, 50, 0.0), (2, 200, 1, 50, 0.2), (3, 37, 2, 32, 0.0), (2, 50, 4, 32, 0.5),
-    (1, 256, 1, 64, 0.0), (2, 100, 2, 25, 0.3), (5, 16, 1, 50, 0.0),
+    (1, 256, 1, 64, 0.0), (2, 100, 2, 25, 0.3), (5, 16, 1, 50, 0.0), (5, 24, 1, 20, 0.0), (4, 20, 1, 50, 0.0), (4, 20, 1, 20, 0.2),
     # outside the LDS-resident MFMA envelope (T > 256 or head dim > 64) -> general-shape kernels (cr_attn_wide.hip)
     (2, 300, 1, 50, 0.2), (2, 512, 2, 64, 0.0), (2, 40, 1, 100, 0.3), (2, 130, 1, 256, 0.0), (1, 1024, 1, 8, 0.0),
 ]
