@@ -350,6 +350,12 @@ static int launch_bwd_kv(const cr_attn_bwd_desc* bd, const AttnGeom& g, int wave
     return cr_check_launch("cr_attn_bwd(kv)");
 }
 
+__global__ __launch_bounds__(256) void k_attn_zero_cols(float* p, int ld, int M, int C) {
+    const long long total = (long long)M * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        p[(size_t)(i / C) * ld + (i % C)] = 0.0f;
+}
+
 extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd != nullptr, "cr_attn_bwd: NULL desc");
     const cr_attn_desc* d = &bd->f;
@@ -359,9 +365,27 @@ extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd->dout && bd->dQ && bd->dK && bd->dV && bd->stats, "cr_attn_bwd: NULL pointer");
     CR_REQUIRE(bd->ldg >= d->H * d->d && bd->lddo >= d->H * d->d, "cr_attn_bwd: ldg / lddo too small");
     hipStream_t s = cr_stream(stream);
-    if (!attn_lds_envelope(d)) return cr_attn_wide_bwd_launch(bd, s);
+    if (!attn_lds_envelope(d)) {
+        if (bd->dQ_part) {
+            const int M = d->B * d->T, Cc = d->H * d->d;
+            int grid = cr_ceil_div(M * Cc, 256);
+            if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(k_attn_zero_cols, dim3(grid), dim3(256), 0, s, bd->dQ_part, bd->ldg, M, Cc);
+        }
+        return cr_attn_wide_bwd_launch(bd, s);
+    }
     rc = attn_geom(d, &g, "cr_attn_bwd");
     if (rc) return rc;
+    if (d->row_stats && bd->delta && bd->dQ_part) {     // single pass: forward statistics + delta supplied
+        rc = cr_attn_bwd_single_pass(bd, g, s);
+        if (rc != 0) return rc < 0 ? rc : CR_OK;
+    }
+    if (bd->dQ_part) {                                  // two passes return the whole dQ: the second partial is zero
+        const int M = d->B * d->T, Cc = d->H * d->d;
+        int grid = cr_ceil_div(M * Cc, 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(k_attn_zero_cols, dim3(grid), dim3(256), 0, s, bd->dQ_part, bd->ldg, M, Cc);
+    }
     const int wq = attn_pick_waves(g, lds_bwd_q), wkv = attn_pick_waves(g, lds_bwd_kv);
     if (!wq || !wkv) return cr_attn_wide_bwd_launch(bd, s);
     const int nkt = attn_pick_nkt(g.nkt);

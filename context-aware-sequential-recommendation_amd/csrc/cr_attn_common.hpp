@@ -356,6 +356,9 @@ __device__ __forceinline__ void mma_prob_rows(const f32x4 (&st)[NKT], const floa
 static inline int attn_pick_nds(int d) { return d <= 32 ? 8 : (d <= 52 ? 13 : 16); }
 static inline int attn_pick_nkt(int nkt) { return nkt <= 4 ? 4 : (nkt <= 13 ? 13 : 16); }
 
+// single-pass backward (cr_attn_bwd1.hip): 1 = launched, 0 = shape does not fit (fall back to two passes), < 0 = error
+struct AttnGeom;
+int cr_attn_bwd_single_pass(const cr_attn_bwd_desc* bd, const AttnGeom& g, hipStream_t s);
 // general-shape fallback (cr_attn_wide.hip) for shapes outside the LDS-resident envelope
 int cr_attn_wide_supported(const cr_attn_desc* d);
 int cr_attn_wide_fwd_launch(const cr_attn_desc* d, hipStream_t s);

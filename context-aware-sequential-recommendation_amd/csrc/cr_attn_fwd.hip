@@ -59,6 +59,10 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         const bool is_dead = dead[q] != 0.0f;
         if (__all(is_dead ? 1 : 0) && d.attn_weights == nullptr) {
             // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
+            if (d.row_stats && lg == 0 && q < T) {
+                float* sp = d.row_stats + ((size_t)blockIdx.x * T + q) * 4;
+                sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 2.0f; sp[3] = 0.0f;
+            }
             for (int rr = 0; rr < 16; ++rr) {
                 const int qq = q0 + rr;
                 if (qq < T && lane < d.d) {
@@ -73,6 +77,10 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         bool uniform;
         score_rows<NKT, NDS>(g, Ks, qf, kv, kt_first, qt, T, is_dead, q < T, st, m2, inv, uniform, qi == qi_first);
         if (qi == qi_first) AT_TS(4);
+        if (d.row_stats && lg == 0 && q < T) {                                       // for the single-pass backward
+            float* sp = d.row_stats + ((size_t)blockIdx.x * T + q) * 4;
+            sp[0] = m2; sp[1] = inv; sp[2] = is_dead ? 2.0f : (uniform ? 1.0f : 0.0f); sp[3] = 0.0f;
+        }
         const float qvq = qv[q];
         const bool any_uni = __any(uniform ? 1 : 0) != 0;
         const uint32_t ridx = attn_row_idx(d, head, n, q);

@@ -790,9 +790,29 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         __syncthreads();                                           // all waves are done with every row of T3
         if (base == mb) BK_TSG(gm, 9);
         // LN2 backward in place on own rows: x = o (streamed into T3), dy = df (T1) -> d_o (T1)
+        Stream4 sqin;                                              // q_in rows for the attention delta (T2 is free by now)
+        if (bd.attn_delta) stream_fetch(sqin, d.q_in + (size_t)mw * D, D, tot);
         wave_load_rows(t3, d.o + (size_t)mw * D, F3_P, D, nr, gm.invD);
         ln_bwd_rows(T3, T1, nullptr, gam, ag, ab, D, w4);
         if (nr > 0) wave_store_rows(bd.d_o + (size_t)mw * D, t1, F3_P, D, nr, gm.invD);
+        if (bd.attn_delta) {
+            // delta[m] = sum_c d_o[m][c] * (o[m][c] - q_in[m][c]): the softmax-backward row term of the attention
+            // core (its output is o - q_in, modules.py:262-269), for the single-pass cr_attn_bwd
+            stream_put(t2, sqin, D, tot, gm.invD, PutPlain());
+            const int l = lane & 15, sub = lane >> 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = 16 * w4 + 4 * p + sub;
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = l + 16 * i;
+                    acc += T1[r * F3_P + c] * (T3[r * F3_P + c] - T2[r * F3_P + c]);      // pad columns hold 0
+                }
+                acc = sum16(acc);
+                if (l == 0 && 4 * p + sub < nr) bd.attn_delta[mw + 4 * p + sub] = acc;
+            }
+        }
         __syncthreads();
         if (base == mb) BK_TSG(gm, 10);
     }
@@ -867,10 +887,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
     zero_acc(awq); zero_acc(awk); zero_acc(awv);
     float bqs = 0.0f, bks = 0.0f, bvs = 0.0f;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-    Stream4 s0, s1, s2, s3;                 // dQ, q_in, dK, x  (then s0, s1 again: dV, d_o)
+    Stream4 s0, s1, s2, s3, sp;             // dQ, q_in, dK, x  (then s0, s1 again: dV, d_o); sp: second partial of dQ
     auto fetch4 = [&](int m0) {
         const int mw = m0 + 16 * w4;
         const int tot = max(0, min(16, me - mw)) * D;
+        if (bd.dq_part) stream_fetch(sp, bd.dq_part + (size_t)mw * D, D, tot);
         stream_fetch(s0, bd.dqkv + (size_t)mw * D, D, tot);
         stream_fetch(s1, d.q_in + (size_t)mw * D, D, tot);
         stream_fetch(s2, bd.dqkv + MD + (size_t)mw * D, D, tot);
@@ -889,6 +910,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         if (base != mb) fetch4(m0);
         // ---- phase 1: dQ, q_in -> dWq (+ dbq), dq_in = dQ Wq^T
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
+        if (bd.dq_part) stream_add(tg, sp, D, tot);                // dQ = the two partial sums of the single-pass attention backward
         stream_put(ta, s1, D, tot, gm.invD, PutPlain());
         plant_ones(ta, ones, nr);
         stream_fetch(s0, bd.dqkv + 2 * MD + (size_t)mw * D, D, tot);      // dV and the residual gradient d_o, for later phases

@@ -15,6 +15,7 @@ Memory layout (all fp32, resident in HBM for the life of the engine):
 """
 import ctypes as C
 import math
+import os
 import zlib
 
 import numpy as np
@@ -172,6 +173,7 @@ class Engine:
         self.usernum, self.itemnum = usernum, itemnum
         self.training = training
         # fused row-phase kernels (cr_block_*) need the hidden size to fit one 64-column tile
+        self.single_pass_bwd = os.environ.get("CASTREC_TWO_PASS_ATTN_BWD") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -477,6 +479,12 @@ class Engine:
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
                          dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
         ad.K, ad.V = qkv.data_ptr() + MD4, qkv.data_ptr() + 2 * MD4
+        # single-pass attention backward (H = 1): the forward saves its row statistics, the FFN backward emits
+        # delta, the attention backward returns dQ as two partials that the QKV backward adds
+        one_pass = self.training and H == 1 and self.single_pass_bwd
+        if one_pass:
+            row_stats = self.vec(pfx + "row_stats", H * B * T * 4)
+            ad.row_stats = row_stats.data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
         if not self.training:
@@ -493,9 +501,14 @@ class Engine:
                                  self._acc(id(dx)), G(pfx + "ln1.gamma"), G(pfx + "ln1.beta"), G(pfx + "wqkv"), G(pfx + "bqkv"),
                                  G(pfx + "ln2.gamma"), G(pfx + "ln2.beta"), G(pfx + "w1"), G(pfx + "b1"), G(pfx + "w2"), G(pfx + "b2"),
                                  self.Gs.shape[1], self.n_slabs)
-            self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dqkv.data_ptr(), dqkv.data_ptr() + MD4,
                                 dqkv.data_ptr() + 2 * MD4, D, stats.data_ptr())
+            if one_pass:
+                delta = self.vec("attn_delta", M)                   # shared: consumed within the same block
+                dq_part = self.buf("attn_dq_part", D)
+                bbd.attn_delta, bbd.dq_part = delta.data_ptr(), dq_part.data_ptr()
+                abd.delta, abd.dQ_part = delta.data_ptr(), dq_part.data_ptr()
+            self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst

@@ -75,12 +75,12 @@ class AttnDesc(C.Structure):
     _fields_ = [("Q", c_p), ("K", c_p), ("V", c_p), ("ld", c_i), ("k_valid", c_p), ("q_valid", c_p),
                 ("residual", c_p), ("ldr", c_i), ("dead_ids", c_p), ("out", c_p), ("ldo", c_i),
                 ("attn_weights", c_p), ("B", c_i), ("T", c_i), ("H", c_i), ("d", c_i), ("drop", Rng),
-                ("batch_global", c_i)]
+                ("batch_global", c_i), ("row_stats", c_p)]
 
 
 class AttnBwdDesc(C.Structure):
     _fields_ = [("f", AttnDesc), ("dout", c_p), ("lddo", c_i), ("dQ", c_p), ("dK", c_p), ("dV", c_p),
-                ("ldg", c_i), ("stats", c_p)]
+                ("ldg", c_i), ("stats", c_p), ("delta", c_p), ("dQ_part", c_p)]
 
 
 class BlockDesc(C.Structure):
@@ -93,7 +93,8 @@ class BlockDesc(C.Structure):
 class BlockBwdDesc(C.Structure):
     _fields_ = [("f", BlockDesc), ("dy", c_p), ("d_o", c_p), ("dqkv", c_p), ("dx", c_p), ("dx_accumulate", c_i),
                 ("g_ln1_g", c_p), ("g_ln1_b", c_p), ("g_wqkv", c_p), ("g_bqkv", c_p), ("g_ln2_g", c_p), ("g_ln2_b", c_p),
-                ("g_w1", c_p), ("g_b1", c_p), ("g_w2", c_p), ("g_b2", c_p), ("slab_stride", c_i), ("n_slabs", c_i)]
+                ("g_w1", c_p), ("g_b1", c_p), ("g_w2", c_p), ("g_b2", c_p), ("slab_stride", c_i), ("n_slabs", c_i),
+                ("attn_delta", c_p), ("dq_part", c_p)]
 
 
 class HeadDesc(C.Structure):

@@ -98,17 +98,18 @@ def eltwise(op, x, ldx, y, ldy, M, N, aux=None, ldaux=0, rng=NO_DROP, mask_ids=N
 
 
 def attn_desc(Q, K, V, ld, k_valid, q_valid, residual, ldr, out, ldo, B, T, H, d, rng=NO_DROP, batch_global=None,
-              dead_ids=None, attn_weights=None):
+              dead_ids=None, attn_weights=None, row_stats=None):
     return L.AttnDesc(_p(Q), _p(K), _p(V), ld, _p(k_valid), _p(q_valid), _p(residual), ldr, _p(dead_ids), _p(out), ldo,
-                      _p(attn_weights), B, T, H, d, rng, B if batch_global is None else batch_global)
+                      _p(attn_weights), B, T, H, d, rng, B if batch_global is None else batch_global, _p(row_stats))
 
 
 def attn_fwd(desc):
     L.call("cr_attn_fwd", C.byref(desc), _stream())
 
 
-def attn_bwd(fdesc, dout, lddo, dQ, dK, dV, ldg, stats):
-    d = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(fdesc), _p(dout), lddo, _p(dQ), _p(dK), _p(dV), ldg, _p(stats))
+def attn_bwd(fdesc, dout, lddo, dQ, dK, dV, ldg, stats, delta=None, dQ_part=None):
+    d = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(fdesc), _p(dout), lddo, _p(dQ), _p(dK), _p(dV), ldg, _p(stats),
+                      _p(delta), _p(dQ_part))
     L.call("cr_attn_bwd", C.byref(d), _stream())
 
 

@@ -191,6 +191,8 @@ typedef struct {
     int B, T, H, d;
     cr_rng drop;               /* element index = ((j*Bglobal + n)*T + q)*T + k, see batch_global */
     int batch_global;          /* Bglobal (>= B) for shard-invariant dropout indices */
+    float* row_stats;          /* optional [H*B*T*4]: the forward saves {row max (base-2 units), 1/sum, flag, 0} per
+                                  query row (flag 0 normal, 1 uniform row, 2 dead row) for the single-pass backward */
 } cr_attn_desc;
 int cr_attn_fwd(const cr_attn_desc* d, void* stream);
 
@@ -198,7 +200,14 @@ typedef struct {
     cr_attn_desc f;            /* forward description (out / attn_weights unused) */
     const float* dout; int lddo;   /* gradient of `out` (the residual branch is handled by the caller) */
     float* dQ; float* dK; float* dV; int ldg;
-    float* stats;              /* workspace [H*B*T*4] floats */
+    float* stats;              /* workspace [H*B*T*4] floats (two-pass backward) */
+    /* Single-pass backward (5 MFMA products instead of 7, one launch): taken when f.row_stats (saved by
+     * cr_attn_fwd with the same description), `delta` and `dQ_part` are all given and the shape fits.
+     *   delta[m]  = sum_c dout[m][c] * (out[m][c] - residual[m][c])      (cr_block_ln_ffn_bwd can emit it)
+     *   dQ is returned as TWO partial sums, dQ and dQ_part ([M, ldg] like dQ); the caller adds them
+     *   (cr_block_ln_qkv_bwd does).  Heads H = 1 only. */
+    const float* delta;        /* optional [M] */
+    float* dQ_part;            /* optional [M, ldg] */
 } cr_attn_bwd_desc;
 int cr_attn_bwd(const cr_attn_bwd_desc* d, void* stream);
 
@@ -236,6 +245,9 @@ typedef struct {
     float* g_ln1_g; float* g_ln1_b; float* g_wqkv; float* g_bqkv;      /* slab-0 pointers */
     float* g_ln2_g; float* g_ln2_b; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
     int slab_stride, n_slabs;
+    float* attn_delta;                         /* optional [M], written by ffn_bwd: sum_c d_o[m][c] * (o[m][c] - q_in[m][c]),
+                                                  the softmax-backward row term the single-pass cr_attn_bwd needs */
+    const float* dq_part;                      /* optional [M,D], read by qkv_bwd: second partial of dQ (added to dqkv's dQ rows) */
 } cr_block_bwd_desc;
 int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* d, void* stream);
 int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);

@@ -292,6 +292,23 @@ def test_attention_fwd_bwd(ops, B, T, H, d, rate):
     row = w.detach().numpy()[0, 0]
     if qvalid[0, 0] and keep is None:
         assert np.allclose(row, 1.0 / T)
+    # single-pass backward (forward statistics saved, delta supplied, dQ returned as two partial sums)
+    if H == 1 and T <= 256 and 4 <= d <= 64:
+        rst = torch.full((H * B * T * 4,), float("nan"), device="cuda")
+        out2 = torch.full((M, ld), float("nan"), device="cuda")
+        desc2 = ops.attn_desc(Qd, Kd, Vd, ld, kvd, qvd, Rd, ld, out2, ld, B, T, H, d, rng=drop.rng(21), row_stats=rst)
+        ops.attn_fwd(desc2)
+        delta = (dOd[:, :Cc] * (out2[:, :Cc] - Rd[:, :Cc])).sum(1).contiguous()
+        dQa = torch.full((M, ld), float("nan"), device="cuda"); dQb = torch.full((M, ld), float("nan"), device="cuda")
+        dK2 = torch.full((M, ld), float("nan"), device="cuda"); dV2 = torch.full((M, ld), float("nan"), device="cuda")
+        ops.attn_bwd(desc2, dOd, ld, dQa, dK2, dV2, ld, stats, delta=delta, dQ_part=dQb)
+        torch.cuda.synchronize()
+        e2 = dict(out=relerr(out2[:, :Cc], ref.detach().numpy().reshape(M, Cc)),
+                  dV=relerr(dV2[:, :Cc], Vt.grad.numpy().reshape(M, Cc)),
+                  dQ=relerr((dQa + dQb)[:, :Cc], Qt.grad.numpy().reshape(M, Cc)),
+                  dK=relerr(dK2[:, :Cc], Kt.grad.numpy().reshape(M, Cc)))
+        print("single-pass errs", e2)
+        assert e2["out"] < 5e-6 and e2["dV"] < 1e-5 and e2["dQ"] < 2e-5 and e2["dK"] < 2e-5, e2
 
 
 def test_attention_dead_rows_and_rejects(ops):
