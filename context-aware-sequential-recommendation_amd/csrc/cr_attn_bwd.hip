@@ -8,12 +8,14 @@
 // flag: 0 = normal row, 1 = uniform row with a non-zero incoming gradient, 2 = contributes nothing.
 template <int NKT, int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_desc bd, AttnGeom g) {
+    constexpr int KPA = 4 * NDS + 2;                     // LDS pitches as compile-time constants: operand offsets fold into
+    constexpr int KPB = 4 * NDS + (((4 * NDS) % 8 == 4) ? 0 : 4);   // the ds_read immediates (the runtime pitch cost a multiply-add per access)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* Ks = smem;                                   // [T16][PA]  A-pattern (scores) and B-pattern (dQ) reads
-    float* Vs = Ks + g.T16 * g.PA + A_TAIL;             // [T16][PA]  A-pattern reads (dP^T)
-    float* kv = Vs + g.T16 * g.PA;
+    float* Vs = Ks + g.T16 * KPA + A_TAIL;             // [T16][PA]  A-pattern reads (dP^T)
+    float* kv = Vs + g.T16 * KPA;
     float* qv = kv + g.T16;
     float* dead = qv + g.T16;
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
     const int t0c = (t0 < T) ? base_row + t0 : base_row;
     const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
     const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
-    stage_pair<NDS>(Ks, g.PA, d.K, d.ld, Vs, g.PA, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
+    stage_pair<NDS>(Ks, KPA, d.K, d.ld, Vs, KPA, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
     if (t0 < g.T16) {
         kv[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;      // additive key bias
         qv[t0] = (t0 < T) ? qv0 : 0.0f;
@@ -110,13 +112,13 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
             const bool c1 = (kt + 1 < NKT) && kt + 1 >= kt_first && kt + 1 <= qt;
             f32x4 acc0 = zero4, acc1 = zero4;
             if (c0 && c1) {
-                mma_tile_frag2<NDS>(Vs + 16 * kt * g.PA, Vs + 16 * (kt + 1) * g.PA, g.PA, dof, dof, acc0, acc1);
+                mma_tile_frag2<NDS>(Vs + 16 * kt * KPA, Vs + 16 * (kt + 1) * KPA, KPA, dof, dof, acc0, acc1);
                 acc0 = dp_finish(kt, acc0);
                 acc1 = dp_finish(kt + 1, acc1);
             } else if (c0) {
-                acc0 = dp_finish(kt, mma_tile_frag<NDS>(Vs + 16 * kt * g.PA, g.PA, dof));
+                acc0 = dp_finish(kt, mma_tile_frag<NDS>(Vs + 16 * kt * KPA, KPA, dof));
             } else if (c1) {
-                acc1 = dp_finish(kt + 1, mma_tile_frag<NDS>(Vs + 16 * (kt + 1) * g.PA, g.PA, dof));
+                acc1 = dp_finish(kt + 1, mma_tile_frag<NDS>(Vs + 16 * (kt + 1) * KPA, KPA, dof));
             }
             dps[kt] = acc0;
             if (kt + 1 < NKT) dps[kt + 1] = acc1;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
         f32x4 acc[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma_prob_rows<NKT, NDT>(st, Ks, g.PA, kt_first, qt + 1, acc);
+        mma_prob_rows<NKT, NDT>(st, Ks, KPA, kt_first, qt + 1, acc);
         if (qi == qi_first) AT_TS(6);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
@@ -157,16 +159,18 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_q(cr_attn_bwd_des
 
 template <int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_desc bd, AttnGeom g) {
+    constexpr int KPA = 4 * NDS + 2;                     // LDS pitches as compile-time constants: operand offsets fold into
+    constexpr int KPB = 4 * NDS + (((4 * NDS) % 8 == 4) ? 0 : 4);   // the ds_read immediates (the runtime pitch cost a multiply-add per access)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* Qs = smem;                                   // [T16][PA]  A- and B-pattern reads
-    float* Os = Qs + g.T16 * g.PA + A_TAIL;             // [T16][PA]  dOut
+    float* Os = Qs + g.T16 * KPA + A_TAIL;             // [T16][PA]  dOut
     // per-row statistics, stored so that the inner loop is branch-free (16-byte reads of 4 consecutive rows):
     //   P[q][key] = valid * exp2(s*c - smx) * sinv + (key < T ? suni : 0)
     // normal row: smx = max, sinv = 1/sum, suni = 0; uniform row: sinv = 0, suni = 1/T; dead row: both 0
     // (smx = +1e30 wherever sinv = 0, so the exponential is exactly 0 instead of a possible inf * 0)
-    float* smx = Os + g.T16 * g.PA + A_TAIL;            // [T16] each
+    float* smx = Os + g.T16 * KPA + A_TAIL;            // [T16] each
     float* sinv = smx + g.T16;
     float* sdel = sinv + g.T16;
     float* sflag = sdel + g.T16;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
     const int t0 = threadIdx.x;
     const f4s st0 = *reinterpret_cast<const f4s*>(bd.stats + ((size_t)blockIdx.x * T + (t0 < T ? t0 : 0)) * 4);
     const float qv0 = d.q_valid[base_row + (t0 < T ? t0 : 0)];
-    stage_pair<NDS>(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
+    stage_pair<NDS>(Qs, KPA, d.Q, d.ld, Os, KPA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
     auto put_stats = [&](int t, float mx_, float inv_, float del_, float flag_, float qv_) {
         const float flag = (t < T) ? flag_ : 2.0f;
         const bool normal = flag == 0.0f;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
             if (tile_live[qt] == 0.0f) continue;                          // nothing flows through dead query tiles
             if ((qt < kt || !tile_has_key) && tile_uni[qt] == 0.0f) continue;   // causal / padding skip (uniform rows see all keys)
             f32x4 s_acc, p_acc;                                                      // S[q][key], dP[q][key]: two interleaved chains
-            mma_tile_frag2<NDS>(Qs + 16 * qt * g.PA, Os + 16 * qt * g.PA, g.PA, kf, vf, s_acc, p_acc);
+            mma_tile_frag2<NDS>(Qs + 16 * qt * KPA, Os + 16 * qt * KPA, KPA, kf, vf, s_acc, p_acc);
             float pa[4], pd[4];
             {
                 const int q4 = 16 * qt + 4 * lg;                                          // this lane's 4 query rows
@@ -271,15 +275,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_kv(cr_attn_bwd_de
                     pd[r] = pn * (p_acc[r] * w - dd[r]) * g.isd;                          // dS / sqrt(d)
                 }
             }
-            const float* op = Os + (16 * qt + 4 * lg) * g.PA + li;
-            const float* qp = Qs + (16 * qt + 4 * lg) * g.PA + li;
+            const float* op = Os + (16 * qt + 4 * lg) * KPA + li;
+            const float* qp = Qs + (16 * qt + 4 * lg) * KPA + li;
             float bo[4][NDT], bq[4][NDT];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int jt = 0; jt < NDT; ++jt) {
-                    bo[r][jt] = op[r * g.PA + 16 * jt];
-                    bq[r][jt] = qp[r * g.PA + 16 * jt];
+                    bo[r][jt] = op[r * KPA + 16 * jt];
+                    bq[r][jt] = qp[r * KPA + 16 * jt];
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r)

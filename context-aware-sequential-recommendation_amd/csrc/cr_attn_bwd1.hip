@@ -23,13 +23,15 @@
 
 template <int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_desc bd, AttnGeom g) {
+    constexpr int KPA = 4 * NDS + 2;                     // LDS pitches as compile-time constants: operand offsets fold into
+    constexpr int KPB = 4 * NDS + (((4 * NDS) % 8 == 4) ? 0 : 4);   // the ds_read immediates (the runtime pitch cost a multiply-add per access)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* Qs = smem;                                   // [T16][PA]  A- and B-pattern reads
-    float* Os = Qs + g.T16 * g.PA + A_TAIL;             // [T16][PA]  dOut
-    float* dQs = Os + g.T16 * g.PA + A_TAIL;            // [T16][PA]  dQ accumulator (this workgroup's key tiles)
-    float* Tw = dQs + g.T16 * g.PA;                     // [nw][16][B1_TP] dS transpose slots
+    float* Os = Qs + g.T16 * KPA + A_TAIL;             // [T16][PA]  dOut
+    float* dQs = Os + g.T16 * KPA + A_TAIL;            // [T16][PA]  dQ accumulator (this workgroup's key tiles)
+    float* Tw = dQs + g.T16 * KPA;                     // [nw][16][B1_TP] dS transpose slots
     float* smx = Tw + nw * 16 * B1_TP + 16;             // per-row statistics, as in the two-pass key-owner kernel
     smx = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(smx) + 15) & ~(uintptr_t)15);
     float* sinv = smx + g.T16;
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
     const f4s st0 = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)blockIdx.x * T + t0c) * 4);
     const float qv0 = d.q_valid[base_row + t0c];
     const float dl0 = bd.delta[base_row + t0c];
-    stage_pair<NDS>(Qs, g.PA, d.Q, d.ld, Os, g.PA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
-    for (int i = threadIdx.x; i < g.T16 * g.PA; i += blockDim.x) dQs[i] = 0.0f;
+    stage_pair<NDS>(Qs, KPA, d.Q, d.ld, Os, KPA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
+    for (int i = threadIdx.x; i < g.T16 * KPA; i += blockDim.x) dQs[i] = 0.0f;
     auto put_stats = [&](int t, float mx_, float inv_, float flag_, float del_, float qv_) {
         const float flag = (t < T) ? flag_ : 2.0f;
         const bool normal = flag == 0.0f;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
             const bool causal_live = have && (qt >= kt) && tile_has_key;             // normal rows of this tile see these keys
             if (have && tile_live[qt] != 0.0f && (causal_live || tile_uni[qt] != 0.0f)) {
             f32x4 s_acc, p_acc;                                                      // S[q][key], dP[q][key]: two interleaved chains
-            mma_tile_frag2<NDS>(Qs + 16 * qt * g.PA, Os + 16 * qt * g.PA, g.PA, kf, vf, s_acc, p_acc);
+            mma_tile_frag2<NDS>(Qs + 16 * qt * KPA, Os + 16 * qt * KPA, KPA, kf, vf, s_acc, p_acc);
             float pa[4], pd[4];
             {
                 const int q4 = 16 * qt + 4 * lg;                                          // this lane's 4 query rows
@@ -160,15 +162,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
             // dS tile -> the wave's transpose slot (row = query, column = key); read back below with the query on li
 #pragma unroll
             for (int r = 0; r < 4; ++r) tw[(4 * lg + r) * B1_TP + li] = pd[r];
-            const float* op = Os + (16 * qt + 4 * lg) * g.PA + li;
-            const float* qp = Qs + (16 * qt + 4 * lg) * g.PA + li;
+            const float* op = Os + (16 * qt + 4 * lg) * KPA + li;
+            const float* qp = Qs + (16 * qt + 4 * lg) * KPA + li;
             float bo[4][NDT], bq[4][NDT];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int jt = 0; jt < NDT; ++jt) {
-                    bo[r][jt] = op[r * g.PA + 16 * jt];
-                    bq[r][jt] = qp[r * g.PA + 16 * jt];
+                    bo[r][jt] = op[r * KPA + 16 * jt];
+                    bq[r][jt] = qp[r * KPA + 16 * jt];
                 }
             float at[4];                                                                  // dS[q = li][key = 4 s + lg]
 #pragma unroll
@@ -188,11 +190,15 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int jt = 0; jt < NDT; ++jt) dq[jt] = mfma16(at[s], kb[s][jt], dq[jt]);
-                float* dqp = dQs + (16 * qt + 4 * lg) * g.PA + li;   // no other wave touches this query tile in this step
+                float* dqp = dQs + (16 * qt + 4 * lg) * KPA + li;   // no other wave touches this query tile in this step
+                // Columns >= 4*NDS of the 16*NDT computed ones are padding (exact zeros) and, the pitch being < 64, would
+                // alias the first columns of the NEXT row: two lanes of one wave would read-add-write the same word in
+                // different instructions, which is only safe if those stay strictly sequential.  Skip them.
 #pragma unroll
                 for (int jt = 0; jt < NDT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dqp[r * g.PA + 16 * jt] += dq[jt][r];
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * jt + li < 4 * NDS) dqp[r * KPA + 16 * jt] += dq[jt][r];
             }
             }
             __syncthreads();
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
     for (int item = threadIdx.x; item < T * NDS; item += blockDim.x) {
         const int r = item / NDS, q = item - r * NDS;
         if (4 * q >= d.d) continue;
-        const float2* pt = reinterpret_cast<const float2*>(dQs + r * g.PA + 4 * q);
+        const float2* pt = reinterpret_cast<const float2*>(dQs + r * KPA + 4 * q);
         const float2 a = pt[0], b = pt[1];
         float* gp = gq + (size_t)(base_row + r) * bd.ldg + hoff + 4 * q;
         if (4 * q + 3 < d.d) {

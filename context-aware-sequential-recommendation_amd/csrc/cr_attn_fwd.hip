@@ -9,11 +9,13 @@ extern "C" void cr_debug_attn_ts(void* p, int which) { g_attn_ts = static_cast<u
 
 template <int NKT, int NDS, int NDT>
 __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, AttnGeom g) {
+    constexpr int KPA = 4 * NDS + 2;                     // LDS pitches as compile-time constants: operand offsets fold into
+    constexpr int KPB = 4 * NDS + (((4 * NDS) % 8 == 4) ? 0 : 4);   // the ds_read immediates (the runtime pitch cost a multiply-add per access)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* Ks = smem;                                   // [T16][PA]  A-pattern reads
-    float* Vs = Ks + g.T16 * g.PA;                      // [T16][PB]  B-pattern reads (+ tail)
-    float* kv = Vs + g.T16 * g.PB + A_TAIL;             // [T16]
+    float* Vs = Ks + g.T16 * KPA;                      // [T16][PB]  B-pattern reads (+ tail)
+    float* kv = Vs + g.T16 * KPB + A_TAIL;             // [T16]
     float* qv = kv + g.T16;                             // [T16]
     float* dead = qv + g.T16;                           // [T16]
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
     const int t0c = (t0 < T) ? base_row + t0 : base_row;
     const float kv0 = d.k_valid[t0c], qv0 = d.q_valid[t0c];
     const int id0 = d.dead_ids ? d.dead_ids[t0c] : 1;
-    stage_pair<NDS>(Ks, g.PA, d.K, d.ld, Vs, g.PB, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
+    stage_pair<NDS>(Ks, KPA, d.K, d.ld, Vs, KPB, d.V, d.ld, base_row, hoff, T, d.d, g.T16);
     if (t0 < g.T16) {
         kv[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;      // additive key bias
         qv[t0] = (t0 < T) ? qv0 : 0.0f;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_fwd(cr_attn_desc d, A
         f32x4 acc[NDT];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma_prob_rows<NKT, NDT>(st, Vs, g.PB, any_uni ? 0 : kt_first, any_uni ? g.nkt : qt + 1, acc);   // modules.py:262
+        mma_prob_rows<NKT, NDT>(st, Vs, KPB, any_uni ? 0 : kt_first, any_uni ? g.nkt : qt + 1, acc);   // modules.py:262
         if (qi == qi_first) AT_TS(6);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
