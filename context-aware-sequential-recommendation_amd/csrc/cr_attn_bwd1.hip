@@ -32,8 +32,8 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
     float* Os = Qs + g.T16 * KPA + A_TAIL;             // [T16][PA]  dOut
     float* dQs = Os + g.T16 * KPA + A_TAIL;            // [T16][PA]  dQ accumulator (this workgroup's key tiles)
     float* Tw = dQs + g.T16 * KPA;                     // [nw][16][B1_TP] dS transpose slots
-    float* smx = Tw + nw * 16 * B1_TP + 16;             // per-row statistics, as in the two-pass key-owner kernel
-    smx = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(smx) + 15) & ~(uintptr_t)15);
+    float* smx = Tw + nw * 16 * B1_TP;                  // per-row statistics, as in the two-pass key-owner kernel (16-byte
+                                                        // aligned: every block above is a multiple of 4 floats)
     float* sinv = smx + g.T16;
     float* sdel = sinv + g.T16;
     float* sflag = sdel + g.T16;
