@@ -106,7 +106,7 @@ def kernel_profile(eng, staged, n_steps=8):
     return per_launch, by_name
 
 
-KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd"], "cr_attn_bwd": ["k_attn_bwd_q", "k_attn_bwd_kv"],
+KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd"], "cr_attn_bwd": ["k_attn_bwd"],
               "cr_layernorm_fwd": ["k_ln_fwd"], "cr_layernorm_bwd": ["k_ln_bwd"], "cr_adam_step": ["k_adam"],
               "cr_head_fwd_bwd": ["k_head"], "cr_embed_fwd": ["k_embed_fwd"], "cr_embed_bwd": ["k_embed_bwd"]}
 
