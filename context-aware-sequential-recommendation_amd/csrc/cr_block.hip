@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         stream_fetch(s2, bd.dqkv + MD + (size_t)mw * D, D, tot);
         stream_fetch(s3, d.x + (size_t)mw * D, D, tot);
     };
+    BK_TSG(gm, 0); BK_TSG(gm, 1);
     if (mb < me) fetch4(mb + 64 * grp);
     put_wt_packed<NT>(Wqt, vq, D, 4 * ks);
     put_wt_packed<NT>(Wkt, vk, D, 4 * ks);
@@ -908,6 +909,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         const int nr = max(0, min(16, me - mw)), tot = nr * D;
         float* tg = TG + 16 * w4 * F3_P; float* ta = TA + 16 * w4 * F3_P; float* tb = TB + 16 * w4 * F3_P;
         if (base != mb) fetch4(m0);
+        if (base == mb) BK_TSG(gm, 2);
         // ---- phase 1: dQ, q_in -> dWq (+ dbq), dq_in = dQ Wq^T
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
         if (bd.dq_part) stream_add(tg, sp, D, tot);                // dQ = the two partial sums of the single-pass attention backward
@@ -915,12 +917,15 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         plant_ones(ta, ones, nr);
         stream_fetch(s0, bd.dqkv + 2 * MD + (size_t)mw * D, D, tot);      // dV and the residual gradient d_o, for later phases
         stream_fetch(s1, bd.d_o + (size_t)mw * D, D, tot);
+        if (base == mb) BK_TSG(gm, 3);
         __syncthreads();
+        if (base == mb) BK_TSG(gm, 4);
         tile_wgrad(awq, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bqs += colsum64(TG, gtid);
         f32x4 acc[4], dxa[4];
         zero_acc(acc); zero_acc(dxa);
         tile_mma<4>(acc, TG, F3_P, Wqt, ks, w4);
+        if (base == mb) BK_TSG(gm, 5);
         __syncthreads();                                           // all rows of TG (dQ) and TA (q_in) have been read
         // ---- phase 2: dK, x -> dWk (+ dbk), dx_part = dK Wk^T
         stream_put(tg, s2, D, tot, gm.invD, PutPlain());
@@ -930,6 +935,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         tile_wgrad(awk, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bks += colsum64(TG, gtid);
         tile_mma<4>(dxa, TG, F3_P, Wkt, ks, w4);
+        if (base == mb) BK_TSG(gm, 6);
         __syncthreads();                                           // all rows of TG (dK) have been read
         // ---- phase 3: dV -> dWv (+ dbv), dx_part += dV Wv^T
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
@@ -937,7 +943,9 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         tile_wgrad(awv, TA, TG, F3_P, w4);
         if (ones < 0 && gtid < 64) bvs += colsum64(TG, gtid);
         tile_mma<4>(dxa, TG, F3_P, Wvt, ks, w4);
+        if (base == mb) BK_TSG(gm, 7);
         __syncthreads();                                           // all rows of TG (dV) and TA (x) have been read
+        if (base == mb) BK_TSG(gm, 8);
         // ---- phase 4 (own rows): dq_in = dQ Wq^T + d_o (modules.py:269); dx = dx_part + LN1bwd(dq_in; x)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -958,7 +966,9 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
             }
             wave_store_rows(gdx, tg, F3_P, D, nr, gm.invD);
         }
+        if (base == mb) BK_TSG(gm, 9);
     }
+    BK_TSG(gm, 15);
     // fold the groups' weight-gradient strips through LDS (group 1's tile area), fixed order, two rounds
     if (NG == 2) {
         __syncthreads();

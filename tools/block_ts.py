@@ -57,4 +57,5 @@ def timeline(entry, desc, nwg, names):
         print("  stamp %2d -> %2d  %-34s median %6.0f ticks (%.2f us)  p90 %6.0f" % (a, b, names.get((a, b), ""), np.median(dlt), np.median(dlt) * 0.46e-3, np.percentile(dlt, 90)))
 
 timeline("cr_block_ln_qkv_fwd", bd, (M + 63) // 64, {(1, 2): "issue loads", (2, 3): "barrier wait", (3, 4): "LN + q_in store", (4, 5): "Q proj + store", (5, 6): "K,V proj + store"})
+timeline("cr_block_ln_qkv_bwd", bb, NS, {(1, 2): "weights + streams issued + weights->LDS", (2, 3): "phase-1 puts", (3, 4): "barrier", (4, 5): "wgrad q + dq_in mma", (5, 6): "barrier + phase 2 (dK, x) puts + wgrad k + mma", (6, 7): "barrier + phase 3 (dV) + wgrad v + mma", (7, 8): "barrier", (8, 9): "phase 4: LN1 bwd + store"})
 timeline("cr_block_ln_ffn_bwd", bb, NS, {(1, 2): "issue weight + stream loads", (2, 3): "weights -> LDS", (3, 4): "mask + zero rows", (4, 5): "put g2", (5, 6): "put hid, f_in", (6, 7): "barrier + wgrad2 + barrier", (7, 8): "dhid + gate + barrier", (8, 9): "wgrad1 + df + barrier", (9, 10): "LN2 bwd + store + barrier"})
