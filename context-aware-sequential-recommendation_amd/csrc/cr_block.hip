@@ -2,15 +2,16 @@
 // attention core): a 64-row tile of activations stays in LDS from LayerNorm through the projections,
 // so each activation is read from HBM/L2 once per phase and ~10 small launches per block disappear.
 //
-// Tile shapes: workgroup = 4 waves = 64 rows (wave w owns rows [16w, 16w+16)), all D (<= 64) columns.
-// MFMA v_mfma_f32_16x16x4_f32.  LDS pitches: row tiles / row-read weights P = 4*ceil(D/4) + 2 (A-pattern
-// conflict-free, % 4 == 2); column-read weights are stored packed (see BK_WROW).  All LDS is dynamic and
-// sized by D, so the forward kernels fit two workgroups per CU.
+// Tile shapes: a group of 4 waves owns a 64-row tile (wave w its rows [16w, 16w+16)), all D (<= 64) columns;
+// the forward kernels run one group per workgroup, the backward kernels two (512 threads, shared weights).
+// MFMA v_mfma_f32_16x16x4_f32.  Row tiles have pitch 66 (all 64 columns are computed and written, pad columns
+// are exact zeros: no per-lane conditions in the element code); weights live in LDS as packed conflict-free
+// images (see BK_WROW), the backward kernels use the packed TRANSPOSED images so g @ W^T is the same MFMA loop.
 //
-// Latency structure (profiles/r01_d_*): forward kernels stage the row tile and ALL their weights with one
-// burst of loads and one barrier -- after it every wave works only on rows it owns.  The persistent backward
-// kernels prefetch the next tile into registers under the MFMAs of the current one, and obtain the bias
-// gradients for free by planting a column of ones in the A-tile of the weight-gradient MFMA (D < 64).
+// Latency structure (profiles/, tools/block_ts.py): forward kernels stage the row tile and ALL their weights with
+// one burst of 16-byte loads and one barrier -- after it every wave works only on rows it owns.  The backward
+// kernels accumulate the weight gradients in MFMA accumulators across tiles and obtain the bias gradients for
+// free by planting a column of ones in the A-tile of the weight-gradient MFMA (D < 64).
 #include <stdlib.h>
 
 #include "cr_common.hpp"
@@ -50,50 +51,6 @@ extern "C" void cr_debug_block_ts(void* p) { g_block_ts = static_cast<unsigned l
 #define BK_TS(slot) do { } while (0)
 static unsigned long long* const g_block_ts = nullptr;
 #endif
-
-// ---- small helpers ---------------------------------------------------------------------------------
-// 16 elements per thread of a [64 x 64] window of a row-major matrix: rows m0 + tr + 4i, column c0 + tc
-__device__ __forceinline__ void fetch_tile(float (&v)[16], const float* src, int ld, int c0, int m0, int m_end, int D) {
-    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = m0 + tr + 4 * i;
-        v[i] = (m < m_end && tc < D) ? src[(size_t)m * ld + c0 + tc] : 0.0f;
-    }
-}
-// ... and their place in a row tile (pitch P); column `ones` of valid rows is set to 1 (bias-gradient trick)
-__device__ __forceinline__ void put_tile(float* dst, const float (&v)[16], int P, int ones, int m0, int m_end) {
-    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63;
-    if (tc < P) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = tr + 4 * i;
-            dst[r * P + tc] = (tc == ones && m0 + r < m_end) ? 1.0f : v[i];
-        }
-    }
-}
-__device__ __forceinline__ void load_tile(float* dst, const float* src, int ld, int c0, int m0, int m_end, int D, int P, int ones) {
-    float v[16];
-    fetch_tile(v, src, ld, c0, m0, m_end, D);
-    put_tile(dst, v, P, ones, m0, m_end);
-}
-
-// weight [K=D rows][N=D cols] (row pitch ldw, column offset c0) -> Ws[k][pitch]; zero padded to 64 x 64.
-// Read by rows (pitch P) it is the B operand of g @ W^T.
-__device__ __forceinline__ void load_w(float* Ws, int pitch, const float* W, int ldw, int c0, int D, int rows = 64) {
-    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = tr + 4 * i;
-        v[i] = (k < D && tc < D) ? W[(size_t)k * ldw + c0 + tc] : 0.0f;
-    }
-    if (tc < pitch) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (tr + 4 * i < rows) Ws[(tr + 4 * i) * pitch + tc] = v[i];
-    }
-}
 
 // Weight [K=D rows][N=D cols] (row pitch ldw, column offset c0) -> packed LDS image of 4*ks k-rows x 64, zero padded.
 // The vector-memory pipe of a CU retires one wave-instruction per ~16 clocks whatever its width (per-wave
@@ -186,22 +143,6 @@ __device__ __forceinline__ void tile_mma(f32x4 (&acc)[4], const float* As, int P
                 for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[s], b[s][j], acc[j]);
             }
         }
-    }
-}
-
-// acc[i][k] (+)= sum_n As[i][n] * Wr[k][n]   (g @ W^T; lanes walk the ROWS k = 16j + li of the staged W)
-__device__ __forceinline__ void tile_mma_t(f32x4 (&acc)[4], const float* As, const float* Wr, int P, int ks, int wave) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const float* ap = As + (16 * wave + li) * P + lg;
-    const float* bp = Wr + li * P + lg;
-#pragma unroll 2
-    for (int kk = 0; kk < ks; ++kk) {
-        const float a = ap[4 * kk];
-        float b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = bp[16 * j * P + 4 * kk];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = mfma16(a, b[j], acc[j]);
     }
 }
 
