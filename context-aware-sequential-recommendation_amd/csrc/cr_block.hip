@@ -63,20 +63,31 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 // NT = threads of the workgroup (256 or 512): 1024 items, 1024 / NT per thread
 template <int NT> struct WFragT { f4u v[1024 / NT]; };
 typedef WFragT<256> WFrag;
-template <int NT>
+// Item <-> (k, q) mapping.  KFAST = false: consecutive lanes take consecutive chunks q of one row (coalesced rows;
+// right for the plain image, whose 16-byte LDS writes then differ in q).  KFAST = true: consecutive lanes take
+// consecutive ROWS k -- what the TRANSPOSED image needs: its element (n, k) lands on LDS bank (k & 15) + 16 (n & 1),
+// so lanes that differ only in q would all hit one bank (16-way conflicts: 2.8 us of LDS time per workgroup at the
+// start of the backward kernels); the loads are 16 bytes from 64 different rows, cheap for an L2-resident 10 KB weight.
+template <bool KFAST>
+__device__ __forceinline__ void w_item(int item, int& k, int& q) {
+    if (KFAST) { k = item & 63; q = item >> 6; } else { k = item >> 4; q = item & 15; }
+}
+template <int NT, bool KFAST = false>
 __device__ __forceinline__ void fetch_w(WFragT<NT>& w, const float* W, int ldw, int c0, int D) {
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
-        const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
+        int k, q;
+        w_item<KFAST>(threadIdx.x + NT * it, k, q);
         const bool valid = (k < D) && (4 * q < D);
         const int col = valid ? min(4 * q, D - 4) : 0;
         w.v[it] = *reinterpret_cast<const f4u*>(W + (size_t)(valid ? k : 0) * ldw + c0 + col);
     }
 }
 // element t of item `it` after the zero padding / back-shift fix-up
-template <int NT>
+template <int NT, bool KFAST = false>
 __device__ __forceinline__ void wfrag_item(const WFragT<NT>& w, int it, int D, float (&e)[4]) {
-    const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
+    int k, q;
+    w_item<KFAST>(threadIdx.x + NT * it, k, q);
     const bool valid = (k < D) && (4 * q < D);
     const int shift = valid ? 4 * q - min(4 * q, D - 4) : 0;
     const float x0 = w.v[it].x, x1 = w.v[it].y, x2 = w.v[it].z, x3 = w.v[it].w;
@@ -100,12 +111,13 @@ __device__ __forceinline__ void put_w_packed(float* Ws, const WFragT<NT>& w, int
     }
 }
 template <int NT>
-__device__ __forceinline__ void put_wt_packed(float* Ws, const WFragT<NT>& w, int D, int nrows) {
+__device__ __forceinline__ void put_wt_packed(float* Ws, const WFragT<NT>& w, int D, int nrows) {     // pair with fetch_w<NT, true>
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
-        const int item = threadIdx.x + NT * it, k = item >> 4, q = item & 15;
+        int k, q;
+        w_item<true>(threadIdx.x + NT * it, k, q);
         float e[4];
-        wfrag_item(w, it, D, e);
+        wfrag_item<NT, true>(w, it, D, e);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             if (4 * q + t < nrows) Ws[bk_waddr(4 * q + t, k)] = e[t];
@@ -631,8 +643,8 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
     // loads first (weights, gamma, the first tile's streams), LDS writes after
     WFragT<NT> vw1, vw2;
-    fetch_w<NT>(vw1, d.w1, D, 0, D);
-    fetch_w<NT>(vw2, d.w2, D, 0, D);
+    fetch_w<NT, true>(vw1, d.w1, D, 0, D);
+    fetch_w<NT, true>(vw2, d.w2, D, 0, D);
     const float gam_v = d.ln2_g[threadIdx.x < D ? threadIdx.x : 0];
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
@@ -820,9 +832,9 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
     const int mb = blockIdx.x * rps, me = min(d.M, mb + rps);
     const size_t MD = (size_t)d.M * D;
     WFragT<NT> vq, vk, vv;
-    fetch_w<NT>(vq, d.wqkv, 3 * D, 0, D);
-    fetch_w<NT>(vk, d.wqkv, 3 * D, D, D);
-    fetch_w<NT>(vv, d.wqkv, 3 * D, 2 * D, D);
+    fetch_w<NT, true>(vq, d.wqkv, 3 * D, 0, D);
+    fetch_w<NT, true>(vk, d.wqkv, 3 * D, D, D);
+    fetch_w<NT, true>(vv, d.wqkv, 3 * D, 2 * D, D);
     const float gam_v = d.ln1_g[threadIdx.x < D ? threadIdx.x : 0];
     f32x4 awq[4], awk[4], awv[4];
     zero_acc(awq); zero_acc(awk); zero_acc(awv);
