@@ -97,6 +97,20 @@ class _Model(object):
         if "M" in d and self._train is not None:
             self._train.Mom.copy_(d["M"]); self._train.Vel.copy_(d["V"]); self._train.state.copy_(d["state"])
 
+    def load_tf_checkpoint(self, prefix):
+        """Loads a checkpoint written by the reference (tf.train.Saver bundle `<prefix>.index` +
+        `<prefix>.data-00000-of-00001`, main.py:231-233 there); optimiser slots are ignored."""
+        from . import tf_bundle
+        params = tf_bundle.load_logical(prefix)
+        want = {n: tuple(self._owner.layout.view(self._owner.P, n).shape) for n in self._owner.layout.logical_names()}
+        missing, extra = sorted(set(want) - set(params)), sorted(set(params) - set(want))
+        if missing or extra:
+            raise ValueError("checkpoint %s does not match model %s: missing %s, unexpected %s" % (prefix, self.name, missing, extra))
+        for n, shp in want.items():
+            if tuple(params[n].shape) != shp:
+                raise ValueError("checkpoint %s: %s has shape %s, model expects %s" % (prefix, n, params[n].shape, shp))
+        self._owner.load_params(params)
+
     def get_params(self):
         return self._owner.get_params()
 

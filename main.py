@@ -90,8 +90,11 @@ def main(argv=None):
 
     if args.test_model:                                            # main.py:161-189
         ck = os.path.join(args.test_model, 'model.ckpt')
-        if os.path.exists(ck):
-            model.load(ck)
+        if os.path.exists(ck) or os.path.exists(ck + '.index'):
+            if os.path.exists(ck + '.index'):
+                model.load_tf_checkpoint(ck)                            # a run directory written by the reference (TF bundle)
+            else:
+                model.load(ck)
             print('loaded saved model {}'.format(args.test_model))
             u, seq, pos, neg, timeseq, ratings_seq, hours_seq, days_seq, _ = sampler.next_batch()
             auc, loss = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq)   # the reference's one-train-step quirk

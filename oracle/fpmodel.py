@@ -379,20 +379,27 @@ def to_batch(seq, pos, neg, time=None, hours=None, days=None, test_item=None):
     return b
 
 
-# logical name -> TF variable name in the reference's checkpoints
+# logical name -> TF variable name in the reference's checkpoints (pinned by tests/test_tf_bundle.py against the
+# bundle index files of the reference's own saved models, tests/golden/tf_index)
 def tf_name(name):
     scope = {"trunk": "SASRec/num_blocks_%d", "ctx_time": "CONTEXT/timeseq_num_blocks_%d"}
     fixed = {"item_emb": "SASRec/input_embeddings/lookup_table", "pos_emb": "SASRec/dec_pos/lookup_table",
-             "time_emb": "CONTEXT/time_embeddings/lookup_table", "trunk.lnf.beta": "SASRec/ln/Variable",
-             "trunk.lnf.gamma": "SASRec/ln/Variable_1"}
+             "time_emb": "CONTEXT/time_embeddings/lookup_table",
+             "hours_emb": "INPUT-CONTEXT/hours_embeddings/lookup_table", "days_emb": "INPUT-CONTEXT/days_embeddings/lookup_table",
+             "trunk.lnf.beta": "SASRec/ln/Variable", "trunk.lnf.gamma": "SASRec/ln/Variable_1",
+             "ctx_time.lnf.beta": "CONTEXT/ln/Variable", "ctx_time.lnf.gamma": "CONTEXT/ln/Variable_1",
+             "mlp.w1": "SASRec/MLP/dense/kernel", "mlp.b1": "SASRec/MLP/dense/bias",
+             "mlp.w2": "SASRec/MLP/dense_1/kernel", "mlp.b2": "SASRec/MLP/dense_1/bias"}
     if name in fixed:
         return fixed[name]
     parts = name.split(".")
     if parts[0] in scope and parts[1].isdigit():
         base = scope[parts[0]] % int(parts[1])
         leaf = ".".join(parts[2:])
-        m = {"ln1.beta": "ln/Variable", "ln1.gamma": "ln/Variable_1", "ln2.beta": "ln_1/Variable",
-             "ln2.gamma": "ln_1/Variable_1", "wq": "self_attention/dense/kernel", "bq": "self_attention/dense/bias",
+        # the context blocks create one extra, unused LayerNorm pair first (`ln`, cast_1.py:45): theirs are ln_1 / ln_2
+        l1, l2 = ("ln_1", "ln_2") if parts[0] == "ctx_time" else ("ln", "ln_1")
+        m = {"ln1.beta": l1 + "/Variable", "ln1.gamma": l1 + "/Variable_1", "ln2.beta": l2 + "/Variable",
+             "ln2.gamma": l2 + "/Variable_1", "wq": "self_attention/dense/kernel", "bq": "self_attention/dense/bias",
              "wk": "self_attention/dense_1/kernel", "bk": "self_attention/dense_1/bias",
              "wv": "self_attention/dense_2/kernel", "bv": "self_attention/dense_2/bias",
              "w1": "multihead_attention/conv1d/kernel", "b1": "multihead_attention/conv1d/bias",

@@ -222,3 +222,44 @@ def test_graph_replay_equals_eager(E):
     torch.cuda.synchronize()
     la, lb = a.loss_auc(), b.loss_auc()
     assert la[0] == pytest.approx(lb[0], rel=1e-3) and int(b.state[4:5].view(torch.int32)[0]) == 4
+
+
+def test_trained_reference_weights_at_the_headline_shape(E):
+    """The TRAINED variables of the reference's cast_1 ml-1m run (tests/golden/cast_1_ml1m_weights.npz, extracted
+    from its TensorFlow checkpoint by castrec_amd/tf_bundle.py): eval logits, loss and every gradient against the
+    oracle at T=200, D=50, one head -- the bench workload's exact shape, with real weight statistics."""
+    import os
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cast_1_ml1m_weights.npz"))
+    rs = np.random.RandomState(11)
+    B, T, D, H, itemnum, max_bins = 6, 200, 50, 1, 3416, 200
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=max_bins, seed=5)
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=max_bins)
+    P = {k: torch.tensor(w[k]) for k in w.files}
+    seq = rs.randint(1, itemnum + 1, (B, T)); pos = rs.randint(1, itemnum + 1, (B, T)); neg = rs.randint(1, itemnum + 1, (B, T))
+    for b, n in enumerate([0, 3, 60, 150, 190, 199]):                    # ragged left padding, one nearly empty sequence
+        seq[b, :n] = 0; pos[b, :n] = 0; neg[b, :n] = 0
+    time = np.minimum(rs.randint(0, 40, (B, T)).cumsum(1)[:, ::-1] // 8, max_bins) * (seq != 0)   # non-increasing bins, last = 0
+    zeros = np.zeros_like(seq)
+    # inference graph
+    ev = E.Engine("cast_1", 6040, itemnum, hp, B, training=False)
+    ev.load_params(P)
+    Pd = {k: v.double().cpu() for k, v in ev.get_params().items()}
+    cand = rs.randint(1, itemnum + 1, 101)
+    out = fm.forward("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros, test_item=cand), drop=None)
+    ev.forward_eval(seq, time, zeros, zeros)
+    lg = ev.test_logits(torch.tensor(np.tile(cand, (B, 1)).astype(np.int32)).cuda())
+    torch.cuda.synchronize()
+    assert rel(lg, out["test_logits"]) < 1e-4                          # north-star bound: 1e-3
+    # training step with dropout (oracle fed with the engine's masks): loss and every gradient
+    eng = E.Engine("cast_1", 6040, itemnum, hp, B, training=True, n_slabs=5)
+    eng.load_params(P)
+    o2, G = fm.loss_and_grads("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros), oracle_drop(E, 5, 1, 0.2, B, T, H))
+    eng.set_batch(seq, pos, neg, time, zeros, zeros)
+    eng.launch_step(apply=False)
+    torch.cuda.synchronize()
+    st = eng.state.cpu().numpy()
+    assert st[0] / st[2] == pytest.approx(float(o2["loss"]), rel=2e-5)
+    got = eng.grads()
+    gmax = max(float(G[k].abs().max()) for k in G)
+    worst = max((float((got[k].cpu().double() - G[k]).abs().max()) / max(float(G[k].abs().max()), 1e-3 * gmax), k) for k in G)
+    assert worst[0] < 2e-4, worst

@@ -1,0 +1,82 @@
+"""Reader for the reference's saved checkpoints (castrec_amd/tf_bundle.py) against the bundle index files of the
+eight model classes the reference ships (tests/golden/tf_index, copied by tests/golden/make_tf_fixtures.py)."""
+import importlib.util
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import fpmodel as fm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location(
+    "tf_bundle", os.path.join(os.path.dirname(HERE), "context-aware-sequential-recommendation_amd", "tf_bundle.py"))
+tfb = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(tfb)                      # plain numpy module: no GPU library needed
+
+MODELS = ["sasrec", "sasrec_static"] + ["cast_%d" % i for i in range(1, 7)]
+SIZES = json.load(open(os.path.join(HERE, "golden", "ckpt_sizes.json")))
+
+
+def _hp():
+    return fm.Hyper(maxlen=SIZES["maxlen"], hidden_units=SIZES["hidden_units"], num_blocks=SIZES["num_blocks"], num_heads=1,
+                    dropout_rate=0.2, max_bins=SIZES["max_bins"])
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_index_matches_parameter_inventory(model):
+    idx = tfb.read_index(os.path.join(HERE, "golden", "tf_index", model + ".index"))
+    # the data file is exactly the concatenation the index describes (sizes pinned in ckpt_sizes.json)
+    assert max(e["offset"] + e["size"] for e in idx.values()) == SIZES["sizes"][model]
+    got, unused = {}, []
+    for name, e in idx.items():
+        ln = tfb.logical_name(name)
+        if ln is None:
+            if "Adam" not in name and name not in ("beta1_power", "beta2_power", "global_step"):
+                unused.append(name)
+            continue
+        shape = tuple(e["shape"][1:] if len(e["shape"]) == 3 and e["shape"][0] == 1 else e["shape"])
+        assert ln not in got
+        got[ln] = shape
+    want = {n: tuple(s) for n, s, _ in fm.param_spec(model, SIZES["usernum"], SIZES["itemnum"], _hp())}
+    assert got == want
+    # the only variables neither trained nor mapped: the LayerNorm pair cast_N creates per context block and never uses
+    assert all("timeseq_num_blocks" in n and "/ln/" in n for n in unused)
+    assert sum(int(np.prod(idx[n]["shape"])) for n in unused) == (SIZES["untrained_ln_floats_cast"] if model.startswith("cast") else 0)
+    # the oracle's own logical -> reference-name table is the inverse of the importer's
+    for n in want:
+        assert fm.tf_name(n) in idx and tfb.logical_name(fm.tf_name(n)) == n
+    # every trained variable carries two Adam slots
+    trained = [n for n in idx if tfb.logical_name(n) is not None]
+    assert all(n + "/Adam" in idx and n + "/Adam_1" in idx for n in trained)
+
+
+def test_load_reads_tensors_at_their_offsets(tmp_path):
+    src = os.path.join(HERE, "golden", "tf_index", "cast_1.index")
+    idx = tfb.read_index(src)
+    total = max(e["offset"] + e["size"] for e in idx.values())
+    raw = np.arange(total // 4, dtype="<f4")                       # float k sits at byte offset 4k
+    prefix = str(tmp_path / "model.ckpt")
+    shutil.copyfile(src, prefix + ".index")
+    raw.tofile(prefix + ".data-00000-of-00001")
+    t = tfb.load(prefix)
+    for name, e in idx.items():
+        if e["dtype"] != 1:
+            continue
+        a = t[name]
+        assert list(a.shape) == e["shape"]
+        assert a.reshape(-1)[0] == e["offset"] // 4 and (a.size == 0 or a.reshape(-1)[-1] == e["offset"] // 4 + a.size - 1)
+    logical = tfb.to_logical(t)
+    assert logical["trunk.0.w1"].shape == (50, 50) and logical["item_emb"].shape == (3417, 50)
+    with pytest.raises(KeyError):
+        tfb.logical_name("SASRec/num_blocks_0/unknown/kernel")
+
+
+def test_trained_weight_fixture_is_consistent():
+    w = np.load(os.path.join(HERE, "golden", "cast_1_ml1m_weights.npz"))
+    want = {n: tuple(s) for n, s, _ in fm.param_spec("cast_1", SIZES["usernum"], SIZES["itemnum"], _hp())}
+    assert {k: w[k].shape for k in w.files} == want
+    # trained: LayerNorm offsets have left zero (the initial-point mask degeneracy of DESIGN.md section 2 is gone)
+    assert float(np.abs(w["trunk.0.ln1.beta"]).max()) > 1e-3
