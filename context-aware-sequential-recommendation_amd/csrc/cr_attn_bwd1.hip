@@ -15,7 +15,9 @@
 // the walk is ROTATED instead: in step j the wave that owns key tile kt works on query tile (kt + j) mod nkt, and
 // a workgroup barrier closes every step.  Distinct key tiles meet distinct query tiles in every step, so the
 // accumulation is a plain LDS read-add-write with a fixed order (bitwise reproducible), at the price of nkt
-// barriers per round.  When a sample is split over two workgroups (gridDim.y = 2) each holds a partial dQ:
+// barriers per round.  The start of each key tile's walk (AttnGeom.rot, chosen on the host) is shifted so that the
+// two waves sharing a SIMD have their causally live steps at different times (a light tile's few live steps fit
+// into the heavy tile's dead ones): every step then costs one pair, not two.  When a sample is split over two workgroups (gridDim.y = 2) each holds a partial dQ:
 // workgroup 0 writes `dQ`, workgroup 1 writes `dQ_part`, the caller adds.
 #include "cr_attn_common.hpp"
 
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
         }
 #pragma unroll 1
         for (int step = 0; step < g.nkt; ++step) {
-            int qt = (have ? kt : 0) + step;                                         // rotated walk: see the header
+            int qt = (have ? g.rot[kt] : 0) + step;                                  // rotated walk: see the header
             if (qt >= g.nkt) qt -= g.nkt;
             const bool causal_live = have && (qt >= kt) && tile_has_key;             // normal rows of this tile see these keys
             if (have && tile_live[qt] != 0.0f && (causal_live || tile_uni[qt] != 0.0f)) {
@@ -258,14 +260,58 @@ static int launch_bwd_one(const cr_attn_bwd_desc* bd, const AttnGeom& g, int wav
     return cr_check_launch("cr_attn_bwd(single pass)");
 }
 
+// Rotation starts.  Key tile kt is causally live on query tiles kt .. nkt-1; walking from start o it is live in the
+// cyclic step window [kt - o, nkt - o).  Per workgroup and round: starts must be distinct (that is what makes the LDS
+// accumulation conflict-free) and the windows of the two tiles on one SIMD should not overlap.  Small backtracking
+// search (<= 8 tiles); if no perfect assignment exists (e.g. tile 0 shares a SIMD), keep the plain start o = kt.
+static bool rot_search(int i, int n, const int* kt, const int* simd, int nkt, int* off, unsigned* used, unsigned* busy) {
+    if (i == n) return true;
+    const int L = nkt - kt[i];
+    for (int j0 = 0; j0 < nkt; ++j0) {
+        const int o = ((kt[i] - j0) % nkt + nkt) % nkt;
+        if (*used & (1u << o)) continue;
+        unsigned win = 0;
+        for (int s = 0; s < L; ++s) win |= 1u << ((j0 + s) % nkt);
+        if (busy[simd[i]] & win) continue;
+        *used |= 1u << o; busy[simd[i]] |= win; off[kt[i]] = o;
+        if (rot_search(i + 1, n, kt, simd, nkt, off, used, busy)) return true;
+        *used &= ~(1u << o); busy[simd[i]] &= ~win;
+    }
+    return false;
+}
+
+static void rot_table(AttnGeom* g, int nw, int nsplit) {
+    for (int k = 0; k < 16; ++k) g->rot[k] = k;
+    const int R = nw >= 2 ? 2 : 1, half = nw / R, P = nsplit * half;
+    const int nrounds = (g->nkt + nsplit * nw - 1) / (nsplit * nw);
+    for (int y = 0; y < nsplit; ++y)
+        for (int round = 0; round < nrounds; ++round) {
+            int kt[16], simd[16], n = 0;
+            for (int w = 0; w < nw; ++w) {                        // mirrors sched_init / sched_rank_at on the device
+                const int p = (w % half) * nsplit + y, r = w / half + R * round;
+                const int rank = r * P + ((r & 1) ? P - 1 - p : p);
+                if (rank < g->nkt) { kt[n] = rank; simd[n] = w % half; ++n; }
+            }
+            for (int a = 0; a < n; ++a)                           // heaviest (smallest kt) first
+                for (int b = a + 1; b < n; ++b)
+                    if (kt[b] < kt[a]) { int t = kt[a]; kt[a] = kt[b]; kt[b] = t; t = simd[a]; simd[a] = simd[b]; simd[b] = t; }
+            int off[16];
+            unsigned used = 0, busy[16] = {0};
+            if (rot_search(0, n, kt, simd, g->nkt, off, &used, busy))
+                for (int a = 0; a < n; ++a) g->rot[kt[a]] = off[kt[a]];
+        }
+}
+
 // returns 1 if the single-pass kernel was launched, 0 if the shape does not fit it (caller falls back), < 0 on error
-int cr_attn_bwd_single_pass(const cr_attn_bwd_desc* bd, const AttnGeom& g, hipStream_t s) {
+int cr_attn_bwd_single_pass(const cr_attn_bwd_desc* bd, const AttnGeom& g0, hipStream_t s) {
     const cr_attn_desc* d = &bd->f;
     if (d->H != 1) return 0;                            // dQ partial layout assumes one head per row block
+    AttnGeom g = g0;
     const int waves = attn_pick_waves(g, lds_bwd_one);
     if (waves < A_MAX_WAVES) return 0;                  // LDS-resident dQ tile does not fit next to Q and dOut
     int nsplit = attn_nsplit(d, g, waves);
     if (nsplit > 2) nsplit = 2;
+    rot_table(&g, waves, nsplit);
     int rc;
     if (g.nds == 8) rc = launch_bwd_one<8, 2>(bd, g, waves, nsplit, s);
     else if (g.nds == 13) rc = launch_bwd_one<13, 4>(bd, g, waves, nsplit, s);

@@ -37,6 +37,7 @@ struct AttnGeom {
     float isd;               // 1/sqrt(d)   (modules.py:219)
     float isd_log2e;         // isd * log2(e): softmax exponent in base 2 (v_exp_f32)
     float invT;
+    int rot[16];             // single-pass backward: query tile at which key tile kt starts its rotated walk
     unsigned long long* ts;  // debug: per-wave phase stamps [waves][16] (tools/attn_ts.py); NULL in production
 };
 #ifdef CR_TIMELINE
