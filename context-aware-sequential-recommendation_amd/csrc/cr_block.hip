@@ -329,133 +329,17 @@ __device__ __forceinline__ void ln_rows(const float* Xs, float* Ys, int P, const
 }
 
 
-// ---- F3: LN2 + point-wise feed-forward + residual + mask -----------------------------------------------
-// Pad-tolerant, branch-free element code: tiles have pitch 66 and ALL 64 columns are computed and written to
-// LDS unconditionally -- weights, biases and inputs are zero beyond D, so pad columns come out as exact zeros
-// (relu(0) = 0, dropout(0) = 0) without a single per-lane condition.  Global traffic goes through the
-// wave-contiguous row streams, which know the valid row count.
-__device__ __forceinline__ void ln_rows_fast(const float* Xs, float* Ys, const float* gam, const float* bet, int D, int wave) {
-    // LayerNorm (modules.py:74-78) of the wave's 16 rows; gam/bet are zero-padded LDS arrays of 64 floats
-    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-    const float invD = 1.0f / (float)D;
-    float g[4], b[4], in[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { g[i] = gam[l + 16 * i]; b[i] = bet[l + 16 * i]; in[i] = (l + 16 * i < D) ? 1.0f : 0.0f; }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = 16 * wave + 4 * p + sub;
-        float x[4], s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = Xs[r * F3_P + l + 16 * i]; s += x[i]; }        // pad columns hold 0
-        const float mean = sum16(s) * invD;
-        float v = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = (x[i] - mean) * in[i]; v += x[i] * x[i]; }
-        const float rs = 1.0f / sqrtf(sum16(v) * invD + 1e-8f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Ys[r * F3_P + l + 16 * i] = g[i] * (x[i] * rs) + b[i];  // pad: 0*.. + 0 = 0
-    }
-}
-
-__global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, BlockGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int D = d.D;
-    float* Os = smem;                       // [64][66] input tile, reused for the hidden tile and the output tile
-    float* Fs = Os + 64 * F3_P;             // [64][66]
-    float* W1s = Fs + 64 * F3_P;            // packed [4*ks][64]
-    float* W2s = W1s + 4 * g.ks * BK_WROW;  // packed [4*ks][64]
-    float* vec = W2s + 4 * g.ks * BK_WROW;  // 4 x [64]: gamma2, beta2, b1, b2 (zero padded)
-    float* msk = vec + 256;                 // [64] row mask (sasrec.py:83)
-    float* Hs = Os;
-    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);   // step counter load: requested first, needed late
-    const int m0 = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int mw = m0 + 16 * wave;                                  // first row of this wave
-    const int nr = max(0, min(16, d.M - mw));                       // its valid rows
-    wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
-    {
-        WFrag wa, wb;
-        fetch_w(wa, d.w1, D, 0, D);
-        fetch_w(wb, d.w2, D, 0, D);
-        put_w_packed(W1s, wa, D, 4 * g.ks);
-        put_w_packed(W2s, wb, D, 4 * g.ks);
-    }
-    {
-        const int t = threadIdx.x, c = t & 63, which = t >> 6;
-        const float* src = which == 0 ? d.ln2_g : (which == 1 ? d.ln2_b : (which == 2 ? d.b1 : d.b2));
-        vec[t] = (c < D) ? src[c] : 0.0f;
-        if (t < 64) msk[t] = (m0 + t < d.M && d.mask_ids[m0 + t] != 0) ? 1.0f : 0.0f;
-    }
-    __syncthreads();                        // the only barrier
-    ln_rows_fast(Os, Fs, vec, vec + 64, D, wave);                                           // sasrec.py:81
-    if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
-    // per-lane hashing bases: idx = (row_offset + m) * D + col
-    uint32_t rb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rb[r] = (d.drop_ffn1.row_offset + (uint32_t)(mw + 4 * lg + r)) * (uint32_t)D + (uint32_t)li;
-    f32x4 acc[4];
-    zero_acc(acc);
-    tile_mma(acc, Fs, F3_P, W1s, g.ks, wave);                                               // modules.py:300-302
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float bias = vec[128 + 16 * j + li];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(acc[j][r] + bias, 0.0f);
-            if (d1.on) v *= drop_factor_x(d1, rb[r] * CR_PHI + d1.key + (16u * j) * CR_PHI);   // modules.py:303-304
-            Hs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = v;
-        }
-    }
-    if (nr > 0) wave_store_rows(d.hid + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
-    zero_acc(acc);
-    tile_mma(acc, Hs, F3_P, W2s, g.ks, wave);                                               // modules.py:306-308
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float bias = vec[192 + 16 * j + li];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + 4 * lg + r;
-            float v = acc[j][r] + bias;
-            if (d2.on) v *= drop_factor_x(d2, rb[r] * CR_PHI + d2.key + (16u * j) * CR_PHI);   // modules.py:309-310
-            v = (v + Fs[row * F3_P + 16 * j + li]) * msk[row];                               // modules.py:313, sasrec.py:83
-            Hs[row * F3_P + 16 * j + li] = v;              // the MFMAs above have consumed the wave's Hs rows
-        }
-    }
-    if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
-}
-
 // ---- F1: LN1 + Q/K/V projections --------------------------------------------------------------------
 // Q, K, V are stored as three dense [M, D] matrices ([3, M, D]) so each wave's 16 output rows of each are one
-// contiguous block.
-__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// contiguous block.  f1_body is everything after the staging barrier: Xs holds the block input rows, Ws the three
+// packed weights, vec = gamma1 | beta1 | bq | bk | bv (zero padded); every wave works only on the rows it owns.
+__device__ __forceinline__ void f1_body(const cr_block_desc& d, const BlockGeom& g, float* Xs, float* Qs, const float* Ws,
+                                        const float* vec, int m0) {
     const int D = d.D;
-    float* Xs = smem;                       // [64][66]
-    float* Qs = Xs + 64 * F3_P;             // [64][66] LN1 output, then staging of each projection's result
-    float* Ws = Qs + 64 * F3_P;             // 3 x packed [4*ks][64]: Wq, Wk, Wv
     const int wsz = 4 * g.ks * BK_WROW;
-    float* vec = Ws + 3 * wsz;              // 5 x [64]: gamma1, beta1, bq, bk, bv (zero padded)
-    const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;
     const int nr = max(0, min(16, d.M - mw));
-    BK_TS(0); BK_TS(1);
-    wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
-    {
-        WFrag w3[3];
-#pragma unroll
-        for (int part = 0; part < 3; ++part) fetch_w(w3[part], d.wqkv, 3 * D, part * D, D);
-#pragma unroll
-        for (int part = 0; part < 3; ++part) put_w_packed(Ws + part * wsz, w3[part], D, 4 * g.ks);
-    }
-    for (int t = threadIdx.x; t < 320; t += 256) {
-        const int c = t & 63, which = t >> 6;
-        const float* src = which == 0 ? d.ln1_g : (which == 1 ? d.ln1_b : d.bqkv + (which - 2) * D);
-        vec[t] = (c < D) ? src[c] : 0.0f;
-    }
-    BK_TS(2);
-    __syncthreads();                        // the only barrier
-    BK_TS(3);
     // LN1 with the data-dependent key / query masks (modules.py:222,248-249)
     {
         const int l = lane & 15, sub = lane >> 4;
@@ -501,7 +385,207 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
         if (nr > 0) wave_store_rows(d.qkv + ((size_t)part * d.M + mw) * D, Qs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
         if (part == 0) BK_TS(5);
     }
+}
+
+// gamma1 | beta1 | bq | bk | bv of a block, two values per thread (320 = 5 x 64 slots)
+__device__ __forceinline__ void f1_fetch_vec(const cr_block_desc& d, float (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u, c = t & 63, which = (t >> 6) % 5;
+        const float* src = which == 0 ? d.ln1_g : (which == 1 ? d.ln1_b : d.bqkv + (which - 2) * d.D);
+        v[u] = src[c < d.D ? c : 0];
+    }
+}
+__device__ __forceinline__ void f1_put_vec(float* vec, const float (&v)[2], int D) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        if (t < 320) vec[t] = ((t & 63) < D) ? v[u] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = d.D;
+    float* Xs = smem;                       // [64][66]
+    float* Qs = Xs + 64 * F3_P;             // [64][66] LN1 output, then staging of each projection's result
+    float* Ws = Qs + 64 * F3_P;             // 3 x packed [4*ks][64]: Wq, Wk, Wv
+    const int wsz = 4 * g.ks * BK_WROW;
+    float* vec = Ws + 3 * wsz;              // 5 x [64]: gamma1, beta1, bq, bk, bv (zero padded)
+    const int m0 = blockIdx.x * 64;
+    const int wave = threadIdx.x >> 6;
+    const int mw = m0 + 16 * wave;
+    const int nr = max(0, min(16, d.M - mw));
+    BK_TS(0); BK_TS(1);
+    wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
+    {
+        WFrag w3[3];
+        float vv[2];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fetch_w(w3[part], d.wqkv, 3 * D, part * D, D);
+        f1_fetch_vec(d, vv);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) put_w_packed(Ws + part * wsz, w3[part], D, 4 * g.ks);
+        f1_put_vec(vec, vv, D);
+    }
+    BK_TS(2);
+    __syncthreads();                        // the only barrier
+    BK_TS(3);
+    f1_body(d, g, Xs, Qs, Ws, vec, m0);
     BK_TS(6); BK_TS(15);
+}
+
+// ---- F3: LN2 + point-wise feed-forward + residual + mask -----------------------------------------------
+// Pad-tolerant, branch-free element code: tiles have pitch 66 and ALL 64 columns are computed and written to
+// LDS unconditionally -- weights, biases and inputs are zero beyond D, so pad columns come out as exact zeros
+// (relu(0) = 0, dropout(0) = 0) without a single per-lane condition.  Global traffic goes through the
+// wave-contiguous row streams, which know the valid row count.
+__device__ __forceinline__ void ln_rows_fast(const float* Xs, float* Ys, const float* gam, const float* bet, int D, int wave) {
+    // LayerNorm (modules.py:74-78) of the wave's 16 rows; gam/bet are zero-padded LDS arrays of 64 floats
+    const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
+    const float invD = 1.0f / (float)D;
+    float g[4], b[4], in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] = gam[l + 16 * i]; b[i] = bet[l + 16 * i]; in[i] = (l + 16 * i < D) ? 1.0f : 0.0f; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = 16 * wave + 4 * p + sub;
+        float x[4], s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = Xs[r * F3_P + l + 16 * i]; s += x[i]; }        // pad columns hold 0
+        const float mean = sum16(s) * invD;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = (x[i] - mean) * in[i]; v += x[i] * x[i]; }
+        const float rs = 1.0f / sqrtf(sum16(v) * invD + 1e-8f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ys[r * F3_P + l + 16 * i] = g[i] * (x[i] * rs) + b[i];  // pad: 0*.. + 0 = 0
+    }
+}
+
+// TAIL = 0: plain.  TAIL = 1: the NEXT block's LN1 + Q/K/V projections run on the output rows while they are still
+// in LDS (one launch, one staging and one round trip of y less per block boundary).  TAIL = 2: the stack's final
+// LayerNorm (sasrec.py:85) is applied to the output rows and written to `out` (a column block of a [M, ld] buffer).
+struct BlockTail {
+    cr_block_desc next;                     // TAIL 1
+    const float* lnf_g; const float* lnf_b; float* out; int ld_out, col_out;   // TAIL 2
+};
+__device__ __forceinline__ void f3_dummy() {}
+template <int TAIL>
+__global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, BlockGeom g, BlockTail tl) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = d.D;
+    const int wsz = 4 * g.ks * BK_WROW;
+    float* Os = smem;                       // [64][66] input tile, reused for the hidden tile and the output tile
+    float* Fs = Os + 64 * F3_P;             // [64][66]
+    float* W1s = Fs + 64 * F3_P;            // packed [4*ks][64]
+    float* W2s = W1s + wsz;                 // packed [4*ks][64]   (TAIL 1: a third slot follows for Wq|Wk|Wv)
+    float* vec = W2s + (TAIL == 1 ? 2 : 1) * wsz;   // 5 x [64]: gamma2, beta2, b1, b2 (zero padded) -- later the next block's vectors
+    float* msk = vec + 320;                 // [64] row mask (sasrec.py:83)
+    float* Hs = Os;
+    const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);   // step counter load: requested first, needed late
+    const int m0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int mw = m0 + 16 * wave;                                  // first row of this wave
+    const int nr = max(0, min(16, d.M - mw));                       // its valid rows
+    wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
+    {
+        WFrag wa, wb;
+        fetch_w(wa, d.w1, D, 0, D);
+        fetch_w(wb, d.w2, D, 0, D);
+        put_w_packed(W1s, wa, D, 4 * g.ks);
+        put_w_packed(W2s, wb, D, 4 * g.ks);
+    }
+    {
+        const int t = threadIdx.x, c = t & 63, which = t >> 6;
+        const float* src = which == 0 ? d.ln2_g : (which == 1 ? d.ln2_b : (which == 2 ? d.b1 : d.b2));
+        vec[t] = (c < D) ? src[c] : 0.0f;
+        if (t < 64) msk[t] = (m0 + t < d.M && d.mask_ids[m0 + t] != 0) ? 1.0f : 0.0f;
+    }
+    float lng[4], lnb[4];                                           // TAIL 2: final LayerNorm gamma / beta of this lane's columns
+    if (TAIL == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = li + 16 * i;
+            lng[i] = tl.lnf_g[c < D ? c : 0];
+            lnb[i] = tl.lnf_b[c < D ? c : 0];
+        }
+    }
+    __syncthreads();
+    ln_rows_fast(Os, Fs, vec, vec + 64, D, wave);                                           // sasrec.py:81
+    if (nr > 0) wave_store_rows(d.f_in + (size_t)mw * D, Fs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    // per-lane hashing bases: idx = (row_offset + m) * D + col
+    uint32_t rb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r] = (d.drop_ffn1.row_offset + (uint32_t)(mw + 4 * lg + r)) * (uint32_t)D + (uint32_t)li;
+    f32x4 acc[4];
+    zero_acc(acc);
+    tile_mma(acc, Fs, F3_P, W1s, g.ks, wave);                                               // modules.py:300-302
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float bias = vec[128 + 16 * j + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = fmaxf(acc[j][r] + bias, 0.0f);
+            if (d1.on) v *= drop_factor_x(d1, rb[r] * CR_PHI + d1.key + (16u * j) * CR_PHI);   // modules.py:303-304
+            Hs[(16 * wave + 4 * lg + r) * F3_P + 16 * j + li] = v;
+        }
+    }
+    if (nr > 0) wave_store_rows(d.hid + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    // TAIL 1: the next block's weights and vectors are requested now and fly under the second GEMM and its epilogue
+    WFrag nw3[3];
+    float nvv[2];
+    if (TAIL == 1) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fetch_w(nw3[part], tl.next.wqkv, 3 * D, part * D, D);
+        f1_fetch_vec(tl.next, nvv);
+    }
+    zero_acc(acc);
+    tile_mma(acc, Hs, F3_P, W2s, g.ks, wave);                                               // modules.py:306-308
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float bias = vec[192 + 16 * j + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + 4 * lg + r;
+            float v = acc[j][r] + bias;
+            if (d2.on) v *= drop_factor_x(d2, rb[r] * CR_PHI + d2.key + (16u * j) * CR_PHI);   // modules.py:309-310
+            v = (v + Fs[row * F3_P + 16 * j + li]) * msk[row];                               // modules.py:313, sasrec.py:83
+            Hs[row * F3_P + 16 * j + li] = v;              // the MFMAs above have consumed the wave's Hs rows
+        }
+    }
+    if (nr > 0) wave_store_rows(d.y + (size_t)mw * D, Hs + 16 * wave * F3_P, F3_P, D, nr, g.invD);
+    if (TAIL == 1) {
+        __syncthreads();                                            // every wave is done with W1 / W2 / vec
+#pragma unroll
+        for (int part = 0; part < 3; ++part) put_w_packed(W1s + part * wsz, nw3[part], D, 4 * g.ks);
+        f1_put_vec(vec, nvv, D);
+        __syncthreads();
+        f1_body(tl.next, g, Hs, Fs, W1s, vec, m0);                  // y rows (masked) are the next block's x
+    }
+    if (TAIL == 2) {
+        // final LayerNorm of the stack on the wave's own output rows -> Fs -> out[:, col_out : col_out + D]
+        const int l = lane & 15, sub = lane >> 4;
+        const float invD = 1.0f / (float)D;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 16 * wave + 4 * p + sub;
+            float x[4], sm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = Hs[r * F3_P + l + 16 * i]; sm += x[i]; }
+            const float mean = sum16(sm) * invD;
+            float v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = (l + 16 * i < D) ? x[i] - mean : 0.0f; v += x[i] * x[i]; }
+            const float sd = sqrtf(sum16(v) * invD + 1e-8f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = l + 16 * i;
+                if (c < D && 4 * p + sub < nr)
+                    tl.out[(size_t)(mw + 4 * p + sub) * tl.ld_out + tl.col_out + c] = lng[i] * (x[i] / sd) + lnb[i];
+            }
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1019,18 +1103,50 @@ extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
     return cr_check_launch("cr_block_ln_qkv_fwd");
 }
 
-extern "C" int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream) {
+static int block_ffn_fwd_launch(const cr_block_desc* d, const cr_block_tail_desc* t, void* stream, const char* who) {
     BlockGeom g;
-    int rc = block_check(d, &g, "cr_block_ln_ffn_fwd");
+    int rc = block_check(d, &g, who);
     if (rc) return rc;
     CR_REQUIRE(d->o && d->f_in && d->hid && d->y && d->mask_ids && d->ln2_g && d->ln2_b && d->w1 && d->b1 && d->w2 && d->b2,
-               "cr_block_ln_ffn_fwd: NULL pointer");
-    static bool attr = false;
-    rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd), &attr);
-    if (rc) return rc;
-    const size_t lds = sizeof(float) * (2 * 64 * F3_P + 2 * 4 * g.ks * BK_WROW + 256 + 64);
-    hipLaunchKernelGGL(k_block_ln_ffn_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
-    return cr_check_launch("cr_block_ln_ffn_fwd");
+               "%s: NULL pointer", who);
+    BlockTail tl = {};
+    const int kind = t ? t->kind : 0;
+    CR_REQUIRE(kind >= 0 && kind <= 2, "%s: tail kind %d", who, kind);
+    if (kind == 1) {
+        CR_REQUIRE(t->next != nullptr, "%s: tail 1 needs the next block's description", who);
+        const cr_block_desc* n = t->next;
+        CR_REQUIRE(n->M == d->M && n->D == d->D, "%s: next block has a different shape", who);
+        CR_REQUIRE(n->x == d->y, "%s: the next block's input must be this block's output", who);
+        CR_REQUIRE(n->q_in && n->qkv && n->k_valid && n->q_valid && n->ln1_g && n->ln1_b && n->wqkv && n->bqkv, "%s: next block: NULL pointer", who);
+        tl.next = *n;
+    } else if (kind == 2) {
+        CR_REQUIRE(t->lnf_gamma && t->lnf_beta && t->out && t->ld_out >= t->col_out + d->D, "%s: tail 2: bad final-LayerNorm output", who);
+        tl.lnf_g = t->lnf_gamma; tl.lnf_b = t->lnf_beta; tl.out = t->out; tl.ld_out = t->ld_out; tl.col_out = t->col_out;
+    }
+    const size_t lds = sizeof(float) * (2 * 64 * F3_P + (kind == 1 ? 3 : 2) * 4 * g.ks * BK_WROW + 320 + 64);
+    static bool attr[3] = {false, false, false};
+    if (kind == 0) {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<0>), &attr[0]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_ffn_fwd<0>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
+    } else if (kind == 1) {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<1>), &attr[1]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_ffn_fwd<1>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
+    } else {
+        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<2>), &attr[2]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_ffn_fwd<2>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
+    }
+    return cr_check_launch(who);
+}
+
+extern "C" int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream) {
+    return block_ffn_fwd_launch(d, nullptr, stream, "cr_block_ln_ffn_fwd");
+}
+
+extern "C" int cr_block_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t, void* stream) {
+    return block_ffn_fwd_launch(d, t, stream, "cr_block_ln_ffn_fwd_tail");
 }
 
 extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {

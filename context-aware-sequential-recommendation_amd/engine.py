@@ -174,6 +174,7 @@ class Engine:
         self.training = training
         # fused row-phase kernels (cr_block_*) need the hidden size to fit one 64-column tile
         self.single_pass_bwd = os.environ.get("CASTREC_TWO_PASS_ATTN_BWD") != "1"
+        self.fuse_tails = os.environ.get("CASTREC_NO_TAILS") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -293,13 +294,15 @@ class Engine:
             self._bufs[key] = torch.zeros_like(t)
         return self._bufs[key]
 
-    def op_layernorm(self, x, y, y_ld, y_col, pname, flags=None):
-        """modules.py:53-80.  y may be a column block of a wider (concat) buffer."""
+    def op_layernorm(self, x, y, y_ld, y_col, pname, flags=None, skip_fwd=False):
+        """modules.py:53-80.  y may be a column block of a wider (concat) buffer.  skip_fwd: the forward ran as the
+        tail of the producing FFN kernel; only the backward is registered here."""
         M, D = self.M, self.D
         yptr = y.data_ptr() + 4 * y_col
         d = L.LnDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), self._pptr(pname + ".beta"), yptr, y_ld, M, D, 1e-8,
                      flags[0].data_ptr() if flags else None, flags[1].data_ptr() if flags else None)
-        self._call(self.fwd, "cr_layernorm_fwd", C.byref(d))
+        if not skip_fwd:
+            self._call(self.fwd, "cr_layernorm_fwd", C.byref(d))
         if not self.training:
             return
 
@@ -367,8 +370,10 @@ class Engine:
             return lst
         self._bwd_factories.append(factory)
 
-    def op_block(self, x, y, pfx, attn_out=None):
-        """One transformer block (sasrec.py:65-83): y = mask * FFN(LN2(MHA(LN1(x), x)))."""
+    def op_block(self, x, y, pfx, attn_out=None, skip_qkv=False, tail=None):
+        """One transformer block (sasrec.py:65-83): y = mask * FFN(LN2(MHA(LN1(x), x))).
+        Fused path only: `skip_qkv` = the LN1 + QKV phase was run as the tail of the previous block's FFN kernel;
+        `tail` = ("next", next block's prefix, its output buffer) or ("lnf", param prefix, out, ld, col)."""
         M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
         d_head = D // H
         q_in, o, f_in, hid = (self.buf(pfx + n, D) for n in ("q_in", "o", "f_in", "hid"))
@@ -377,7 +382,7 @@ class Engine:
         ids = self.ids["seq"]
         wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
         if self.fused:
-            return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid)
+            return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv, tail)
         # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
         ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
                        1e-8, kvalid.data_ptr(), qvalid.data_ptr())
@@ -463,17 +468,27 @@ class Engine:
             return lst
         self._bwd_factories.append(factory)
 
-    def _op_block_fused(self, x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid):
-        """Same block through the fused row-phase kernels (cr_block_*): 3 launches forward, 4 backward."""
+    def _block_desc(self, x, y, pfx):
+        """cr_block_desc of the block with parameter prefix `pfx` (buffers are created on first use, by name)."""
+        M, D = self.M, self.D
+        q_in, o, f_in, hid = (self.buf(pfx + n, D) for n in ("q_in", "o", "f_in", "hid"))
+        qkv = self.buf(pfx + "qkv", D, rows=3 * M)
+        kvalid, qvalid = self.vec(pfx + "kvalid"), self.vec(pfx + "qvalid")
+        P = self._pptr
+        return L.BlockDesc(M, D, P(pfx + "ln1.gamma"), P(pfx + "ln1.beta"), P(pfx + "wqkv"), P(pfx + "bqkv"),
+                           P(pfx + "ln2.gamma"), P(pfx + "ln2.beta"), P(pfx + "w1"), P(pfx + "b1"), P(pfx + "w2"), P(pfx + "b2"),
+                           x.data_ptr(), q_in.data_ptr(), qkv.data_ptr(), kvalid.data_ptr(), qvalid.data_ptr(), o.data_ptr(),
+                           f_in.data_ptr(), hid.data_ptr(), y.data_ptr(), self.ids["seq"].data_ptr(),
+                           self.rng(pfx[:-1] + ".ffn1"), self.rng(pfx[:-1] + ".ffn2"))
+
+    def _op_block_fused(self, x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv=False, tail=None):
+        """Same block through the fused row-phase kernels (cr_block_*): 3 launches forward, 3 backward; with tails
+        (the next block's LN1 + QKV, or the stack's final LayerNorm, inside the FFN kernel) 2 forward."""
         M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
         ids = self.ids["seq"]
-        P = self._pptr
-        bd = L.BlockDesc(M, D, P(pfx + "ln1.gamma"), P(pfx + "ln1.beta"), P(pfx + "wqkv"), P(pfx + "bqkv"),
-                         P(pfx + "ln2.gamma"), P(pfx + "ln2.beta"), P(pfx + "w1"), P(pfx + "b1"), P(pfx + "w2"), P(pfx + "b2"),
-                         x.data_ptr(), q_in.data_ptr(), qkv.data_ptr(), kvalid.data_ptr(), qvalid.data_ptr(), o.data_ptr(),
-                         f_in.data_ptr(), hid.data_ptr(), y.data_ptr(), ids.data_ptr(),
-                         self.rng(pfx[:-1] + ".ffn1"), self.rng(pfx[:-1] + ".ffn2"))
-        self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
+        bd = self._block_desc(x, y, pfx)
+        if not skip_qkv:
+            self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
         MD4 = 4 * M * D
         ad = O.attn_desc(qkv, None, None, D, kvalid, qvalid, q_in, D, o, D, B, T, H, D // H,
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
@@ -486,7 +501,17 @@ class Engine:
             row_stats = self.vec(pfx + "row_stats", H * B * T * 4)
             ad.row_stats = row_stats.data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
-        self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
+        if tail is None:
+            self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
+        elif tail[0] == "next":
+            nbd = self._block_desc(y, tail[2], tail[1])
+            td = L.BlockTailDesc(1, C.pointer(nbd), None, None, None, 0, 0)
+            self._keep.append(nbd)
+            self._call(self.fwd, "cr_block_ln_ffn_fwd_tail", C.byref(bd), C.byref(td))
+        else:
+            _, pname, out, out_ld, out_col = tail
+            td = L.BlockTailDesc(2, None, self._pptr(pname + ".gamma"), self._pptr(pname + ".beta"), out.data_ptr(), out_ld, out_col)
+            self._call(self.fwd, "cr_block_ln_ffn_fwd_tail", C.byref(bd), C.byref(td))
         if not self.training:
             return
 
@@ -515,17 +540,23 @@ class Engine:
         self._bwd_factories.append(factory)
 
     def op_stack(self, x, prefix, nblocks, out, out_ld, out_col, want_attn=False):
-        """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns."""
+        """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns.
+        Fused path: block i+1's LN1 + QKV phase and the final LayerNorm run as tails of the FFN kernels."""
+        tails = self.fused and self.fuse_tails and nblocks > 0
+        ys = [self.buf("%s.%d.y" % (prefix, i), self.D) for i in range(nblocks)]
         cur = x
         for i in range(nblocks):
-            nxt = self.buf("%s.%d.y" % (prefix, i), self.D)
+            nxt = ys[i]
             aw = None
             if want_attn and i == nblocks - 1:
                 self.attn_weights = torch.zeros(self.H * self.B, self.T, self.T, dtype=torch.float32, device=self.dev)
                 aw = self.attn_weights
-            self.op_block(cur, nxt, "%s.%d." % (prefix, i), attn_out=aw)
+            tail = None
+            if tails:
+                tail = ("next", "%s.%d." % (prefix, i + 1), ys[i + 1]) if i + 1 < nblocks else ("lnf", prefix + ".lnf", out, out_ld, out_col)
+            self.op_block(cur, nxt, "%s.%d." % (prefix, i), attn_out=aw, skip_qkv=tails and i > 0, tail=tail)
             cur = nxt
-        self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf")
+        self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf", skip_fwd=tails)
 
     def op_head(self, seq_emb):
         """sasrec.py:87-115 (+ unnormalised gradients) / test_logits sasrec.py:93-97."""

@@ -236,6 +236,17 @@ typedef struct {
 int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream);
 int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream);
 
+/* cr_block_ln_ffn_fwd with a tail stage applied to the output rows while they are still on chip:
+ *   kind 1: the NEXT block's cr_block_ln_qkv_fwd (next->x must be this block's y) -- one launch per block boundary less;
+ *   kind 2: the stack's final LayerNorm (sasrec.py:85): out[:, col_out : col_out + D] = LN(y; lnf_gamma, lnf_beta).
+ * y is written in both cases (the backward needs it); results are identical to the separate calls. */
+typedef struct {
+    int kind;                                  /* 0 none, 1 next block's LN1 + QKV, 2 final LayerNorm */
+    const cr_block_desc* next;                 /* kind 1 */
+    const float* lnf_gamma; const float* lnf_beta; float* out; int ld_out, col_out;   /* kind 2 */
+} cr_block_tail_desc;
+int cr_block_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t, void* stream);
+
 typedef struct {
     cr_block_desc f;
     const float* dy;                           /* gradient of y [M,D] */
