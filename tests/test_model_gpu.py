@@ -151,6 +151,18 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
                                            ("sasrec", 256, 4, 300, 1),    # config 5 shape class (D=256, maxlen > 256) -> general attention
                                            ("cast_1", 128, 1, 20, 1)])    # head dim 128 > 64 -> general attention
 def test_other_baseline_shapes_match_oracle(E, model, D, H, T, L):
+    _other_shapes(E, model, D, H, T, L)
+
+
+@pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD"])
+def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
+    """The plain FFN forward entry (no tail) and the two-pass attention backward at one head: the engine's default
+    path no longer uses them, the C ABI still offers them."""
+    monkeypatch.setenv(env, "1")
+    _other_shapes(E, "cast_1", 50, 1, 40, 2)
+
+
+def _other_shapes(E, model, D, H, T, L):
     rs = np.random.RandomState(D + T)
     B, itemnum, max_bins = 3, 41, 9
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
