@@ -58,14 +58,28 @@ def get_delta_range(User):
 
 
 def get_users(fpath):
-    """util.py:163-182: 4-column ``user item rating ts`` text, time-sorted per user."""
+    """util.py:163-182: 4-column ``user item rating ts`` text, time-sorted per user.
+
+    Also reads the original SASRec format the reference ships (`data/Video.txt`, parsed by
+    `baselines/SASRec/util.py:16-27`): 2 columns ``user item`` (or 3: ``user item ts``), events in order.  Those files carry
+    no ratings and (2 columns) no time: rating 0 and one synthetic day per event from a fixed origin are filled in, so
+    the context-free models run on them unchanged and the context models see a regular cadence."""
     usernum = itemnum = 0
     ratingnum = 0
     User = {}
+    origin = 956_700_000                                  # first ml-1m timestamp, any fixed origin will do
     with open(fpath, "r") as f:
         for line in f:
-            u, i, r, t = line.rstrip().split(" ")
-            u, i, r, t = int(u), int(i), float(r), int(t)
+            parts = line.rstrip().split(" ")
+            if len(parts) == 4:
+                u, i, r, t = int(parts[0]), int(parts[1]), float(parts[2]), int(parts[3])
+            elif len(parts) == 3:
+                u, i, r, t = int(parts[0]), int(parts[1]), 0.0, int(float(parts[2]))
+            elif len(parts) == 2:
+                u, i, r = int(parts[0]), int(parts[1]), 0.0
+                t = origin + 86400 * len(User.get(u, ()))
+            else:
+                raise ValueError("%s: expected 2, 3 or 4 space-separated columns, got %r" % (fpath, line))
             usernum, itemnum, ratingnum = max(u, usernum), max(i, itemnum), max(r, ratingnum)
             User.setdefault(u, []).append((i, r, t))
     return User, usernum, itemnum, ratingnum

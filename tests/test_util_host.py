@@ -65,3 +65,20 @@ def test_batched_evaluate_reproduces_reference_inputs_and_metrics():
                 np.testing.assert_array_equal(got, want, err_msg=key + "/" + nm)
             allc = np.stack([cl[5] for cl in fmk.calls]).astype(np.int64)
             assert int((allc * (np.arange(101) + 1)).sum()) == int(z[key + "/cand_checksum"])
+
+
+def test_reads_the_two_column_sasrec_format(tmp_path):
+    """`data/Video.txt` of the reference (baselines/SASRec/util.py:16-27): ``user item`` per line."""
+    from castrec_amd import util as U
+    f = tmp_path / "video.txt"
+    f.write_text("1 5\n1 7\n1 9\n1 2\n2 4\n2 5\n3 1\n3 2\n3 3\n")
+    train, valid, test, usernum, itemnum, ratingnum = U.data_partition(str(f))
+    assert (usernum, itemnum) == (3, 9)
+    assert [e[0] for e in train[1]] == [5, 7] and valid[1][0][0] == 9 and test[1][0][0] == 2
+    assert train[2] and valid[2] == [] and test[2] == []                   # fewer than 3 events: all train
+    ts = [e[2] for e in train[1] + valid[1] + test[1]]
+    assert ts == sorted(ts) and ts[1] - ts[0] == 86400                      # synthetic cadence: one day per event
+    g = tmp_path / "three.txt"
+    g.write_text("1 5 100\n1 6 200\n1 7 300\n")
+    tr, va, te, *_ = U.data_partition(str(g))
+    assert tr[1][0][2] == 100 and te[1][0][2] == 300
