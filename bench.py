@@ -68,7 +68,10 @@ def algo_work(name, fnargs, eng):
 
 
 def kernel_profile(eng, staged, n_steps=8):
-    """Eager steps with a HIP event pair around every launch (events on the launch stream)."""
+    """Eager steps with a HIP event pair around every launch (events on the launch stream).  Each step starts
+    with a ~0.5 ms device-side sleep so the host runs ahead of the GPU: every launch is already queued when the
+    GPU reaches its start event, and an event pair brackets kernel execution, not host launch latency (without
+    it the pairs read ~5 us long against rocprofv3's kernel durations)."""
     evs = []
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
@@ -76,6 +79,7 @@ def kernel_profile(eng, staged, n_steps=8):
     eng.Gflat.zero_()
     for it in range(n_steps + 2):
         eng.ids_all.copy_(staged[it % staged.shape[0]])
+        torch.cuda._sleep(1_000_000)
         rec = []
         for name, fn, a in prog:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
