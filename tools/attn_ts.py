@@ -48,6 +48,12 @@ def timeline(which, title, names):
     print("==", title, " waves", len(t), " span %.1f us" % (end.max() / 1e3))
     print("wave start ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(start, [10, 50, 90, 100])))
     print("wave life  ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(end - start, [10, 50, 90, 100])))
+    if os.environ.get("HEAVY") == "1":                  # only the waves that own the heaviest tile (wave 0 of workgroup y = 0)
+        idx = np.arange(len(live))[live]
+        nw_ = 8
+        sel = ((idx % nw_) == 0) & ((idx // nw_) < B * H)
+        t = t[sel]
+        print("   heaviest-tile waves:", len(t))
     used = [i for i in range(1, 15) if (t[:, i] > 0).mean() > 0.3]
     for a, b in zip(used[:-1], used[1:]):
         ok = (t[:, a] > 0) & (t[:, b] > 0)
