@@ -9,8 +9,12 @@ Evaluation is batched (the reference runs one B=1 session call per user) but dra
 of every user from the SAME global numpy stream in the SAME order, so candidate sets -- and therefore
 the metrics for given weights -- are identical to the reference's.
 """
+import base64
 import math
+import os
 import random
+import struct
+import zlib
 
 import numpy as np
 import torch
@@ -22,6 +26,38 @@ def _ev(e):
     if isinstance(e, (tuple, list)):
         return e[0], e[1], e[2]
     return e.item, e.rating, e.timestamp_raw
+
+
+def plot_attention_weights(attention_weights, path):
+    """util.py:46-54: heat map of a [T, T] attention matrix saved as ``<path>/attention_weights.svg`` ('hot' colour
+    map over the matrix's own min..max, nearest-neighbour cells, title "Attention weights").  Written directly (an
+    RGB PNG embedded in an SVG) so the evaluation path needs no plotting library."""
+    a = np.asarray(attention_weights, np.float64)
+    if a.ndim != 2:
+        raise ValueError("attention_weights must be a [T, T] matrix, got shape %s" % (a.shape,))
+    lo, hi = float(a.min()), float(a.max())
+    x = (a - lo) / (hi - lo) if hi > lo else np.zeros_like(a)
+    k1, k2 = 0.365079, 0.746032                             # breakpoints of the 'hot' map: black-red-yellow-white
+    rgb = np.stack([np.clip(x / k1, 0, 1), np.clip((x - k1) / (k2 - k1), 0, 1), np.clip((x - k2) / (1 - k2), 0, 1)], -1)
+    px = np.rint(rgb * 255).astype(np.uint8)
+    h, w = a.shape
+    raw = b"".join(b"\x00" + px[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+    side, top = 600, 40
+    svg = ('<svg xmlns="http://www.w3.org/2000/svg" xmlns:xlink="http://www.w3.org/1999/xlink" width="%d" height="%d">'
+           '<rect width="100%%" height="100%%" fill="white"/>'
+           '<text x="%d" y="26" font-family="sans-serif" font-size="18" text-anchor="middle">Attention weights</text>'
+           '<image x="20" y="%d" width="%d" height="%d" preserveAspectRatio="none" style="image-rendering:pixelated" '
+           'xlink:href="data:image/png;base64,%s"/></svg>\n'
+           % (side + 40, side + top + 20, (side + 40) // 2, top, side, side, base64.b64encode(png).decode()))
+    out = os.path.join(path, "attention_weights.svg")
+    with open(out, "w") as f:
+        f.write(svg)
+    return out
 
 
 def hour_of(ts):
@@ -178,7 +214,9 @@ def _evaluate(model, dataset, args, mode, eval_batch=256):
             n_attn += a.shape[0]
     n = float(len(rows))
     if attn_sum is not None and mode == "test":
-        np.save(__import__("os").path.join(args.test_model, "attention_weights.npy"), attn_sum / max(n_attn, 1))  # util.py:334-336
+        avg = attn_sum / max(n_attn, 1)                                                 # util.py:334-336
+        np.save(os.path.join(args.test_model, "attention_weights.npy"), avg)
+        plot_attention_weights(avg, args.test_model)
     return NDCG / n, HT / n
 
 

@@ -68,6 +68,7 @@ def test_main_cli_trains_evaluates_and_writes_reference_artifacts(tmp_path, monk
     rc = cli.main(["--dataset", "synthetic:tiny", "--train_dir", "t", "--model", "cast_3", "--maxlen", "12", "--batch_size", "4",
                    "--hidden_units", "16", "--max_bins", "20", "--test_model", str(d), "--test_seq_len", "5"])
     assert rc == 0 and (d / "test_seq_len.txt").read_text().startswith("5,")
+    assert (d / "attention_weights.svg").exists() and (d / "attention_weights.npy").exists()     # util.py:334-336
 
 
 def test_dp_replica_single_rank_equals_plain_step():

@@ -82,3 +82,25 @@ def test_reads_the_two_column_sasrec_format(tmp_path):
     g.write_text("1 5 100\n1 6 200\n1 7 300\n")
     tr, va, te, *_ = U.data_partition(str(g))
     assert tr[1][0][2] == 100 and te[1][0][2] == 300
+
+
+def test_attention_heat_map_svg_round_trips(tmp_path):
+    """plot_attention_weights (util.py:46-54): file name, and the embedded PNG decodes to the 'hot' colours of the matrix."""
+    import base64, re, struct, zlib
+    a = np.tril(np.arange(36, dtype=np.float64).reshape(6, 6))
+    out = U.plot_attention_weights(a, str(tmp_path))
+    assert out.endswith("attention_weights.svg")
+    svg = open(out).read()
+    assert "Attention weights" in svg
+    png = base64.b64decode(re.search(r"base64,([A-Za-z0-9+/=]+)", svg).group(1))
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h = struct.unpack(">II", png[16:24])
+    assert (w, h) == (6, 6)
+    i = png.index(b"IDAT")
+    n = struct.unpack(">I", png[i - 4:i])[0]
+    rows = zlib.decompress(png[i + 4:i + 4 + n])
+    px = np.frombuffer(rows, np.uint8).reshape(6, 1 + 18)[:, 1:].reshape(6, 6, 3)
+    assert tuple(px[0, 5]) == (0, 0, 0) and tuple(px[5, 5]) == (255, 255, 255)      # min -> black, max -> white
+    assert px[3, 0, 0] == 255 and 0 < px[3, 0, 1] < 255 and px[3, 0, 2] == 0         # 18/35 = .51: red full, green partial
+    with pytest.raises(ValueError):
+        U.plot_attention_weights(np.zeros((2, 3, 3)), str(tmp_path))
