@@ -765,7 +765,7 @@ class Engine:
 
     def load_params(self, d):
         for n in self.layout.logical_names():
-            self.layout.view(self.P, n).copy_(torch.as_tensor(np.asarray(d[n]), dtype=torch.float32).to(self.dev))
+            self.layout.view(self.P, n).copy_(torch.tensor(np.asarray(d[n]), dtype=torch.float32).to(self.dev))
 
     def grads(self):
         """Normalised gradients by logical name, valid after launch_step(apply=False)."""

@@ -154,6 +154,23 @@ def test_other_baseline_shapes_match_oracle(E, model, D, H, T, L):
     _other_shapes(E, model, D, H, T, L)
 
 
+@pytest.mark.parametrize("model,D,H,T,L,B", [("sasrec", 4, 1, 19, 1, 3),      # smallest hidden size the fused kernels take
+                                             ("cast_1", 5, 1, 33, 2, 3),      # the 4-column chunk that crosses column D is rotated
+                                             ("sasrec", 12, 3, 21, 1, 5),     # head dim 4
+                                             ("cast_3", 13, 1, 24, 1, 3),
+                                             ("cast_1", 33, 1, 50, 1, 2),
+                                             ("sasrec", 47, 1, 70, 2, 2),
+                                             ("cast_8", 63, 3, 31, 1, 3),     # head dim 21, odd everything
+                                             ("sasrec", 60, 4, 129, 1, 2),    # head dim 15, T = 8*16 + 1
+                                             ("cast_1", 64, 1, 255, 1, 1),    # upper edge of the LDS-resident envelope
+                                             ("sasrec", 6, 3, 17, 1, 2),      # head dim 2 < 4 -> general attention under fused blocks
+                                             ("sasrec", 66, 1, 18, 1, 2)])    # first hidden size past the fused kernels
+def test_awkward_hidden_sizes_and_row_counts(E, model, D, H, T, L, B):
+    """Hidden sizes that are not multiples of 4 or 16, row counts B*T that are not multiples of the 16-row strips /
+    64-row tiles, single-sequence batches: every tail path of the staging, MFMA and store code."""
+    _other_shapes(E, model, D, H, T, L, B)
+
+
 @pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD"])
 def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     """The plain FFN forward entry (no tail) and the two-pass attention backward at one head: the engine's default
@@ -162,9 +179,9 @@ def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     _other_shapes(E, "cast_1", 50, 1, 40, 2)
 
 
-def _other_shapes(E, model, D, H, T, L):
+def _other_shapes(E, model, D, H, T, L, B=3):
     rs = np.random.RandomState(D + T)
-    B, itemnum, max_bins = 3, 41, 9
+    itemnum, max_bins = 41, 9
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
                  num_context_blocks=1, lr=1e-3, seed=11)
     ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
