@@ -46,7 +46,8 @@ __device__ __forceinline__ float slab_sum64(const float* slabs, int n_slabs, int
 __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
     __shared__ float part[16][64];
     const uint32_t t = *reinterpret_cast<const uint32_t*>(d.state + 4);
-    const float n = d.state[2];
+    const float* st = d.stats ? d.stats : d.state;
+    const float n = st[2];
     const float inv_n = n > 0.0f ? 1.0f / n : 0.0f;
     const float b1t = powf(d.beta1, (float)t), b2t = powf(d.beta2, (float)t);
     const float lr_t = d.lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.state[5] = n > 0.0f ? d.state[0] / n : 0.0f;   // loss  (sasrec.py:105-108)
-        d.state[6] = n > 0.0f ? d.state[1] / n : 0.0f;   // auc   (sasrec.py:113-115)
+        d.state[5] = n > 0.0f ? st[0] / n : 0.0f;        // loss  (sasrec.py:105-108)
+        d.state[6] = n > 0.0f ? st[1] / n : 0.0f;        // auc   (sasrec.py:113-115)
     }
 }
 

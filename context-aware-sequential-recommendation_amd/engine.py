@@ -673,7 +673,7 @@ class Engine:
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
-                             1e-8, self.state.data_ptr())
+                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total)
             self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
             self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
                             (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,
@@ -717,8 +717,7 @@ class Engine:
         self._run([self._reduce], s)
 
     def launch_adam_from_flat(self):
-        """Adam on the (all-reduced) flat bucket; the global loss statistics come from its tail."""
-        self.state[:3].copy_(self.Gflat[self.layout.n_total:self.layout.n_total + 3])
+        """Adam on the (all-reduced) flat bucket; the global loss statistics are read from its tail."""
         self._run([self._adam_flat], torch.cuda.current_stream().cuda_stream)
 
     def capture(self, dp=False):

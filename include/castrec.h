@@ -284,7 +284,8 @@ int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32
  * g = grad * (1 / n_target); table part: grad = table_grad[i] (zeroed after use);
  * dense part: grad = sum_s dense_slabs[s*n_dense + i].  lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
  * p -= lr_t*m/(sqrt(v)+eps), t = step counter in state[4].  Also writes state[5] = loss,
- * state[6] = auc. */
+ * state[6] = auc.  {loss_sum, auc_sum, n_target} are read from `stats` when it is non-NULL (the
+ * all-reduced tail of the data-parallel bucket, see cr_reduce_slabs), from state[0..2] otherwise. */
 typedef struct {
     float* p; float* m; float* v;     /* flat [n_table + n_dense] */
     float* table_grad;                /* [n_table] */
@@ -292,6 +293,7 @@ typedef struct {
     int n_table, n_dense, n_slabs;
     float lr, beta1, beta2, eps;
     float* state;
+    const float* stats;               /* optional [3] */
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 

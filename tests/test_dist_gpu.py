@@ -73,7 +73,7 @@ def _worker(rank, world, port, q):
     for s in range(STEPS):
         dp.step(make_batch(s))
     torch.cuda.synchronize()
-    q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, eng.state[:3].cpu().numpy()))
+    q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, eng.Gflat[eng.layout.n_total:eng.layout.n_total + 3].cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 

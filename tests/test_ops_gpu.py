@@ -370,7 +370,10 @@ def test_head_fwd_bwd_and_test_logits(ops):
     assert relerr(lg, np.einsum("bd,bjd->bj", last, tzn[cand.astype(np.int64)])) < 2e-6
 
 
-def test_adam_tf_three_steps_with_slabs(ops):
+@pytest.mark.parametrize("external_stats", [False, True])
+def test_adam_tf_three_steps_with_slabs(ops, external_stats):
+    """external_stats: {loss_sum, auc_sum, n_target} come from a separate buffer (the all-reduced bucket tail of the
+    data-parallel path) while state[0..2] hold this rank's local values, which must then be ignored."""
     from oracle import fpmodel as fm
     rs = np.random.RandomState(12)
     nt, nd, ns = 300, 130, 6
@@ -384,10 +387,14 @@ def test_adam_tf_three_steps_with_slabs(ops):
         g = rs.standard_normal(nt + nd); n_target = float(rs.randint(5, 50))
         ops.step_begin(state)
         state[0] = 3.5 * n_target; state[1] = 0.25 * n_target; state[2] = n_target
+        stats = None
+        if external_stats:
+            stats = state[:3].clone()
+            state[0] = -1.0; state[1] = -2.0; state[2] = 1.0
         tg.copy_(dev(g[:nt] * n_target))                            # un-normalised gradients
         parts = rs.dirichlet(np.ones(ns), nd).T * (g[nt:] * n_target)[None]
         slabs.copy_(dev(parts))
-        ops.adam_step(p, m, v, tg, slabs, nt, nd, ns, 1e-3, state)
+        ops.adam_step(p, m, v, tg, slabs, nt, nd, ns, 1e-3, state, stats=stats)
         torch.cuda.synchronize()
         P = opt.step(P, {"w": torch.tensor(g)})
         assert relerr(p, P["w"].numpy()) < 1e-6
