@@ -319,11 +319,10 @@ static size_t lds_bwd_kv(const AttnGeom& g, int w) {
 
 template <int NKT, int NDS, int NDT>
 static int launch_bwd_q(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_bwd_q<NKT, NDS, NDT>));
+    static cr_devmask attr_set = 0;
+    {
+        int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_attn_bwd_q<NKT, NDS, NDT>), &attr_set);
         if (rc) return rc;
-        attr_set = true;
     }
     AttnGeom gg = g;
     if (g_attn_ts_which != 1) gg.ts = nullptr;
@@ -341,11 +340,10 @@ static int dispatch_bwd_q(const cr_attn_bwd_desc* bd, const AttnGeom& g, int wav
 
 template <int NDS, int NDT>
 static int launch_bwd_kv(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_bwd_kv<NDS, NDT>));
+    static cr_devmask attr_set = 0;
+    {
+        int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_attn_bwd_kv<NDS, NDT>), &attr_set);
         if (rc) return rc;
-        attr_set = true;
     }
     AttnGeom gg = g;
     if (g_attn_ts_which != 2) gg.ts = nullptr;

@@ -250,11 +250,10 @@ static size_t lds_bwd_one(const AttnGeom& g, int w) {
 
 template <int NDS, int NDT>
 static int launch_bwd_one(const cr_attn_bwd_desc* bd, const AttnGeom& g, int waves, int nsplit, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_bwd_one<NDS, NDT>));
+    static cr_devmask attr_set = 0;
+    {
+        int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_attn_bwd_one<NDS, NDT>), &attr_set);
         if (rc) return rc;
-        attr_set = true;
     }
     hipLaunchKernelGGL((k_attn_bwd_one<NDS, NDT>), dim3(bd->f.B * bd->f.H, nsplit), dim3(64 * waves), lds_bwd_one(g, waves), s, *bd, g);
     return cr_check_launch("cr_attn_bwd(single pass)");

@@ -400,12 +400,6 @@ static inline int attn_nsplit(const cr_attn_desc* d, const AttnGeom& g, int wave
     return want < 1 ? 1 : want;
 }
 
-static inline int attn_set_lds_attr(const void* fn) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return cr_set_error(CR_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    return CR_OK;
-}
-
 // largest wave count (8, 4, 2, 1) whose LDS footprint fits the 160 KiB of a CU; 0 if none does
 template <class F>
 static int attn_pick_waves(const AttnGeom& g, F lds) {

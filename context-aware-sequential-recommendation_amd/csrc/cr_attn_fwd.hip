@@ -146,11 +146,10 @@ static size_t lds_fwd(const AttnGeom& g, int w) {
 
 template <int NKT, int NDS, int NDT>
 static int launch_fwd(const cr_attn_desc* d, const AttnGeom& g, int waves, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = attn_set_lds_attr(reinterpret_cast<const void*>(&k_attn_fwd<NKT, NDS, NDT>));
+    static cr_devmask attr_set = 0;
+    {
+        int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_attn_fwd<NKT, NDS, NDT>), &attr_set);
         if (rc) return rc;
-        attr_set = true;
     }
     AttnGeom gg = g;
     if (g_attn_ts_which != 0) gg.ts = nullptr;

@@ -1080,23 +1080,14 @@ static int block_check(const cr_block_desc* d, BlockGeom* g, const char* who) {
     return CR_OK;
 }
 
-static int block_lds_attr(const void* fn, bool* done) {
-    if (!*done) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return cr_set_error(CR_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        *done = true;
-    }
-    return CR_OK;
-}
-
 extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
     BlockGeom g;
     int rc = block_check(d, &g, "cr_block_ln_qkv_fwd");
     if (rc) return rc;
     CR_REQUIRE(d->x && d->q_in && d->qkv && d->k_valid && d->q_valid && d->ln1_g && d->ln1_b && d->wqkv && d->bqkv,
                "cr_block_ln_qkv_fwd: NULL pointer");
-    static bool attr = false;
-    rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd), &attr);
+    static cr_devmask attr = 0;
+    rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd), &attr);
     if (rc) return rc;
     const size_t lds = sizeof(float) * (2 * 64 * F3_P + 3 * 4 * g.ks * BK_WROW + 320);
     hipLaunchKernelGGL(k_block_ln_qkv_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
@@ -1124,17 +1115,17 @@ static int block_ffn_fwd_launch(const cr_block_desc* d, const cr_block_tail_desc
         tl.lnf_g = t->lnf_gamma; tl.lnf_b = t->lnf_beta; tl.out = t->out; tl.ld_out = t->ld_out; tl.col_out = t->col_out;
     }
     const size_t lds = sizeof(float) * (2 * 64 * F3_P + (kind == 1 ? 3 : 2) * 4 * g.ks * BK_WROW + 320 + 64);
-    static bool attr[3] = {false, false, false};
+    static cr_devmask attr[3] = {0, 0, 0};
     if (kind == 0) {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<0>), &attr[0]);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<0>), &attr[0]);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_ffn_fwd<0>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
     } else if (kind == 1) {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<1>), &attr[1]);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<1>), &attr[1]);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_ffn_fwd<1>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
     } else {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<2>), &attr[2]);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_ffn_fwd<2>), &attr[2]);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_ffn_fwd<2>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, tl);
     }
@@ -1161,13 +1152,13 @@ extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {
     const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
     const int ng = (rps > 64 && !(g.dbg & 1)) ? 2 : 1;
     const size_t lds = sizeof(float) * (2 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P + 64));
-    static bool attr1 = false, attr2 = false;
+    static cr_devmask attr1 = 0, attr2 = 0;
     if (ng == 2) {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<2>), &attr2);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<2>), &attr2);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_ffn_bwd<2>, dim3(bd->n_slabs), dim3(512), lds, cr_stream(stream), *bd, g);
     } else {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<1>), &attr1);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_ffn_bwd<1>), &attr1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_ffn_bwd<1>, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
     }
@@ -1185,13 +1176,13 @@ extern "C" int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* bd, void* stream) {
     const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
     const int ng = (rps > 64 && !(g.dbg & 2)) ? 2 : 1;
     const size_t lds = sizeof(float) * (3 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P));
-    static bool attr1 = false, attr2 = false;
+    static cr_devmask attr1 = 0, attr2 = 0;
     if (ng == 2) {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2>), &attr2);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2>), &attr2);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_qkv_bwd<2>, dim3(bd->n_slabs), dim3(512), lds, cr_stream(stream), *bd, g);
     } else {
-        rc = block_lds_attr(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1>), &attr1);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1>), &attr1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_block_ln_qkv_bwd<1>, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
     }

@@ -96,3 +96,19 @@ __device__ __forceinline__ float cr_row16_sum(float v) {
 }
 
 static inline int cr_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised, and that
+// attribute belongs to the CURRENT device: each launcher keeps one mask per kernel, one bit per device ordinal, so a
+// process that drives several GPUs gets the attribute on every one of them (a plain "done" flag would skip the
+// second device and its launch would fail).  Ordinals >= 64 are simply not cached.
+typedef unsigned long long cr_devmask;
+static inline int cr_raise_lds_limit(const void* fn, cr_devmask* done) {
+    int dev = -1;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    const cr_devmask bit = known ? (1ull << dev) : 0ull;
+    if (bit && (__atomic_load_n(done, __ATOMIC_RELAXED) & bit)) return CR_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return cr_set_error(CR_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (bit) __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+    return CR_OK;
+}
