@@ -279,6 +279,59 @@ __device__ __forceinline__ void wave_store_rows(float* gdst, const float* Ts, in
     }
 }
 
+// The wave's 16-row strip of x built in place from the embedding recipe of cr_embed_fwd (same arithmetic, same
+// dropout counters): x[m] = mask * dropout(table'[id[m]] * scale + pos[m % T] + addend[m]).  Row-chunk items as in
+// stream_fetch; the strip is returned UNROTATED (lane's vector = columns [col0, col0 + 4)), ready for stream_put,
+// and written to the dense x matrix on the way (the backward kernels and the residual read it).
+__device__ __forceinline__ void gather_issue_ids(const cr_embed_desc& e, int mw, int nrows, int (&id)[4], int (&mk)[4]) {
+    const int r0 = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mw + min(r0 + 4 * i, max(nrows - 1, 0));
+        id[i] = (nrows > 0) ? e.ids[m] : 0;
+        mk[i] = (nrows > 0 && e.mask_ids) ? e.mask_ids[m] : 1;
+    }
+}
+__device__ __forceinline__ void gather_rows(Stream4& s, const cr_embed_desc& e, const int (&id)[4], const int (&mk)[4],
+                                            int mw, int nrows, int D) {
+    const int lane = threadIdx.x & 63, q = lane & 15, r0 = lane >> 4;
+    const int col0 = min(4 * q, D - 4);
+    if (nrows <= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.v[i] = (f4r){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const DropCtx dc = drop_ctx(e.drop);
+    f4r tv[4], pv[4], av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mw + min(r0 + 4 * i, nrows - 1);
+        tv[i] = *reinterpret_cast<const f4r*>(e.table + (size_t)id[i] * D + col0);       // row 0 exists; zeroed below when zero_pad
+        pv[i] = (f4r){0.f, 0.f, 0.f, 0.f};
+        av[i] = (f4r){0.f, 0.f, 0.f, 0.f};
+        if (e.pos_table) pv[i] = *reinterpret_cast<const f4r*>(e.pos_table + (size_t)(m % e.T) * D + col0);
+        if (e.addend) av[i] = *reinterpret_cast<const f4r*>(e.addend + (size_t)m * e.ld_add + col0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * i, m = mw + min(r, nrows - 1);
+        const bool padrow = e.zero_pad && id[i] == 0;
+        const bool dead = mk[i] == 0;
+        const uint32_t base = (e.drop.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)col0;
+        float y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = (padrow ? 0.0f : tv[i][t]) * e.scale + pv[i][t] + av[i][t];
+            v = drop_apply(dc, base + (uint32_t)t, v);
+            y[t] = dead ? 0.0f : v;
+        }
+        s.v[i] = (f4r){y[0], y[1], y[2], y[3]};
+        // the chunk that crosses column D was shifted back: it rewrites up to three columns of its left neighbour
+        // with the same values
+        if (r < nrows && 4 * q < D) *reinterpret_cast<f4r*>(e.out + (size_t)m * D + col0) = s.v[i];
+    }
+}
+
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -404,7 +457,8 @@ __device__ __forceinline__ void f1_put_vec(float* vec, const float (&v)[2], int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g) {
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, BlockGeom g, cr_embed_desc e) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = d.D;
     float* Xs = smem;                       // [64][66]
@@ -417,13 +471,20 @@ __global__ __launch_bounds__(256) void k_block_ln_qkv_fwd(cr_block_desc d, Block
     const int mw = m0 + 16 * wave;
     const int nr = max(0, min(16, d.M - mw));
     BK_TS(0); BK_TS(1);
-    wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
+    int id[4], mk[4];
+    if (GATHER) gather_issue_ids(e, mw, nr, id, mk);                // x does not exist yet: this kernel composes it
+    else wave_load_rows(Xs + 16 * wave * F3_P, d.x + (size_t)mw * D, F3_P, D, nr, g.invD);
     {
         WFrag w3[3];
         float vv[2];
 #pragma unroll
         for (int part = 0; part < 3; ++part) fetch_w(w3[part], d.wqkv, 3 * D, part * D, D);
         f1_fetch_vec(d, vv);
+        if (GATHER) {
+            Stream4 sx;
+            gather_rows(sx, e, id, mk, mw, nr, D);
+            stream_put(Xs + 16 * wave * F3_P, sx, D, nr * D, g.invD, PutPlain());
+        }
 #pragma unroll
         for (int part = 0; part < 3; ++part) put_w_packed(Ws + part * wsz, w3[part], D, 4 * g.ks);
         f1_put_vec(vec, vv, D);
@@ -1080,18 +1141,37 @@ static int block_check(const cr_block_desc* d, BlockGeom* g, const char* who) {
     return CR_OK;
 }
 
-extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
+static int block_qkv_fwd_launch(const cr_block_desc* d, const cr_embed_desc* e, void* stream, const char* who) {
     BlockGeom g;
-    int rc = block_check(d, &g, "cr_block_ln_qkv_fwd");
+    int rc = block_check(d, &g, who);
     if (rc) return rc;
     CR_REQUIRE(d->x && d->q_in && d->qkv && d->k_valid && d->q_valid && d->ln1_g && d->ln1_b && d->wqkv && d->bqkv,
-               "cr_block_ln_qkv_fwd: NULL pointer");
-    static cr_devmask attr = 0;
-    rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd), &attr);
-    if (rc) return rc;
+               "%s: NULL pointer", who);
     const size_t lds = sizeof(float) * (2 * 64 * F3_P + 3 * 4 * g.ks * BK_WROW + 320);
-    hipLaunchKernelGGL(k_block_ln_qkv_fwd, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g);
-    return cr_check_launch("cr_block_ln_qkv_fwd");
+    static cr_devmask attr[2] = {0, 0};
+    if (e) {
+        CR_REQUIRE(e->ids && e->table && e->out == d->x && e->ld_out == d->D && e->col_off == 0 && e->M == d->M && e->D == d->D &&
+                   e->T > 0 && e->M % e->T == 0 && e->V > 0 && (e->addend == nullptr || e->ld_add >= e->D),
+                   "%s: the embedding recipe must describe the block's dense input x (out == x, ld_out == D, col_off == 0)", who);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd<true>), &attr[1]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_qkv_fwd<true>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, *e);
+    } else {
+        cr_embed_desc none = {};
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_fwd<false>), &attr[0]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_block_ln_qkv_fwd<false>, dim3(cr_ceil_div(d->M, 64)), dim3(256), lds, cr_stream(stream), *d, g, none);
+    }
+    return cr_check_launch(who);
+}
+
+extern "C" int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream) {
+    return block_qkv_fwd_launch(d, nullptr, stream, "cr_block_ln_qkv_fwd");
+}
+
+extern "C" int cr_block_ln_qkv_fwd_gather(const cr_block_desc* d, const cr_embed_desc* e, void* stream) {
+    CR_REQUIRE(e, "cr_block_ln_qkv_fwd_gather: NULL embedding recipe");
+    return block_qkv_fwd_launch(d, e, stream, "cr_block_ln_qkv_fwd_gather");
 }
 
 static int block_ffn_fwd_launch(const cr_block_desc* d, const cr_block_tail_desc* t, void* stream, const char* who) {

@@ -175,6 +175,8 @@ class Engine:
         # fused row-phase kernels (cr_block_*) need the hidden size to fit one 64-column tile
         self.single_pass_bwd = os.environ.get("CASTREC_TWO_PASS_ATTN_BWD") != "1"
         self.fuse_tails = os.environ.get("CASTREC_NO_TAILS") != "1"
+        self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
+        self._pending_embed = {}
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -256,8 +258,10 @@ class Engine:
 
     # ---- graph pieces --------------------------------------------------------------------------
     def op_embed(self, ids_key, table, out, ld_out, col_off, scale, pos=None, addend=None, drop_site=None,
-                 mask=False, small=False):
-        """modules.py:83-164 + the input composition of each graph. `addend` = (buffer, gradbuffer)."""
+                 mask=False, small=False, into_stack=False):
+        """modules.py:83-164 + the input composition of each graph. `addend` = (buffer, gradbuffer).
+        into_stack: `out` is the dense input of a transformer stack that follows immediately; on the fused path the
+        gather then runs inside the first block's LN1 + QKV kernel (cr_block_ln_qkv_fwd_gather) instead of here."""
         V, D = self.layout.entries[table][1]
         pos_ptr = None
         if pos == "static":
@@ -269,7 +273,10 @@ class Engine:
                         add_buf.data_ptr() if addend else None, add_buf.shape[1] if addend else 0,
                         self.rng(drop_site) if drop_site else O.NO_DROP,
                         self.ids["seq"].data_ptr() if mask else None, out.data_ptr(), ld_out, col_off)
-        self._call(self.fwd, "cr_embed_fwd", C.byref(d))
+        if into_stack and self.fused and self.fuse_embed and ld_out == D and col_off == 0:
+            self._pending_embed[out.data_ptr()] = d                  # emitted by the first block of op_stack
+        else:
+            self._call(self.fwd, "cr_embed_fwd", C.byref(d))
         if not self.training:
             return
 
@@ -488,7 +495,12 @@ class Engine:
         ids = self.ids["seq"]
         bd = self._block_desc(x, y, pfx)
         if not skip_qkv:
-            self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
+            e = self._pending_embed.pop(x.data_ptr(), None)
+            if e is not None:
+                self._keep.append(e)
+                self._call(self.fwd, "cr_block_ln_qkv_fwd_gather", C.byref(bd), C.byref(e))
+            else:
+                self._call(self.fwd, "cr_block_ln_qkv_fwd", C.byref(bd))
         MD4 = 4 * M * D
         ad = O.attn_desc(qkv, None, None, D, kvalid, qvalid, q_in, D, o, D, B, T, H, D // H,
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
@@ -543,6 +555,8 @@ class Engine:
         """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns.
         Fused path: block i+1's LN1 + QKV phase and the final LayerNorm run as tails of the FFN kernels."""
         tails = self.fused and self.fuse_tails and nblocks > 0
+        if nblocks == 0 and x.data_ptr() in self._pending_embed:      # no block to carry the gather
+            self._call(self.fwd, "cr_embed_fwd", C.byref(self._pending_embed.pop(x.data_ptr())))
         ys = [self.buf("%s.%d.y" % (prefix, i), self.D) for i in range(nblocks)]
         cur = x
         for i in range(nblocks):
@@ -581,13 +595,13 @@ class Engine:
 
         def ctx_stack(table, ids_key, prefix, out, out_ld, out_col, want=False):
             e = self.buf(prefix + ".emb", D)
-            self.op_embed(ids_key, table, e, D, 0, sq, small=True)                         # cast_1.py:30-38
+            self.op_embed(ids_key, table, e, D, 0, sq, small=True, into_stack=True)        # cast_1.py:30-38
             self.op_stack(e, prefix, st["ctx"][prefix], out, out_ld, out_col, want_attn=want)   # cast_1.py:42-60
 
         if m in ("sasrec", "sasrec_static"):
             x = self.buf("x0", D)
             self.op_embed("seq", "item_emb", x, D, 0, sq, pos="learned" if m == "sasrec" else "static",
-                          drop_site="emb", mask=True)                                       # sasrec.py:27-62
+                          drop_site="emb", mask=True, into_stack=True)                      # sasrec.py:27-62
             s = self.buf("seq_emb", D)
             self.op_stack(x, "trunk", L_, s, D, 0, want_attn=wa_trunk)
         elif m == "cast_1":
@@ -595,7 +609,7 @@ class Engine:
             ctx_stack("time_emb", "time", "ctx_time", tseq, D, 0, want=wa_ctx)
             x = self.buf("x0", D)
             self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)),
-                          drop_site="emb", mask=True)                                       # cast_1.py:86-91
+                          drop_site="emb", mask=True, into_stack=True)                      # cast_1.py:86-91
             s = self.buf("seq_emb", D)
             self.op_stack(x, "trunk", L_, s, D, 0)
         elif m in ("cast_2", "cast_3", "cast_4", "cast_7", "cast_8", "cast_9"):
@@ -646,13 +660,14 @@ class Engine:
             if m == "cast_5":
                 tseq = self.buf("tseq", D)
                 ctx_stack("time_emb", "time", "ctx_time", tseq, D, 0, want=wa_ctx)
-                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)))  # cast_5.py:113-114
+                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", addend=(tseq, self._grad_of(tseq)),
+                              into_stack=True)                                              # cast_5.py:113-114
                 self.op_stack(x, "trunk", L_, c, k * D, 0)                                  # cast_5.py:118-139
                 self.op_embed("hours", "hours_emb", c, k * D, D, sq, small=True)
                 self.op_embed("days", "days_emb", c, k * D, 2 * D, sq, small=True)
                 self.op_dropout_inplace(c, 3 * D, "concat1")                                # cast_5.py:143-146
             else:
-                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static")                 # cast_6.py:113
+                self.op_embed("seq", "item_emb", x, D, 0, sq, pos="static", into_stack=True)   # cast_6.py:113
                 self.op_stack(x, "trunk", L_, c, k * D, 0)                                  # cast_6.py:117-138
                 ctx_stack("time_emb", "time", "ctx_time", c, k * D, D, want=wa_ctx)
                 self.op_dropout_inplace(c, 2 * D, "concat1")                                # cast_6.py:142-145

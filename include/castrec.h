@@ -236,6 +236,12 @@ typedef struct {
 int cr_block_ln_qkv_fwd(const cr_block_desc* d, void* stream);
 int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream);
 
+/* cr_block_ln_qkv_fwd of a stack's FIRST block with the stack input composed in the same kernel: `e` is the
+ * cr_embed_fwd call that would have produced d->x (sasrec.py:27-62 / cast_1.py:30-38,86-91); it must describe
+ * exactly that matrix (e->out == d->x, ld_out == D, col_off == 0, same M and D).  x is still written (the backward
+ * and the residual read it); results are identical to cr_embed_fwd followed by cr_block_ln_qkv_fwd. */
+int cr_block_ln_qkv_fwd_gather(const cr_block_desc* d, const cr_embed_desc* e, void* stream);
+
 /* cr_block_ln_ffn_fwd with a tail stage applied to the output rows while they are still on chip:
  *   kind 1: the NEXT block's cr_block_ln_qkv_fwd (next->x must be this block's y) -- one launch per block boundary less;
  *   kind 2: the stack's final LayerNorm (sasrec.py:85): out[:, col_out : col_out + D] = LN(y; lnf_gamma, lnf_beta).
