@@ -956,8 +956,12 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
 // NG groups of 4 waves per workgroup (see B3), three 64-row tiles per group, reused phase by phase:
 //   TG: dQ -> dK -> dV -> dq_in -> dx      TA: q_in -> x      TB: dK Wk^T + dV Wv^T
 // so that two groups and the three packed transposed weights fit the 160 KB of a CU (two waves per SIMD).
-template <int NG>
-__global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm) {
+// SCATTER: the block is the first of its stack and x was composed by an embedding gather (cr_embed_fwd /
+// cr_block_ln_qkv_fwd_gather): instead of storing dx, the wave applies that gather's backward to its 16 rows right
+// here -- mask and dropout regenerated, d_addend written, table rows scatter-added with one contiguous float-atomic
+// burst per row (cr_embed_bwd's large-table mode; `sc` is the descriptor that call would have taken).
+template <int NG, bool SCATTER>
+__global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm, cr_embed_bwd_desc sc) {
     constexpr int NT = 256 * NG;
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1056,13 +1060,49 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         stream_add(tg, s1, D, tot);                                 // tg += d_o (residual branch)
         if (ones >= 0 && lane < 16) ta[lane * F3_P + ones] = 0.0f;     // remove the ones column before LN reads x
         ln_bwd_rows(TA, TG, TB, gam, ag, ab, D, w4);
-        if (nr > 0) {
+        if (nr > 0 && !SCATTER) {
             float* gdx = bd.dx + (size_t)mw * D;
             if (bd.dx_accumulate) {
                 wave_load_rows(tb, gdx, F3_P, D, nr, gm.invD);
                 for (int e = lane; e < 16 * F3_P; e += 64) tg[e] += tb[e];
             }
             wave_store_rows(gdx, tg, F3_P, D, nr, gm.invD);
+        }
+        if (nr > 0 && SCATTER) {
+            const cr_embed_desc& e = sc.f;
+            const DropCtx dc = drop_ctx(e.drop);
+            const int mrow = mw + min(lane & 15, nr - 1);
+            const int my_id = e.ids[mrow];                              // lane r (< 16) holds the id / mask of row r
+            const int my_mk = e.mask_ids ? e.mask_ids[mrow] : 1;
+            {   // g = dx * mask, dropout regenerated (same counters as the forward), in place in the wave's strip
+                const int q = lane & 15, r0 = lane >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + 4 * i;
+                    const int mk = __shfl(my_mk, r, 64);
+                    if (r < nr && 4 * q < D) {
+                        float2* pt = reinterpret_cast<float2*>(tg + r * F3_P + 4 * q);
+                        float2 a = pt[0], b = pt[1];
+                        const uint32_t base_idx = (e.drop.row_offset + (uint32_t)(mw + r)) * (uint32_t)D + (uint32_t)(4 * q);
+                        const float k = mk != 0 ? 1.0f : 0.0f;
+                        a.x = drop_apply(dc, base_idx + 0u, a.x * k);
+                        a.y = drop_apply(dc, base_idx + 1u, a.y * k);
+                        b.x = drop_apply(dc, base_idx + 2u, b.x * k);
+                        b.y = drop_apply(dc, base_idx + 3u, b.y * k);
+                        pt[0] = a;
+                        pt[1] = b;
+                    }
+                }
+            }
+            if (sc.d_addend) wave_store_rows(sc.d_addend + (size_t)mw * D, tg, F3_P, D, nr, gm.invD);
+            if (sc.table_grad) {
+#pragma unroll 4
+                for (int r = 0; r < nr; ++r) {
+                    const int id = __shfl(my_id, r, 64);
+                    if (!(e.zero_pad && id == 0) && lane < D)
+                        atomicAdd(sc.table_grad + (size_t)id * D + lane, tg[r * F3_P + lane] * e.scale);
+                }
+            }
         }
         if (base == mb) BK_TSG(gm, 9);
     }
@@ -1245,26 +1285,57 @@ extern "C" int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* bd, void* stream) {
     return cr_check_launch("cr_block_ln_ffn_bwd");
 }
 
-extern "C" int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* bd, void* stream) {
-    CR_REQUIRE(bd != nullptr, "cr_block_ln_qkv_bwd: NULL desc");
+static int block_qkv_bwd_launch(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, void* stream, const char* who) {
+    CR_REQUIRE(bd != nullptr, "%s: NULL desc", who);
     BlockGeom g;
-    int rc = block_check(&bd->f, &g, "cr_block_ln_qkv_bwd");
+    int rc = block_check(&bd->f, &g, who);
     if (rc) return rc;
     const cr_block_desc* d = &bd->f;
-    CR_REQUIRE(bd->dqkv && bd->d_o && bd->dx && d->q_in && d->x && d->wqkv && d->ln1_g, "cr_block_ln_qkv_bwd: NULL pointer");
-    CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b && bd->n_slabs > 0, "cr_block_ln_qkv_bwd: NULL gradient pointer");
+    CR_REQUIRE(bd->dqkv && bd->d_o && d->q_in && d->x && d->wqkv && d->ln1_g, "%s: NULL pointer", who);
+    CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b && bd->n_slabs > 0, "%s: NULL gradient pointer", who);
     const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
     const int ng = (rps > 64 && !(g.dbg & 2)) ? 2 : 1;
     const size_t lds = sizeof(float) * (3 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P));
-    static cr_devmask attr1 = 0, attr2 = 0;
-    if (ng == 2) {
-        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2>), &attr2);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_block_ln_qkv_bwd<2>, dim3(bd->n_slabs), dim3(512), lds, cr_stream(stream), *bd, g);
-    } else {
-        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1>), &attr1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_block_ln_qkv_bwd<1>, dim3(bd->n_slabs), dim3(256), lds, cr_stream(stream), *bd, g);
+    static cr_devmask attr[4] = {0, 0, 0, 0};
+    hipStream_t s = cr_stream(stream);
+    if (sc) {
+        const cr_embed_desc* e = &sc->f;
+        CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
+                   "%s: the embedding recipe must describe the block's dense input x", who);
+        CR_REQUIRE(sc->n_slabs == 0 && sc->pos_grad == nullptr, "%s: small-table mode and a learned positional table are not fused", who);
+        CR_REQUIRE(!bd->dx_accumulate, "%s: dx_accumulate is not supported (this kernel must be the only producer of dx)", who);
+        CR_REQUIRE(sc->table_grad || sc->d_addend, "%s: nothing to scatter into", who);
+        CR_REQUIRE(sc->d_addend == nullptr || e->ld_add == d->D, "%s: d_addend must be dense [M, D]", who);
+        if (ng == 2) {
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, true>), &attr[3]);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, true>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, *sc);
+        } else {
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, true>), &attr[2]);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, true>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, *sc);
+        }
+        return cr_check_launch(who);
     }
-    return cr_check_launch("cr_block_ln_qkv_bwd");
+    CR_REQUIRE(bd->dx, "%s: dx is NULL", who);
+    cr_embed_bwd_desc none = {};
+    if (ng == 2) {
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, false>), &attr[1]);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, false>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, none);
+    } else {
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, false>), &attr[0]);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, false>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, none);
+    }
+    return cr_check_launch(who);
+}
+
+extern "C" int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* bd, void* stream) {
+    return block_qkv_bwd_launch(bd, nullptr, stream, "cr_block_ln_qkv_bwd");
+}
+
+extern "C" int cr_block_ln_qkv_bwd_scatter(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, void* stream) {
+    CR_REQUIRE(sc != nullptr, "cr_block_ln_qkv_bwd_scatter: NULL embedding recipe");
+    return block_qkv_bwd_launch(bd, sc, stream, "cr_block_ln_qkv_bwd_scatter");
 }

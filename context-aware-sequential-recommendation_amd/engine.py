@@ -177,6 +177,7 @@ class Engine:
         self.fuse_tails = os.environ.get("CASTREC_NO_TAILS") != "1"
         self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
         self._pending_embed = {}
+        self._scatter_recipe, self._scatter_claimed = {}, set()
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -280,17 +281,27 @@ class Engine:
         if not self.training:
             return
 
-        def factory(dname=out, d=d):
+        def make_bwd_desc():
             f = L.EmbedDesc.from_buffer_copy(d)
             f.out = self._grad_of(out).data_ptr()
             dadd = None
             if addend:
                 assert self._acc(id(addend[1])) == 0, "addend gradient must be first-written here"
                 dadd = addend[1].data_ptr()
-            bd = L.EmbedBwdDesc(f, self._gptr(table), self._gptr("pos_emb") if pos == "learned" else None, dadd,
-                                self.Gs.shape[1] if small else 0, self.n_slabs if small else 0)
+            return L.EmbedBwdDesc(f, self._gptr(table), self._gptr("pos_emb") if pos == "learned" else None, dadd,
+                                  self.Gs.shape[1] if small else 0, self.n_slabs if small else 0)
+
+        # the first block's QKV backward can apply this scatter itself (cr_block_ln_qkv_bwd_scatter): large-table
+        # mode without a learned positional table only; the block's factory (it runs before this one) claims it
+        if (out.data_ptr() in self._pending_embed and not small and pos != "learned"
+                and (addend is None or addend[0].shape[1] == D)):
+            self._scatter_recipe[out.data_ptr()] = make_bwd_desc
+
+        def factory():
+            if out.data_ptr() in self._scatter_claimed:
+                return []
             lst = []
-            self._call(lst, "cr_embed_bwd", C.byref(bd))
+            self._call(lst, "cr_embed_bwd", C.byref(make_bwd_desc()))
             return lst
         self._bwd_factories.append(factory)
 
@@ -547,7 +558,12 @@ class Engine:
                 abd.delta, abd.dQ_part = delta.data_ptr(), dq_part.data_ptr()
             self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
-            self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
+            recipe = self._scatter_recipe.get(x.data_ptr())
+            if recipe is not None and not bbd.dx_accumulate:
+                self._scatter_claimed.add(x.data_ptr())
+                self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()))
+            else:
+                self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst
         self._bwd_factories.append(factory)
 
