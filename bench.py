@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--num_blocks", type=int, default=2)
     ap.add_argument("--num_heads", type=int, default=1)
     ap.add_argument("--dropout_rate", type=float, default=0.2)
-    ap.add_argument("--n_slabs", type=int, default=256)
+    ap.add_argument("--n_slabs", type=int, default=0, help="gradient slabs; 0 = engine default (ceil(M/128) capped at 256)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel HIP-event table here")

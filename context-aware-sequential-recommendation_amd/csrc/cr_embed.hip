@@ -187,48 +187,71 @@ __global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
 #define EMB_SMALL_MAX 12288   // floats of LDS (48 KiB)
 __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
     const cr_embed_desc& d = bd.f;
-    __shared__ float tab[EMB_SMALL_MAX];
+    __shared__ __attribute__((aligned(16))) float tab[EMB_SMALL_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = d.V * d.D;
-    for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.0f;
+    for (int i = threadIdx.x; i < (n + 3) >> 2; i += 256) *reinterpret_cast<f4e*>(tab + 4 * i) = (f4e){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const DropCtx dc = drop_ctx(d.drop);
     const int rps = (d.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
     if (d.D <= 64) {
-        // 16 lanes per row, 4 rows per wave-instruction, U = 4 such groups requested together: the serial
-        // id -> row -> LDS-atomic chain of one row per wave was pure latency (19 us for 5 MB)
-        const int sub = lane >> 4, l = lane & 15;
-        constexpr int U = 4;
-        for (int mb = m0 + wave * 4; mb < m1; mb += 16 * U) {
-            int mm[U], id[U];
-            float keep[U], g[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int m = mb + 16 * u + sub;
-                const bool act = m < m1;
-                mm[u] = act ? m : m0;
-                id[u] = d.ids[mm[u]];
-                keep[u] = (act && !(d.mask_ids && d.mask_ids[mm[u]] == 0)) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = l + 16 * i;
-                    g[u][i] = (c < d.D) ? d.out[(size_t)mm[u] * d.ld_out + d.col_off + c] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int m = mb + 16 * u + sub;
+        // LDS float atomics (ds_add_f32) retire only a few lanes per clock: the 6 400 of them a workgroup needed for
+        // its 128 rows were 10 of this kernel's 14 us.  Instead every table row has ONE owner wave (id mod 4): a wave
+        // scans the ids of 64 gradient rows at a time, requests up to 16 of the rows it owns together (lane = column),
+        // and adds them into the LDS image with plain read-add-write -- no other wave touches those table rows, and
+        // a wave's own LDS operations stay in order.  d_addend (every row, owned or not) is a separate streaming pass.
+        if (bd.d_addend) {
+            const int sub = lane >> 4, l = lane & 15;
+            for (int mb = m0 + wave * 4; mb < m1; mb += 16) {
+                const int m = mb + sub;
                 if (m >= m1) continue;
-                const bool skip_table = (d.zero_pad && id[u] == 0);
+                const float keep = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = l + 16 * i;
                     if (c < d.D) {
-                        float gv = g[u][i] * keep[u];
-                        gv = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, gv);
-                        if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = gv;
-                        if (!skip_table) atomicAdd(&tab[id[u] * d.D + c], gv * d.scale);
+                        const float gv = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep;
+                        bd.d_addend[(size_t)m * d.ld_add + c] =
+                            drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, gv);
+                    }
+                }
+            }
+        }
+        constexpr int U = 16;
+        const bool col = lane < d.D;
+        for (int h0 = m0; h0 < m1; h0 += 64) {
+            const int m = h0 + lane;
+            const bool act = m < m1;
+            const int id = act ? d.ids[m] : 0;
+            const int keep = (act && !(d.mask_ids && d.mask_ids[m] == 0)) ? 1 : 0;
+            const bool mine = act && !(d.zero_pad && id == 0) && ((id & 3) == wave);
+            unsigned long long todo = __ballot(mine ? 1 : 0);
+            while (todo) {
+                float g[U];
+                int rr[U];
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (todo) {
+                        const int r = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        rr[k] = r;
+                        g[k] = col ? d.out[(size_t)(h0 + r) * d.ld_out + d.col_off + lane] : 0.0f;
+                        cnt = k + 1;
+                    } else {
+                        rr[k] = 0;
+                        g[k] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (k < cnt) {
+                        const int idk = __builtin_amdgcn_readlane(id, rr[k]);
+                        const int kk = __builtin_amdgcn_readlane(keep, rr[k]);
+                        float gv = kk ? g[k] : 0.0f;
+                        gv = drop_apply(dc, (d.drop.row_offset + (uint32_t)(h0 + rr[k])) * (uint32_t)d.D + (uint32_t)lane, gv);
+                        if (col) tab[idk * d.D + lane] += gv * d.scale;
                     }
                 }
             }
@@ -246,8 +269,24 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
         }
     }
     __syncthreads();
+    // LDS image -> this workgroup's slab: 16-byte pieces, four of them in flight per thread (the one-dword loop was a
+    // chain of 40 dependent LDS-read -> store pairs per thread)
     float* slab = bd.table_grad + (size_t)blockIdx.x * bd.slab_stride;
-    for (int i = threadIdx.x; i < n; i += 256) slab[i] = tab[i];
+    const int n4 = n >> 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+        f4e v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n4) v[u] = *reinterpret_cast<const f4e*>(tab + 4 * i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n4) *reinterpret_cast<f4e*>(slab + 4 * i) = v[u];
+        }
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) slab[i] = tab[i];
 }
 
 // Large table without a positional-table gradient (static sinusoid graphs, context-free inputs): nothing

@@ -58,6 +58,17 @@ class Hyper:
             raise ValueError("hidden_units must be divisible by num_heads (tf.split, modules.py:208)")
 
 
+def auto_slabs(M):
+    """Number of gradient slabs = workgroups of every weight-gradient kernel.  The fused backward kernels work on two
+    64-row tile groups per workgroup: ceil(M / 128) workgroups have both groups full (M = 25 600: 200 slabs, 0.8 %
+    faster end to end than 256 slabs of 100 rows, and 22 % fewer slab bytes for Adam to sum); small problems get one
+    64-row tile per workgroup so that enough workgroups exist; never more than one workgroup per CU."""
+    n = -(-M // 128)
+    if n < 128:
+        n = -(-M // 64)
+    return max(1, min(256, n))
+
+
 # ---------------------------------------------------------------------------------------------------
 # parameter layout
 # ---------------------------------------------------------------------------------------------------
@@ -161,7 +172,7 @@ class ParamLayout:
 
 # ---------------------------------------------------------------------------------------------------
 class Engine:
-    def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=256,
+    def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=None,
                  share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda", fused=None):
         if model not in MODELS:
             raise ValueError("model must be one of %s" % MODELS)
@@ -185,6 +196,8 @@ class Engine:
         self.seed = hp.seed if seed is None else seed
         self.layout = share.layout if share is not None else ParamLayout(model, usernum, itemnum, hp)
         lay = self.layout
+        if not n_slabs:
+            n_slabs = auto_slabs(batch_size * hp.maxlen)
         self.n_slabs = n_slabs
         f32 = dict(dtype=torch.float32, device=self.dev)
         if share is not None:

@@ -19,7 +19,7 @@ from .engine import MODELS, Engine, Hyper
 class _Model(object):
     NAME = None
 
-    def __init__(self, usernum, itemnum, args, reuse=None, n_slabs=256, batch_global=None, row_offset=0):
+    def __init__(self, usernum, itemnum, args, reuse=None, n_slabs=None, batch_global=None, row_offset=0):
         self.name = self.NAME
         self.usernum, self.itemnum, self.args = usernum, itemnum, args
         self.hp = Hyper(args)
