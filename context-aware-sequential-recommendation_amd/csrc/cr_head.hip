@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
         const int mm = act ? m : d.M - 1;
         const int p = act ? d.pos[mm] : 0, ng = act ? d.neg[mm] : 0;
         float s[MAXC], ep[MAXC], en[MAXC];
-        float pl = 0.0f, nl = 0.0f;
+        float pl = 0.0f, nl = 0.0f, gp = 0.0f, gn = 0.0f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = l + LPR * i;
@@ -60,10 +60,28 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
                 const int c = l + LPR * i;
                 if (c < d.D) {
                     if (d.d_seq_emb) d.d_seq_emb[(size_t)m * d.ldd + c] = dpl * ep[i] + dnl * en[i];
-                    if (d.table_grad && ist != 0.0f) {
+                    if (LPR != 16 && d.table_grad && ist != 0.0f) {
                         if (p != 0) atomicAdd(d.table_grad + (size_t)p * d.D + c, dpl * s[i]);
                         if (ng != 0) atomicAdd(d.table_grad + (size_t)ng * d.D + c, dnl * s[i]);
                     }
+                }
+            }
+            gp = dpl;
+            gn = dnl;
+        }
+        if (LPR == 16 && d.table_grad) {
+            // Table rows get one CONTIGUOUS 4*D-byte float-atomic burst each (lane = column), the shape the atomic
+            // units take at full rate; with the 16-lanes-per-row mapping above one instruction carried four 64-byte
+            // pieces of four different rows.  The row's scalars come from its lane group, s[] is re-read (L1 hit).
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int mr = mb + rr;
+                const float gpr = __shfl(gp, rr * LPR, 64), gnr = __shfl(gn, rr * LPR, 64);
+                const int pr = __shfl(p, rr * LPR, 64), nr = __shfl(ng, rr * LPR, 64);
+                if (mr < d.M && pr != 0 && lane < d.D) {                       // ist == (pos id != 0)
+                    const float sv = d.seq_emb[(size_t)mr * d.ld + lane];
+                    atomicAdd(d.table_grad + (size_t)pr * d.D + lane, gpr * sv);
+                    if (nr != 0) atomicAdd(d.table_grad + (size_t)nr * d.D + lane, gnr * sv);
                 }
             }
         }
