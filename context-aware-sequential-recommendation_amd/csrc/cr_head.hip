@@ -111,6 +111,169 @@ extern "C" int cr_head_fwd_bwd(const cr_head_desc* d, void* stream) {
     return cr_check_launch("cr_head_fwd_bwd");
 }
 
+// Head + backward of the LayerNorm that produced seq_emb (sasrec.py:85), in one pass: the gradient row
+// dy = dpl * E[pos] + dnl * E[neg] never leaves the registers it is computed in -- it goes straight through the
+// LayerNorm backward of cr_layernorm.hip (same row mapping, same arithmetic, same slab reduction: n_slabs workgroups
+// of 16 waves, workgroup s owns rows [s*rps, (s+1)*rps) and writes slab s of dgamma / dbeta).
+template <int LPR, int MAXC>
+__global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc n) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float sg[512], sb[512];
+    __shared__ float red[3][16 * RPW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    for (int c = threadIdx.x; c < d.D; c += 1024) { sg[c] = 0.0f; sb[c] = 0.0f; }
+    __syncthreads();
+    const int rps = (d.M + gridDim.x - 1) / gridDim.x;
+    const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
+    float gam[MAXC], ag[MAXC], ab[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = l + LPR * i;
+        gam[i] = (c < d.D) ? n.gamma[c] : 0.0f;
+        ag[i] = 0.0f; ab[i] = 0.0f;
+    }
+    const float invD = 1.0f / (float)d.D;
+    float loss_acc = 0.0f, auc_acc = 0.0f, n_acc = 0.0f;
+    for (int mb = m0 + wave * RPW; mb < m1; mb += 16 * RPW) {
+        const int m = mb + sub;
+        const bool act = m < m1;
+        const int mm = act ? m : m0;
+        const int p = act ? d.pos[mm] : 0, ng = act ? d.neg[mm] : 0;
+        float s[MAXC], ep[MAXC], en[MAXC], x[MAXC];
+        float pl = 0.0f, nl = 0.0f, xs = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
+            const bool ok = c < d.D;
+            s[i] = ok ? d.seq_emb[(size_t)mm * d.ld + c] : 0.0f;
+            x[i] = ok ? n.x[(size_t)mm * n.ldx + c] : 0.0f;
+            ep[i] = (ok && p != 0) ? d.table[(size_t)p * d.D + c] : 0.0f;      // row 0 == zeros (modules.py:154-156)
+            en[i] = (ok && ng != 0) ? d.table[(size_t)ng * d.D + c] : 0.0f;
+            pl += ep[i] * s[i];
+            nl += en[i] * s[i];
+            xs += x[i];
+        }
+        pl = head_row_sum<LPR>(pl);                                            // sasrec.py:100
+        nl = head_row_sum<LPR>(nl);                                            // sasrec.py:101
+        const float ist = (p != 0) ? 1.0f : 0.0f;                              // sasrec.py:104
+        const float sp = 1.0f / (1.0f + expf(-pl)), sn = 1.0f / (1.0f + expf(-nl));
+        if (l == 0 && act) {
+            loss_acc += ist * (-logf(sp + 1e-24f) - logf(1.0f - sn + 1e-24f)); // sasrec.py:105-108
+            const float dlt = pl - nl;
+            const float sgn = (dlt > 0.0f) ? 1.0f : ((dlt < 0.0f) ? -1.0f : 0.0f);
+            auc_acc += ist * (sgn + 1.0f) * 0.5f;                              // sasrec.py:113-115
+            n_acc += ist;
+            if (d.pos_logits) d.pos_logits[m] = pl;
+            if (d.neg_logits) d.neg_logits[m] = nl;
+        }
+        const float dpl = act ? -ist * sp * (1.0f - sp) / (sp + 1e-24f) : 0.0f;
+        const float dnl = act ? ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f) : 0.0f;
+        // ---- LayerNorm backward of this row (modules.py:74-78), dy in registers
+        const float mean = head_row_sum<LPR>(xs) * invD;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const float dxm = (l + LPR * i < d.D) ? (x[i] - mean) : 0.0f;
+            v += dxm * dxm;
+        }
+        const float rstd = 1.0f / sqrtf(head_row_sum<LPR>(v) * invD + n.eps);
+        float dy[MAXC], c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = l + LPR * i;
+            dy[i] = dpl * ep[i] + dnl * en[i];
+            if (act && c < d.D && d.d_seq_emb) d.d_seq_emb[(size_t)m * d.ldd + c] = dy[i];
+            const float xh = (c < d.D) ? (x[i] - mean) * rstd : 0.0f;
+            x[i] = xh;
+            const float dg = dy[i] * gam[i];
+            c1 += dg;
+            c2 += dg * xh;
+            ag[i] += dy[i] * xh;
+            ab[i] += dy[i];
+        }
+        c1 = head_row_sum<LPR>(c1) * invD;
+        c2 = head_row_sum<LPR>(c2) * invD;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = l + LPR * i;
+                if (c < d.D) n.dx[(size_t)m * n.lddx + c] = rstd * (dy[i] * gam[i] - c1 - x[i] * c2);
+            }
+        }
+        if (d.table_grad) {
+            if (LPR == 16) {
+                // contiguous 4*D-byte float-atomic burst per table row (lane = column), as in k_head
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int mr = mb + rr;
+                    const float gpr = __shfl(dpl, rr * LPR, 64), gnr = __shfl(dnl, rr * LPR, 64);
+                    const int pr = __shfl(p, rr * LPR, 64), nr = __shfl(ng, rr * LPR, 64);
+                    if (mr < m1 && pr != 0 && lane < d.D) {
+                        const float sv = d.seq_emb[(size_t)mr * d.ld + lane];
+                        atomicAdd(d.table_grad + (size_t)pr * d.D + lane, gpr * sv);
+                        if (nr != 0) atomicAdd(d.table_grad + (size_t)nr * d.D + lane, gnr * sv);
+                    }
+                }
+            } else if (act && ist != 0.0f) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = l + LPR * i;
+                    if (c < d.D) {
+                        if (p != 0) atomicAdd(d.table_grad + (size_t)p * d.D + c, dpl * s[i]);
+                        if (ng != 0) atomicAdd(d.table_grad + (size_t)ng * d.D + c, dnl * s[i]);
+                    }
+                }
+            }
+        }
+    }
+    if (l == 0) { red[0][wave * RPW + sub] = loss_acc; red[1][wave * RPW + sub] = auc_acc; red[2][wave * RPW + sub] = n_acc; }
+    // dgamma / dbeta: row groups of the wave by shuffles, then the 16 waves in a fixed order (cr_layernorm.hip)
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float v = 0.0f;
+        for (int i = 0; i < 16 * RPW; ++i) v += red[threadIdx.x][i];
+        if (v != 0.0f) atomicAdd(d.state + threadIdx.x, v);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            ag[i] += __shfl_xor(ag[i], o, 64);
+            ab[i] += __shfl_xor(ab[i], o, 64);
+        }
+    }
+    for (int w = 0; w < 16; ++w) {
+        if (wave == w && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = l + LPR * i;
+                if (c < d.D) { sg[c] += ag[i]; sb[c] += ab[i]; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < d.D; c += 1024) {
+        n.dgamma[(size_t)blockIdx.x * n.slab_stride + c] = sg[c];
+        n.dbeta[(size_t)blockIdx.x * n.slab_stride + c] = sb[c];
+    }
+}
+
+extern "C" int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream) {
+    CR_REQUIRE(d && d->seq_emb && d->table && d->pos && d->neg && d->state, "cr_head_fwd_bwd_ln: NULL pointer");
+    CR_REQUIRE(d->M > 0 && d->D > 0 && d->V > 0 && d->ld >= d->D, "cr_head_fwd_bwd_ln: bad shape");
+    CR_REQUIRE(n && n->x && n->gamma && n->dx && n->dgamma && n->dbeta, "cr_head_fwd_bwd_ln: NULL LayerNorm pointer");
+    CR_REQUIRE(n->M == d->M && n->D == d->D && n->n_slabs > 0 && n->ldx >= d->D && n->lddx >= d->D,
+               "cr_head_fwd_bwd_ln: the LayerNorm description must match the head's rows");
+    CR_REQUIRE(!n->accumulate, "cr_head_fwd_bwd_ln: accumulate is not supported");
+    if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd_ln: D=%d > 512", d->D);
+    if (d->D <= 64)
+        hipLaunchKernelGGL((k_head_ln<16, 4>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
+    else
+        hipLaunchKernelGGL((k_head_ln<64, 8>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
+    return cr_check_launch("cr_head_fwd_bwd_ln");
+}
+
 // test_logits (sasrec.py:93-97): last position of every sequence against its candidate items.
 __global__ __launch_bounds__(256) void k_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                                                      int B, int T, int D, int n_cand, float* logits) {

@@ -189,6 +189,8 @@ class Engine:
         self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
         self._pending_embed = {}
         self._scatter_recipe, self._scatter_claimed = {}, set()
+        self._ln_recipe, self._ln_claimed = {}, set()
+        self.fuse_head_ln = os.environ.get("CASTREC_NO_HEAD_LN") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -336,8 +338,11 @@ class Engine:
             self._call(self.fwd, "cr_layernorm_fwd", C.byref(d))
         if not self.training:
             return
+        self._ln_recipe[yptr] = (x, pname)            # op_head may take this backward over (cr_head_fwd_bwd_ln)
 
         def factory():
+            if yptr in self._ln_claimed:
+                return []
             dy = self._grad_of(y)
             dx = self._grad_of(x)
             bd = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), dy.data_ptr() + 4 * y_col, y_ld,
@@ -606,6 +611,21 @@ class Engine:
         M, D = self.M, self.D
         self.seq_emb = seq_emb
         if not self.training:
+            return
+        rec = self._ln_recipe.get(seq_emb.data_ptr()) if self.fuse_head_ln else None
+        if rec is not None:
+            # seq_emb is the output of a LayerNorm (the stack's final one): its backward runs inside the head kernel,
+            # on the gradient rows while they are in registers; d(seq_emb) is never stored
+            x, pname = rec
+            dx = self._grad_of(x)
+            assert self._acc(id(dx)) == 0
+            self._ln_claimed.add(seq_emb.data_ptr())
+            d = L.HeadDesc(seq_emb.data_ptr(), seq_emb.shape[1], self._pptr("item_emb"), self.ids["pos"].data_ptr(),
+                           self.ids["neg"].data_ptr(), M, D, self.itemnum + 1, self.state.data_ptr(), None, 0,
+                           self._gptr("item_emb"), None, None)
+            n = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), None, 0, dx.data_ptr(), D, 0,
+                            self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+            self._call(self.fwd, "cr_head_fwd_bwd_ln", C.byref(d), C.byref(n))
             return
         ds = self._grad_of(seq_emb)
         self._grad_written.add(id(ds))

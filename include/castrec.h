@@ -289,6 +289,12 @@ typedef struct {
 } cr_head_desc;
 int cr_head_fwd_bwd(const cr_head_desc* d, void* stream);
 
+/* cr_head_fwd_bwd with the backward of the LayerNorm that produced seq_emb (sasrec.py:85) applied to each gradient
+ * row while it is still in registers: `n` is the cr_layernorm_bwd call that would have followed (n->dy is ignored,
+ * n->accumulate must be 0); d->d_seq_emb may be NULL (the gradient row is then never stored).  Results are identical
+ * to cr_head_fwd_bwd followed by cr_layernorm_bwd. */
+int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream);
+
 /* test_logits (sasrec.py:93-97): logits[b, j] = seq_emb[b*T + T-1, :] . table'[cand[b, j], :] */
 int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                    int B, int T, int D, int V, int n_cand, float* logits, void* stream);
