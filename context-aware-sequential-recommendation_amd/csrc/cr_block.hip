@@ -1103,6 +1103,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
                         atomicAdd(sc.table_grad + (size_t)id * D + lane, tg[r * F3_P + lane] * e.scale);
                 }
             }
+            if (sc.pos_grad) {                                          // learned positional table: row m % T, no scale
+#pragma unroll 4
+                for (int r = 0; r < nr; ++r)
+                    if (lane < D) atomicAdd(sc.pos_grad + (size_t)((mw + r) % e.T) * D + lane, tg[r * F3_P + lane]);
+            }
         }
         if (base == mb) BK_TSG(gm, 9);
     }
@@ -1302,9 +1307,9 @@ static int block_qkv_bwd_launch(const cr_block_bwd_desc* bd, const cr_embed_bwd_
         const cr_embed_desc* e = &sc->f;
         CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
                    "%s: the embedding recipe must describe the block's dense input x", who);
-        CR_REQUIRE(sc->n_slabs == 0 && sc->pos_grad == nullptr, "%s: small-table mode and a learned positional table are not fused", who);
+        CR_REQUIRE(sc->n_slabs == 0, "%s: small-table mode is not fused", who);
         CR_REQUIRE(!bd->dx_accumulate, "%s: dx_accumulate is not supported (this kernel must be the only producer of dx)", who);
-        CR_REQUIRE(sc->table_grad || sc->d_addend, "%s: nothing to scatter into", who);
+        CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "%s: nothing to scatter into", who);
         CR_REQUIRE(sc->d_addend == nullptr || e->ld_add == d->D, "%s: d_addend must be dense [M, D]", who);
         if (ng == 2) {
             rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, true>), &attr[3]);

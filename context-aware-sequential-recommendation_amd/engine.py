@@ -307,8 +307,9 @@ class Engine:
                                   self.Gs.shape[1] if small else 0, self.n_slabs if small else 0)
 
         # the first block's QKV backward can apply this scatter itself (cr_block_ln_qkv_bwd_scatter): large-table
-        # mode without a learned positional table only; the block's factory (it runs before this one) claims it
-        if (out.data_ptr() in self._pending_embed and not small and pos != "learned"
+        # mode only (a learned positional table's gradient is then accumulated with atomics: its slot in the table
+        # section is zero at that point); the block's factory (it runs before this one) claims it
+        if (out.data_ptr() in self._pending_embed and not small
                 and (addend is None or addend[0].shape[1] == D)):
             self._scatter_recipe[out.data_ptr()] = make_bwd_desc
 

@@ -271,9 +271,11 @@ int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
 
 /* cr_block_ln_qkv_bwd of a stack's FIRST block whose input x was composed by an embedding gather: instead of
  * storing dx the kernel applies that gather's backward to its rows (cr_embed_bwd, large-table mode): `sc` is the
- * descriptor that call would have taken (sc->f.out is ignored; no learned positional table, no small-table slabs,
- * d_addend dense [M, D]); bd->dx may be NULL and bd->dx_accumulate must be 0.  Results are identical to
- * cr_block_ln_qkv_bwd followed by cr_embed_bwd up to the order of the float atomics into table_grad. */
+ * descriptor that call would have taken (sc->f.out is ignored; no small-table slabs; d_addend dense [M, D]);
+ * bd->dx may be NULL and bd->dx_accumulate must be 0.  One difference: sc->pos_grad is ACCUMULATED with float
+ * atomics here (cr_embed_bwd writes it), so it must be zero on entry -- cr_adam_step leaves the table section
+ * zeroed.  Otherwise results are identical to cr_block_ln_qkv_bwd followed by cr_embed_bwd up to the order of the
+ * float atomics. */
 int cr_block_ln_qkv_bwd_scatter(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, void* stream);
 
 /* ---- prediction head: pos/neg dot-product BCE (sasrec.py:87-115), forward + backward ---- */
