@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): ml-1m-shaped synthetic corpus, CAST1 (models/cast_1.py), maxlen 200,
 hidden 50, 2 blocks, 1 head, dropout 0.2, batch 128 per GPU (weak scaling: global batch 128*N is one
 batch of the single reference sampler stream, rank r takes rows [128r, 128(r+1))), random-init weights.
-A step = step_begin + forward + backward + (RCCL all-reduce for N>1) + dense TF-Adam, replayed from a
+A step = forward + backward + (RCCL all-reduce for N>1) + dense TF-Adam, replayed from a
 HIP graph; the id batches are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
@@ -75,7 +75,7 @@ def kernel_profile(eng, staged, n_steps=8):
     evs = []
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
-    prog = [("cr_step_begin", L.lib.cr_step_begin, (eng.state.data_ptr(),))] + eng.fwd + eng.bwd + [eng._adam]
+    prog = eng.fwd + eng.bwd + [eng._adam]
     eng.Gflat.zero_()
     for it in range(n_steps + 2):
         eng.ids_all.copy_(staged[it % staged.shape[0]])
@@ -216,7 +216,7 @@ def main():
     if use_graph:
         eng.ids_all.copy_(staged[0])
         eng.capture(dp=dp)
-        eng.state.zero_(); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
+        eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
 
     def step(i):
         eng.ids_all.copy_(staged[i % NB])

@@ -45,7 +45,7 @@ __device__ __forceinline__ float slab_sum64(const float* slabs, int n_slabs, int
 // blocks [0, nb_dense): 64 dense parameters each (slab reduction + update); the rest: table entries, grid-stride
 __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
     __shared__ float part[16][64];
-    const uint32_t t = *reinterpret_cast<const uint32_t*>(d.state + 4);
+    const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
     const float* st = d.stats ? d.stats : d.state;
     const float n = st[2];
     const float inv_n = n > 0.0f ? 1.0f / n : 0.0f;
@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.state[5] = n > 0.0f ? st[0] / n : 0.0f;        // loss  (sasrec.py:105-108)
         d.state[6] = n > 0.0f ? st[1] / n : 0.0f;        // auc   (sasrec.py:113-115)
+        if (d.step_snapshot) {                           // end of the step: no block of this kernel reads state[0..4]
+            d.state[0] = 0.0f; d.state[1] = 0.0f; d.state[2] = 0.0f; d.state[3] = 0.0f;
+            *reinterpret_cast<uint32_t*>(d.state + 4) = t + 1u;
+        }
     }
 }
 
@@ -82,6 +86,7 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     CR_REQUIRE(d->n_table >= 0 && d->n_dense >= 0 && d->n_table + d->n_dense > 0, "cr_adam_step: bad sizes");
     CR_REQUIRE(d->n_table == 0 || d->table_grad, "cr_adam_step: table_grad is NULL");
     CR_REQUIRE(d->n_dense == 0 || (d->dense_slabs && d->n_slabs > 0), "cr_adam_step: dense_slabs missing");
+    CR_REQUIRE(d->step_snapshot == nullptr || d->stats != nullptr, "cr_adam_step: step_snapshot needs stats (a copy of the sums that does not alias state[0..2])");
     const int nb_dense = cr_ceil_div(d->n_dense, 64);
     int nb_table = cr_ceil_div(d->n_table, 256);
     if (nb_table > 2048) nb_table = 2048;

@@ -960,7 +960,9 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
 // cr_block_ln_qkv_fwd_gather): instead of storing dx, the wave applies that gather's backward to its 16 rows right
 // here -- mask and dropout regenerated, d_addend written, table rows scatter-added with one contiguous float-atomic
 // burst per row (cr_embed_bwd's large-table mode; `sc` is the descriptor that call would have taken).
-template <int NG, bool SCATTER>
+// SCATTER: 0 none, 1 table rows (+ d_addend), 2 also a learned positional table (kept out of variant 1: the extra
+// live values pushed the kernel, which sits at the 256-VGPR cap, from 48 to 88 bytes of scratch and cost 3.5 us).
+template <int NG, int SCATTER>
 __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc bd, BlockGeom gm, cr_embed_bwd_desc sc) {
     constexpr int NT = 256 * NG;
     const cr_block_desc& d = bd.f;
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
                         atomicAdd(sc.table_grad + (size_t)id * D + lane, tg[r * F3_P + lane] * e.scale);
                 }
             }
-            if (sc.pos_grad) {                                          // learned positional table: row m % T, no scale
+            if (SCATTER == 2 && sc.pos_grad) {                          // learned positional table: row m % T, no scale
 #pragma unroll 4
                 for (int r = 0; r < nr; ++r)
                     if (lane < D) atomicAdd(sc.pos_grad + (size_t)((mw + r) % e.T) * D + lane, tg[r * F3_P + lane]);
@@ -1301,7 +1303,7 @@ static int block_qkv_bwd_launch(const cr_block_bwd_desc* bd, const cr_embed_bwd_
     const int rps = (d->M + bd->n_slabs - 1) / bd->n_slabs;
     const int ng = (rps > 64 && !(g.dbg & 2)) ? 2 : 1;
     const size_t lds = sizeof(float) * (3 * 4 * g.ks * BK_WROW + 64 + 512 * ng + ng * (3 * 64 * F3_P));
-    static cr_devmask attr[4] = {0, 0, 0, 0};
+    static cr_devmask attr[6] = {0, 0, 0, 0, 0, 0};
     hipStream_t s = cr_stream(stream);
     if (sc) {
         const cr_embed_desc* e = &sc->f;
@@ -1311,27 +1313,36 @@ static int block_qkv_bwd_launch(const cr_block_bwd_desc* bd, const cr_embed_bwd_
         CR_REQUIRE(!bd->dx_accumulate, "%s: dx_accumulate is not supported (this kernel must be the only producer of dx)", who);
         CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "%s: nothing to scatter into", who);
         CR_REQUIRE(sc->d_addend == nullptr || e->ld_add == d->D, "%s: d_addend must be dense [M, D]", who);
-        if (ng == 2) {
-            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, true>), &attr[3]);
+        const bool pos = sc->pos_grad != nullptr;
+        if (ng == 2 && !pos) {
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, 1>), &attr[3]);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, true>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, *sc);
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, 1>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, *sc);
+        } else if (ng == 2) {
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, 2>), &attr[5]);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, 2>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, *sc);
+        } else if (!pos) {
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, 1>), &attr[2]);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, 1>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, *sc);
         } else {
-            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, true>), &attr[2]);
+            rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, 2>), &attr[4]);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, true>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, *sc);
+            hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, 2>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, *sc);
         }
         return cr_check_launch(who);
     }
     CR_REQUIRE(bd->dx, "%s: dx is NULL", who);
     cr_embed_bwd_desc none = {};
     if (ng == 2) {
-        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, false>), &attr[1]);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<2, 0>), &attr[1]);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, false>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, none);
+        hipLaunchKernelGGL((k_block_ln_qkv_bwd<2, 0>), dim3(bd->n_slabs), dim3(512), lds, s, *bd, g, none);
     } else {
-        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, false>), &attr[0]);
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_block_ln_qkv_bwd<1, 0>), &attr[0]);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, false>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, none);
+        hipLaunchKernelGGL((k_block_ln_qkv_bwd<1, 0>), dim3(bd->n_slabs), dim3(256), lds, s, *bd, g, none);
     }
     return cr_check_launch(who);
 }

@@ -207,6 +207,7 @@ class Engine:
         else:
             self.P = torch.from_numpy(lay.init_host(self.seed)).to(self.dev)
         self.state = torch.zeros(L.CR_STATE_FLOATS, **f32)
+        self.state[4:5].view(torch.int32)[0] = 1                      # number of the first step (see set_step)
         if training:
             self.Mom = torch.zeros(lay.n_total, **f32)
             self.Vel = torch.zeros(lay.n_total, **f32)
@@ -733,12 +734,16 @@ class Engine:
             for fac in reversed(self._bwd_factories):
                 self.bwd += fac()
             lay = self.layout
+            # the step ends inside Adam (castrec.h, state block): sums and step number are read from the snapshot the
+            # head kernel took, and the kernel zeroes the sums and advances the counter -- no cr_step_begin launch
+            snap, tsnap = self.state.data_ptr() + 4 * 8, self.state.data_ptr() + 4 * 11
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
-                            lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr())
+                            lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr(),
+                            snap, tsnap)
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
-                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total)
+                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap)
             self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
             self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
                             (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,
@@ -754,6 +759,16 @@ class Engine:
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32))
             self.ids[k].copy_(t.reshape(-1).to(torch.int32), non_blocking=True)
 
+    def set_step(self, k=1):
+        """The next launch runs as step number k (dropout keys, Adam bias correction); loss sums cleared."""
+        self.state[:4].zero_()
+        self.state[8:].zero_()
+        self.state[4:5].view(torch.int32)[0] = k
+
+    def step_number(self):
+        """Number of the step the next launch will run (1 + completed optimiser steps)."""
+        return int(self.state[4:5].view(torch.int32)[0])
+
     def _run(self, lst, stream):
         for name, fn, args in lst:
             rc = fn(*args, stream)
@@ -761,9 +776,10 @@ class Engine:
                 raise RuntimeError("castrec %s failed (%d): %s" % (name, rc, L.lib.cr_last_error().decode()))
 
     def launch_step(self, apply=True, between=None):
-        """step_begin -> forward -> backward -> [between()] -> Adam, on the current stream."""
+        """forward -> backward -> [between()] -> Adam, on the current stream.  state[4] holds the number of the step
+        being run; Adam ends the step (zeroes the loss sums, advances the counter).  Without Adam (apply=False) the
+        state is left as the kernels wrote it: call set_step() before running again."""
         s = torch.cuda.current_stream().cuda_stream
-        L.check(L.lib.cr_step_begin(self.state.data_ptr(), s), "cr_step_begin")
         self._run(self.fwd, s)
         if self.training:
             self._run(self.bwd, s)
@@ -774,9 +790,8 @@ class Engine:
 
     # ---- data-parallel pieces (castrec_amd.dist drives them around an RCCL all-reduce) ----------
     def launch_backward_to_flat(self):
-        """step_begin -> forward -> backward -> slabs collapsed into Gflat (+ loss stats in its tail)."""
+        """forward -> backward -> slabs collapsed into Gflat (+ loss stats in its tail)."""
         s = torch.cuda.current_stream().cuda_stream
-        L.check(L.lib.cr_step_begin(self.state.data_ptr(), s), "cr_step_begin")
         self._run(self.fwd, s)
         self._run(self.bwd, s)
         self._run([self._reduce], s)
@@ -838,4 +853,4 @@ class Engine:
         return {k: self.layout.view(flat, k).clone() for k in self.layout.logical_names()}
 
     def n_launches(self):
-        return 1 + len(self.fwd) + len(self.bwd) + (1 if self.training else 0)
+        return len(self.fwd) + len(self.bwd) + (1 if self.training else 0)

@@ -25,7 +25,7 @@ c_u32 = C.c_uint32
 c_p = C.c_void_p
 
 CR_MAX_BATCH = 4
-CR_STATE_FLOATS = 8
+CR_STATE_FLOATS = 16
 ELT_COPY, ELT_ADD, ELT_DROPOUT, ELT_RELU_BWD, ELT_ROWMASK, ELT_GRADPREP = 0, 1, 2, 3, 4, 5
 
 
@@ -111,7 +111,7 @@ class HeadDesc(C.Structure):
 class AdamDesc(C.Structure):
     _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
                 ("n_table", c_i), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
-                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p)]
+                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p)]
 
 
 def _sig(name, restype, argtypes):

@@ -38,7 +38,7 @@ class _Model(object):
                                  n_slabs=self._n_slabs, batch_global=self._batch_global, row_offset=self._row_offset)
             if self._graph and self._batch_global is None:
                 self._train.capture()
-                self._train.state.zero_(); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
+                self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
         if self._train.B != B:
             raise ValueError("batch size changed from %d to %d (static graph)" % (self._train.B, B))
         return self._train
@@ -95,7 +95,12 @@ class _Model(object):
             raise ValueError("checkpoint %s does not match model %s" % (path, self.name))
         self._owner.P.copy_(d["P"])
         if "M" in d and self._train is not None:
-            self._train.Mom.copy_(d["M"]); self._train.Vel.copy_(d["V"]); self._train.state.copy_(d["state"])
+            self._train.Mom.copy_(d["M"]); self._train.Vel.copy_(d["V"])
+            st = d["state"]
+            if st.numel() == self._train.state.numel():
+                self._train.state.copy_(st)
+            else:                                        # 8-float state of earlier files: [4] counted COMPLETED steps
+                self._train.set_step(int(st[4:5].view(torch.int32)[0]) + 1)
 
     def load_tf_checkpoint(self, prefix):
         """Loads a checkpoint written by the reference (tf.train.Saver bundle `<prefix>.index` +

@@ -126,9 +126,10 @@ def test_logits(seq_emb, ld, table, cand, B, T, D, logits):
 
 
 def adam_step(p, m, v, table_grad, dense_slabs, n_table, n_dense, n_slabs, lr, state, beta1=0.9, beta2=0.98, eps=1e-8,
-              stats=None):
+              stats=None, step_snapshot=None):
     d = L.AdamDesc(_p(p), _p(m), _p(v), _p(table_grad), _p(dense_slabs), n_table, n_dense, n_slabs, lr, beta1, beta2,
-                   eps, _p(state), _p(stats) if stats is not None else None)
+                   eps, _p(state), _p(stats) if stats is not None else None,
+                   _p(step_snapshot) if step_snapshot is not None else None)
     L.call("cr_adam_step", C.byref(d), _stream())
 
 

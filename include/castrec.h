@@ -38,7 +38,7 @@ extern "C" {
 #define CR_ERR_HIP (-3)         /* HIP runtime error (launch failure ...) */
 
 #define CR_MAX_BATCH 4          /* problems per batched GEMM launch */
-#define CR_STATE_FLOATS 8       /* device state block, see cr_step_begin */
+#define CR_STATE_FLOATS 16      /* device state block, see cr_step_begin */
 
 int cr_version(void);
 const char* cr_last_error(void);
@@ -58,7 +58,13 @@ typedef struct {
 /* state (device, CR_STATE_FLOATS floats):
  *   [0] loss_sum  [1] auc_sum  [2] n_target  (accumulated by cr_head_fwd_bwd)
  *   [3] reserved  [4] step counter (uint32 bits)  [5] loss  [6] auc (written by cr_adam_step)
- * cr_step_begin zeroes [0..3] and increments [4]; call it first in every step. */
+ *   [8] [9] [10] copies of [0] [1] [2] and [11] a copy of [4], taken by the LAST workgroup of cr_head_fwd_bwd(_ln)
+ *   to finish (ticket in [12]): a consistent snapshot that later kernels may read while [0..4] move on.
+ * Two ways to drive a step:
+ *   - cr_step_begin first (zeroes [0..3], increments [4]), cr_adam_step with step_snapshot == NULL; or
+ *   - no cr_step_begin: [4] holds the number of the CURRENT step (1 for the first), cr_adam_step gets
+ *     step_snapshot = state + 11 (and stats = state + 8 or the all-reduced copy) and, when done, zeroes [0..3] and
+ *     sets [4] to the next step -- one kernel boundary per step less. */
 int cr_step_begin(float* state, void* stream);
 
 /* ---- embedding gather (modules.py:83-164 `embedding`, sasrec.py:27-62, cast_1.py:86-91) */
@@ -315,6 +321,8 @@ typedef struct {
     float lr, beta1, beta2, eps;
     float* state;
     const float* stats;               /* optional [3] */
+    const uint32_t* step_snapshot;    /* optional: step number t is read from here instead of state[4], and the kernel
+                                         ends the step: state[0..3] = 0, state[4] = t + 1 (see the state block above) */
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 

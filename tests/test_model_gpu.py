@@ -104,7 +104,7 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused):
         assert rel(eng.seq_emb, out["seq_emb"].reshape(B * T, -1)) < 2e-5
         # now apply Adam on both sides (engine: re-run the step with the update; grads are recomputed)
         eng.Gt.zero_()
-        eng.state[4:5].view(torch.int32)[0] = step - 1
+        eng.set_step(step)
         eng.launch_step(apply=True)
         torch.cuda.synchronize()
         P = opt.step(P, G)
@@ -250,7 +250,7 @@ def test_graph_replay_equals_eager(E):
         b.train_step(*batch)
     torch.cuda.synchronize()
     la, lb = a.loss_auc(), b.loss_auc()
-    assert la[0] == pytest.approx(lb[0], rel=1e-3) and int(b.state[4:5].view(torch.int32)[0]) == 4
+    assert la[0] == pytest.approx(lb[0], rel=1e-3) and b.step_number() == 5
 
 
 def test_trained_reference_weights_at_the_headline_shape(E):

@@ -30,7 +30,7 @@ def relerr(got, want):
 
 
 def new_state(step=0):
-    st = torch.zeros(8, dtype=torch.float32, device="cuda")
+    st = torch.zeros(16, dtype=torch.float32, device="cuda")          # CR_STATE_FLOATS
     st[4:5].view(torch.int32)[0] = step
     return st
 
@@ -348,7 +348,7 @@ def test_head_fwd_bwd_and_test_logits(ops):
     loss_sum = (-torch.log(torch.sigmoid(pl) + 1e-24) * ist - torch.log(1 - torch.sigmoid(nl) + 1e-24) * ist).sum()
     loss_sum.backward()
     auc_sum = float((((torch.sign(pl - nl) + 1) / 2) * ist).sum())
-    state = new_state()
+    state = new_state(step=7)
     ds = torch.full((M, D), float("nan"), device="cuda"); tg = torch.zeros(V, D, device="cuda")
     plg = torch.empty(M, device="cuda"); nlg = torch.empty(M, device="cuda")
     sd, tabd, posd, negd = dev(s), dev(table), dev(pos, torch.int32), dev(neg, torch.int32)
@@ -362,6 +362,8 @@ def test_head_fwd_bwd_and_test_logits(ops):
     got = state.cpu().numpy()
     assert got[0] == pytest.approx(float(loss_sum), rel=2e-6)
     assert got[1] == pytest.approx(auc_sum) and got[2] == float(ist.sum())
+    # snapshot taken by the last workgroup to finish: the totals, the step counter, ticket re-armed (castrec.h state block)
+    assert tuple(got[8:11]) == tuple(got[0:3]) and got[8:12].view(np.uint32)[3] == 7 and got[12:13].view(np.uint32)[0] == 0
     assert relerr(plg, pl.detach().numpy()) < 2e-6 and relerr(nlg, nl.detach().numpy()) < 2e-6
     assert relerr(ds, st_.grad.numpy()) < 3e-6
     assert relerr(tg, tb.grad.numpy()) < 3e-6
@@ -370,7 +372,7 @@ def test_head_fwd_bwd_and_test_logits(ops):
     assert relerr(lg, np.einsum("bd,bjd->bj", last, tzn[cand.astype(np.int64)])) < 2e-6
 
 
-@pytest.mark.parametrize("external_stats", [False, True])
+@pytest.mark.parametrize("external_stats", [False, True, "self_advancing"])
 def test_adam_tf_three_steps_with_slabs(ops, external_stats):
     """external_stats: {loss_sum, auc_sum, n_target} come from a separate buffer (the all-reduced bucket tail of the
     data-parallel path) while state[0..2] hold this rank's local values, which must then be ignored."""
@@ -385,23 +387,34 @@ def test_adam_tf_three_steps_with_slabs(ops, external_stats):
     state = new_state()
     for step in range(3):
         g = rs.standard_normal(nt + nd); n_target = float(rs.randint(5, 50))
-        ops.step_begin(state)
+        self_adv = external_stats == "self_advancing"
+        if self_adv:
+            # no cr_step_begin: state[4] already holds this step's number, sums and step come from the snapshot
+            # (state[8..11], normally written by the head kernel), and Adam ends the step itself
+            if step == 0:
+                state[4:5].view(torch.int32)[0] = 1
+            assert float(state[:4].abs().max()) == 0.0           # left clean by the previous step's Adam
+        else:
+            ops.step_begin(state)
         state[0] = 3.5 * n_target; state[1] = 0.25 * n_target; state[2] = n_target
-        stats = None
-        if external_stats:
+        stats, snap = None, None
+        if self_adv:
+            state[8:11] = state[:3]; state[11:12].view(torch.int32)[0] = step + 1
+            stats, snap = state[8:11], state[11:12]
+        elif external_stats:
             stats = state[:3].clone()
             state[0] = -1.0; state[1] = -2.0; state[2] = 1.0
         tg.copy_(dev(g[:nt] * n_target))                            # un-normalised gradients
         parts = rs.dirichlet(np.ones(ns), nd).T * (g[nt:] * n_target)[None]
         slabs.copy_(dev(parts))
-        ops.adam_step(p, m, v, tg, slabs, nt, nd, ns, 1e-3, state, stats=stats)
+        ops.adam_step(p, m, v, tg, slabs, nt, nd, ns, 1e-3, state, stats=stats, step_snapshot=snap)
         torch.cuda.synchronize()
         P = opt.step(P, {"w": torch.tensor(g)})
         assert relerr(p, P["w"].numpy()) < 1e-6
         assert float(tg.abs().max()) == 0.0                         # table grad zeroed for the next step
         s = state.cpu().numpy()
         assert s[5] == pytest.approx(3.5, rel=1e-6) and s[6] == pytest.approx(0.25, rel=1e-6)
-        assert int(state[4:5].view(torch.int32)[0]) == step + 1
+        assert int(state[4:5].view(torch.int32)[0]) == step + (2 if self_adv else 1)     # self-advancing: the NEXT step's number
 
 
 def test_graph_capture_replay(ops):

@@ -22,7 +22,7 @@ for b in range(B): ids[b, T - lens[b]:] = 1
 idd = torch.tensor(ids.reshape(-1), device="cuda")
 kv = torch.tensor((ids != 0).astype(np.float32).reshape(-1), device="cuda")
 qv = kv.clone()
-state = torch.zeros(8, device="cuda")
+state = torch.zeros(16, device="cuda")
 drop = O.Drop(0.2, 1, state)
 desc = O.attn_desc(Q, K, V, D, kv, qv, R, D, out, D, B, T, H, d, rng=drop.rng(3), dead_ids=idd)
 stats = torch.empty(H * B * T * 4, device="cuda")

@@ -7,7 +7,7 @@ from castrec_amd import ops as O, lib as L
 B, T, D = 128, 200, 50
 M = B * T
 f = lambda *s: torch.randn(*s, device="cuda")
-state = torch.zeros(8, device="cuda")
+state = torch.zeros(16, device="cuda")
 drop = O.Drop(0.2, 1, state)
 ids = torch.randint(0, 5, (M,), device="cuda", dtype=torch.int32)
 x, q_in, qkv, kv, qv, o, f_in, hid, y = f(M, D), f(M, D), f(M, 3 * D), f(M), f(M), f(M, D), f(M, D), f(M, D), f(M, D)

@@ -33,7 +33,7 @@ def timeit(name, fn, reps=50, flops=None, bytes_=None):
     print("%-34s %8.1f us  %s" % (name, us, extra), flush=True)
 
 
-state = torch.zeros(8, device=dev)
+state = torch.zeros(16, device=dev)
 drop = O.Drop(0.2, 1, state)
 x, y, w, b, r = f(M, D), f(M, D), f(D, D), f(D), f(M, D)
 ids = torch.randint(0, 5, (M,), device=dev, dtype=torch.int32)
