@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         __syncthreads();
         if (base == mb) BK_TSG(gm, 10);
     }
-    BK_TSG(gm, 15);
+    BK_TSG(gm, 14);
     // fold the groups' weight-gradient strips through LDS (group 1's tile area is free now), fixed order
     if (NG == 2) {
         float* xch = sb + 256 * NG + (3 * 64 * F3_P + 64);         // group 1's tiles: 12736 floats >= 4 * 34 * 64
@@ -949,6 +949,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         if (ones < 0 && threadIdx.x < D) { bd.g_b1[so + threadIdx.x] = b1s; bd.g_b2[so + threadIdx.x] = b2s; }
     }
     store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
+    BK_TSG(gm, 15);
 }
 
 // ---- B1: backward of LN1 + Q/K/V projections --------------------------------------------------------------
@@ -1113,22 +1114,27 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         }
         if (base == mb) BK_TSG(gm, 9);
     }
-    BK_TSG(gm, 15);
-    // fold the groups' weight-gradient strips through LDS (group 1's tile area), fixed order, two rounds
+    BK_TSG(gm, 14);
+    // fold the groups' weight-gradient strips through LDS (group 1's tile area: 12672 floats), fixed order, ONE
+    // exchange for all three accumulators: 4 waves x 48 rows x 64 lanes = 12288 floats, the three bias column sums
+    // (D == 64 only; held by the first wave of a group) behind them.  (Two rounds with five barriers measured the same.)
     if (NG == 2) {
         __syncthreads();
-        float* xch = sb + 256 * NG + (3 * 64 * F3_P);              // 12672 floats >= 4 * 35 * 64
+        float* xch = sb + 256 * NG + (3 * 64 * F3_P);
         if (grp == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    xch[((w4 * 35 + 4 * j + r) * 64) + lane] = awq[j][r];
-                    xch[((w4 * 35 + 16 + 4 * j + r) * 64) + lane] = awk[j][r];
+                    xch[((w4 * 48 + 4 * j + r) * 64) + lane] = awq[j][r];
+                    xch[((w4 * 48 + 16 + 4 * j + r) * 64) + lane] = awk[j][r];
+                    xch[((w4 * 48 + 32 + 4 * j + r) * 64) + lane] = awv[j][r];
                 }
-            xch[(w4 * 35 + 32) * 64 + lane] = bqs;
-            xch[(w4 * 35 + 33) * 64 + lane] = bks;
-            xch[(w4 * 35 + 34) * 64 + lane] = bvs;
+            if (w4 == 0) {
+                xch[12288 + lane] = bqs;
+                xch[12288 + 64 + lane] = bks;
+                xch[12288 + 128 + lane] = bvs;
+            }
         }
         __syncthreads();
         if (grp == 0) {
@@ -1136,26 +1142,15 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    awq[j][r] += xch[((w4 * 35 + 4 * j + r) * 64) + lane];
-                    awk[j][r] += xch[((w4 * 35 + 16 + 4 * j + r) * 64) + lane];
+                    awq[j][r] += xch[((w4 * 48 + 4 * j + r) * 64) + lane];
+                    awk[j][r] += xch[((w4 * 48 + 16 + 4 * j + r) * 64) + lane];
+                    awv[j][r] += xch[((w4 * 48 + 32 + 4 * j + r) * 64) + lane];
                 }
-            bqs += xch[(w4 * 35 + 32) * 64 + lane];
-            bks += xch[(w4 * 35 + 33) * 64 + lane];
-            bvs += xch[(w4 * 35 + 34) * 64 + lane];
-        }
-        __syncthreads();
-        if (grp == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xch[((w4 * 16 + 4 * j + r) * 64) + lane] = awv[j][r];
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) awv[j][r] += xch[((w4 * 16 + 4 * j + r) * 64) + lane];
+            if (w4 == 0) {
+                bqs += xch[12288 + lane];
+                bks += xch[12288 + 64 + lane];
+                bvs += xch[12288 + 128 + lane];
+            }
         }
     }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
@@ -1170,6 +1165,7 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         }
     }
     store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
+    BK_TSG(gm, 15);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------

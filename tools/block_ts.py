@@ -51,11 +51,11 @@ def timeline(entry, desc, nwg, names):
     print("==", entry, " waves", int(live.sum()), " span (first start -> last end stamp) %.1f us" % (end.max() / 1e3))
     print("wave start  ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(start, [10, 50, 90, 100])))
     print("wave life   ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(end - start, [10, 50, 90, 100])))
-    used = [i for i in range(1, 15) if (t[:, :, i][live] > 0).mean() > 0.5]
+    used = [i for i in range(1, 15) if (t[:, :, i][live] > 0).mean() > 0.5]   # slots 0 and 15 are wall-clock stamps (span), 1..14 s_memtime
     for a, b in zip(used[:-1], used[1:]):
         dlt = (t[:, :, b] - t[:, :, a])[live]
         print("  stamp %2d -> %2d  %-34s median %6.0f ticks (%.2f us)  p90 %6.0f" % (a, b, names.get((a, b), ""), np.median(dlt), np.median(dlt) * 0.46e-3, np.percentile(dlt, 90)))
 
 timeline("cr_block_ln_qkv_fwd", bd, (M + 63) // 64, {(1, 2): "issue loads", (2, 3): "barrier wait", (3, 4): "LN + q_in store", (4, 5): "Q proj + store", (5, 6): "K,V proj + store"})
-timeline("cr_block_ln_qkv_bwd", bb, NS, {(1, 2): "weights + streams issued + weights->LDS", (2, 3): "phase-1 puts", (3, 4): "barrier", (4, 5): "wgrad q + dq_in mma", (5, 6): "barrier + phase 2 (dK, x) puts + wgrad k + mma", (6, 7): "barrier + phase 3 (dV) + wgrad v + mma", (7, 8): "barrier", (8, 9): "phase 4: LN1 bwd + store"})
-timeline("cr_block_ln_ffn_bwd", bb, NS, {(1, 2): "issue weight + stream loads", (2, 3): "weights -> LDS", (3, 4): "mask + zero rows", (4, 5): "put g2", (5, 6): "put hid, f_in", (6, 7): "barrier + wgrad2 + barrier", (7, 8): "dhid + gate + barrier", (8, 9): "wgrad1 + df + barrier", (9, 10): "LN2 bwd + store + barrier"})
+timeline("cr_block_ln_qkv_bwd", bb, NS, {(1, 2): "weights + streams issued + weights->LDS", (2, 3): "phase-1 puts", (3, 4): "barrier", (4, 5): "wgrad q + dq_in mma", (5, 6): "barrier + phase 2 (dK, x) puts + wgrad k + mma", (6, 7): "barrier + phase 3 (dV) + wgrad v + mma", (7, 8): "barrier", (8, 9): "phase 4: LN1 bwd + store", (9, 14): "to the start of the group fold + slab stores"})
+timeline("cr_block_ln_ffn_bwd", bb, NS, {(1, 2): "issue weight + stream loads", (2, 3): "weights -> LDS", (3, 4): "mask + zero rows", (4, 5): "put g2", (5, 6): "put hid, f_in", (6, 7): "barrier + wgrad2 + barrier", (7, 8): "dhid + gate + barrier", (8, 9): "wgrad1 + df + barrier", (9, 10): "LN2 bwd + store + barrier", (10, 14): "to the start of the group fold + slab stores"})
