@@ -267,19 +267,38 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
             ab[i] += __shfl_xor(ab[i], o, 64);
         }
     }
-    for (int w = 0; w < 16; ++w) {
-        if (wave == w && sub == 0) {
+    if (LPR == 16) {                                     // per-wave slots + one barrier, as in cr_layernorm.hip
+        __shared__ float wg[16][64], wb[16][64];
+        if (sub == 0) {
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = l + LPR * i;
-                if (c < d.D) { sg[c] += ag[i]; sb[c] += ab[i]; }
+                if (c < 64) { wg[wave][c] = ag[i]; wb[wave][c] = ab[i]; }
             }
         }
         __syncthreads();
-    }
-    for (int c = threadIdx.x; c < d.D; c += 1024) {
-        n.dgamma[(size_t)blockIdx.x * n.slab_stride + c] = sg[c];
-        n.dbeta[(size_t)blockIdx.x * n.slab_stride + c] = sb[c];
+        if ((int)threadIdx.x < d.D) {
+            float g = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { g += wg[w][threadIdx.x]; b += wb[w][threadIdx.x]; }
+            n.dgamma[(size_t)blockIdx.x * n.slab_stride + threadIdx.x] = g;
+            n.dbeta[(size_t)blockIdx.x * n.slab_stride + threadIdx.x] = b;
+        }
+    } else {
+        for (int w = 0; w < 16; ++w) {
+            if (wave == w && sub == 0) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = l + LPR * i;
+                    if (c < d.D) { sg[c] += ag[i]; sb[c] += ab[i]; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int c = threadIdx.x; c < d.D; c += 1024) {
+            n.dgamma[(size_t)blockIdx.x * n.slab_stride + c] = sg[c];
+            n.dbeta[(size_t)blockIdx.x * n.slab_stride + c] = sb[c];
+        }
     }
     head_snapshot(d.state);
 }
