@@ -72,11 +72,8 @@ extern "C" int cr_layernorm_fwd(const cr_ln_desc* d, void* stream) {
 template <int LPR, int MAXC>
 __global__ __launch_bounds__(1024) void k_ln_bwd(cr_ln_bwd_desc d) {
     constexpr int RPW = 64 / LPR;
-    __shared__ float sg[512], sb[512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, l = lane % LPR;
-    for (int c = threadIdx.x; c < d.D; c += 1024) { sg[c] = 0.0f; sb[c] = 0.0f; }
-    __syncthreads();
     const int rps = (d.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
     float g[MAXC], ag[MAXC], ab[MAXC];
@@ -167,19 +164,26 @@ __global__ __launch_bounds__(1024) void k_ln_bwd(cr_ln_bwd_desc d) {
         }
         return;
     }
-    for (int w = 0; w < 16; ++w) {                       // serialised on purpose: 16 x D adds, fixed order
-        if (wave == w && sub == 0) {
+    // D <= 512: the same with [16][512] slots, gamma and beta one after the other through one 32 KiB array
+    __shared__ float wide[16][512];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (sub == 0) {
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = l + LPR * i;
-                if (c < d.D) { sg[c] += ag[i]; sb[c] += ab[i]; }
+                if (c < 512) wide[wave][c] = pass == 0 ? ag[i] : ab[i];
             }
         }
         __syncthreads();
-    }
-    for (int c = threadIdx.x; c < d.D; c += 1024) {
-        d.dgamma[(size_t)blockIdx.x * d.slab_stride + c] = sg[c];
-        d.dbeta[(size_t)blockIdx.x * d.slab_stride + c] = sb[c];
+        float* dst = pass == 0 ? d.dgamma : d.dbeta;
+        for (int c = threadIdx.x; c < d.D; c += 1024) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) v += wide[w][c];
+            dst[(size_t)blockIdx.x * d.slab_stride + c] = v;
+        }
+        __syncthreads();
     }
 }
 
