@@ -549,19 +549,21 @@ __global__ __launch_bounds__(256) void k_block_ln_ffn_fwd(cr_block_desc d, Block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int mw = m0 + 16 * wave;                                  // first row of this wave
     const int nr = max(0, min(16, d.M - mw));                       // its valid rows
-    wave_load_rows(Os + 16 * wave * F3_P, d.o + (size_t)mw * D, F3_P, D, nr, g.invD);
-    {
+    {   // every global request of the prologue is issued before the first one is consumed
+        Stream4 so;
+        stream_fetch(so, d.o + (size_t)mw * D, D, nr * D);
         WFrag wa, wb;
         fetch_w(wa, d.w1, D, 0, D);
         fetch_w(wb, d.w2, D, 0, D);
-        put_w_packed(W1s, wa, D, 4 * g.ks);
-        put_w_packed(W2s, wb, D, 4 * g.ks);
-    }
-    {
         const int t = threadIdx.x, c = t & 63, which = t >> 6;
         const float* src = which == 0 ? d.ln2_g : (which == 1 ? d.ln2_b : (which == 2 ? d.b1 : d.b2));
-        vec[t] = (c < D) ? src[c] : 0.0f;
-        if (t < 64) msk[t] = (m0 + t < d.M && d.mask_ids[m0 + t] != 0) ? 1.0f : 0.0f;
+        const float vv = src[c < D ? c : 0];
+        const int mk = (t < 64 && m0 + t < d.M) ? d.mask_ids[m0 + t] : 0;
+        stream_put(Os + 16 * wave * F3_P, so, D, nr * D, g.invD, PutPlain());
+        put_w_packed(W1s, wa, D, 4 * g.ks);
+        put_w_packed(W2s, wb, D, 4 * g.ks);
+        vec[t] = (c < D) ? vv : 0.0f;
+        if (t < 64) msk[t] = mk != 0 ? 1.0f : 0.0f;
     }
     float lng[4], lnb[4];                                           // TAIL 2: final LayerNorm gamma / beta of this lane's columns
     if (TAIL == 2) {
