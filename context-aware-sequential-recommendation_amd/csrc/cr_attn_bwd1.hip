@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const DropCtx dc = drop_ctx(d.drop);                // reads the step counter: requested first, needed late
+    AT_TS(0); AT_TS(1);
     TileSched sch = sched_init(nw, wave);
     int kt = sched_rank(sch);                           // key tile 0 meets every query tile: rank == kt
     float kn[NDS], vn[NDS];                             // K / V fragments of the wave's next key tile
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
     const f4s st0 = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)blockIdx.x * T + t0c) * 4);
     const float qv0 = d.q_valid[base_row + t0c];
     const float dl0 = bd.delta[base_row + t0c];
+    // dQ accumulator cleared while the fragment / statistics requests above are in flight (16-byte LDS stores; the
+    // block is a multiple of 4 floats and 16-byte aligned), then the Q / dOut staging
+    for (int i = threadIdx.x; i < (g.T16 * KPA) >> 2; i += blockDim.x) reinterpret_cast<float4*>(dQs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     stage_pair<NDS>(Qs, KPA, d.Q, d.ld, Os, KPA, bd.dout, bd.lddo, base_row, hoff, T, d.d, g.T16);
-    for (int i = threadIdx.x; i < g.T16 * KPA; i += blockDim.x) dQs[i] = 0.0f;
     auto put_stats = [&](int t, float mx_, float inv_, float flag_, float del_, float qv_) {
         const float flag = (t < T) ? flag_ : 2.0f;
         const bool normal = flag == 0.0f;
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
         const float* sp = d.row_stats + ((size_t)blockIdx.x * T + tc) * 4;
         put_stats(t, sp[0], sp[1], sp[2], bd.delta[base_row + tc], d.q_valid[base_row + tc]);
     }
+    AT_TS(2);
     __syncthreads();
+    AT_TS(3);
     for (int t = threadIdx.x; t < g.nkt; t += blockDim.x) {
         float u = 0.0f, lv = 0.0f;
         for (int i = 0; i < 16; ++i) {
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
         tile_live[t] = lv;
     }
     __syncthreads();
+    AT_TS(4);
     float* tw = Tw + wave * 16 * B1_TP;
     const int nrounds = (g.nkt + (int)gridDim.y * nw - 1) / ((int)gridDim.y * nw);   // same for every wave: barriers inside
     for (int round = 0; round < nrounds; ++round, kt = sched_next(sch)) {
@@ -204,7 +210,10 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
             }
             }
             __syncthreads();
+            if (round == 0 && step == 0) AT_TS(5);
+            if (round == 0 && step == 5) AT_TS(6);
         }
+        if (round == 0) AT_TS(7);
         if (!have) continue;
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) {
@@ -218,7 +227,9 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
             }
         }
     }
+    AT_TS(8);
     __syncthreads();
+    AT_TS(9);
     // this workgroup's partial dQ: row-chunk stores (16 bytes per lane)
     float* gq = (blockIdx.y == 0) ? bd.dQ : bd.dQ_part;
     typedef float f4q __attribute__((ext_vector_type(4), aligned(4)));
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(64 * A_MAX_WAVES) void k_attn_bwd_one(cr_attn_bwd_d
             bd.dQ_part[(size_t)(base_row + r) * bd.ldg + hoff + c] = 0.0f;
         }
     }
+    AT_TS(15);
 }
 
 static size_t lds_bwd_one(const AttnGeom& g, int w) {
@@ -255,7 +267,9 @@ static int launch_bwd_one(const cr_attn_bwd_desc* bd, const AttnGeom& g, int wav
         int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_attn_bwd_one<NDS, NDT>), &attr_set);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_attn_bwd_one<NDS, NDT>), dim3(bd->f.B * bd->f.H, nsplit), dim3(64 * waves), lds_bwd_one(g, waves), s, *bd, g);
+    AttnGeom gg = g;
+    if (g_attn_ts_which != 3) gg.ts = nullptr;
+    hipLaunchKernelGGL((k_attn_bwd_one<NDS, NDT>), dim3(bd->f.B * bd->f.H, nsplit), dim3(64 * waves), lds_bwd_one(g, waves), s, *bd, gg);
     return cr_check_launch("cr_attn_bwd(single pass)");
 }
 

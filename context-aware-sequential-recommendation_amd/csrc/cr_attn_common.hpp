@@ -49,7 +49,7 @@ struct AttnGeom {
                 ((slot) == 0 || (slot) == 15) ? wall_clock64() : clock64();                                  \
     } while (0)
 extern unsigned long long* g_attn_ts;
-extern int g_attn_ts_which;   // 0 = forward, 1 = backward (query-owner), 2 = backward (key-owner)
+extern int g_attn_ts_which;   // 0 = forward, 1 = backward (query-owner), 2 = backward (key-owner), 3 = single-pass backward
 #else
 #define AT_TS(slot) do { } while (0)
 static unsigned long long* const g_attn_ts = nullptr;

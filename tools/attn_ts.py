@@ -26,11 +26,18 @@ state = torch.zeros(16, device="cuda")
 drop = O.Drop(0.2, 1, state)
 desc = O.attn_desc(Q, K, V, D, kv, qv, R, D, out, D, B, T, H, d, rng=drop.rng(3), dead_ids=idd)
 stats = torch.empty(H * B * T * 4, device="cuda")
+row_stats = torch.empty(H * B * T * 4, device="cuda")
+desc.row_stats = row_stats.data_ptr()
+delta, dQp = f(M), f(M, D)
+ONE = os.environ.get("ONE_PASS", "1") == "1"
 fn = getattr(L._lib, "cr_debug_attn_ts"); fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = None
 
 def run():
     O.attn_fwd(desc)
-    O.attn_bwd(desc, dO, D, dQ, dK, dV, D, stats)
+    if ONE:
+        O.attn_bwd(desc, dO, D, dQ, dK, dV, D, stats, delta=delta, dQ_part=dQp)
+    else:
+        O.attn_bwd(desc, dO, D, dQ, dK, dV, D, stats)
 
 def timeline(which, title, names):
     ts = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
@@ -76,5 +83,10 @@ def fine_fwd():
 if FINE:
     fine_fwd(); sys.exit(0)
 timeline(0, "attn fwd", {(1, 2): "issue frag + K/V staging", (2, 3): "barrier", (3, 4): "scores + softmax (tile 0)", (4, 5): "mask/dropout", (5, 6): "P V", (6, 7): "store"})
+if ONE:
+    timeline(3, "attn bwd (single pass)", {(1, 2): "issue frags, stats, Q/dO staging, zero dQ", (2, 3): "barrier", (3, 4): "tile flags + barrier",
+                                           (4, 5): "step 0 (+ frag finish)", (5, 6): "steps 1-5", (6, 7): "steps 6-12", (7, 8): "dK / dV stores",
+                                           (8, 9): "barrier"})
+    sys.exit(0)
 timeline(1, "attn bwd (query-owner)", {(1, 2): "issue frags + K/V staging", (2, 3): "barrier", (3, 4): "scores + softmax (tile 0)", (4, 5): "dP + softmax bwd", (5, 6): "dS scale + dQ mma", (6, 7): "stores"})
 timeline(2, "attn bwd (key-owner)", {(1, 2): "issue frags + Q/dO staging", (2, 3): "barrier", (3, 4): "tile flags + barrier", (4, 5): "q-tile loop (key tile 0)", (5, 6): "stores"})
