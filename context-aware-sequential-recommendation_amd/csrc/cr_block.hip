@@ -182,6 +182,40 @@ __device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, co
     }
 }
 
+// Weight-gradient strip over the tiles of NGRP tile groups at once (group g's tiles at + g * gstride): wave `wave`
+// owns k-rows [16 wave, 16 wave + 16) and the NJ n-tiles starting at n-tile NJ * half, summed over ALL rows of all
+// groups.  With two groups per workgroup (NJ = 2: each group's waves take one half of the columns) every accumulator is
+// final for its (k-strip, column-half) -- no cross-group fold through LDS, half the accumulator registers.
+template <int NJ, int NGRP, int CH = 4>
+__device__ __forceinline__ void tile_wgrad_g(f32x4 (&accw)[NJ], const float* As0, const float* Gs0, int gstride, int P,
+                                             int wave, int half) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int gi = 0; gi < NGRP; ++gi) {
+        const float* ap = As0 + gi * gstride + lg * P + 16 * wave + li;
+        const float* gp = Gs0 + gi * gstride + lg * P + 16 * NJ * half + li;
+#pragma unroll 1
+        for (int m0 = 0; m0 < 16; m0 += CH) {
+            float a[CH], b[CH][NJ];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                a[s] = ap[4 * (m0 + s) * P];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[s][j] = gp[4 * (m0 + s) * P + 16 * j];
+            }
+#pragma unroll
+            for (int s = 0; s < CH; ++s)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accw[j] = mfma16(a[s], b[s][j], accw[j]);
+        }
+    }
+}
+template <int NJ>
+__device__ __forceinline__ void zero_acc_n(f32x4 (&acc)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 // Row I/O of a wave's 16-row strip of a DENSE [M, D] matrix (ld == D) <-> its rows of a pitch-66 LDS tile.
 // An item is (row r, 4-column chunk q): lane -> q = lane & 15, r = (lane >> 4) + 4 i, i = 0..3, so one wave
 // instruction moves four 4*D-byte rows (contiguous in memory) as 16-byte pieces, dword aligned (all gfx950
@@ -679,6 +713,24 @@ __device__ __forceinline__ void store_wgrad(float* dst, int ldw, float* bias_dst
     }
 }
 
+template <int NJ>
+__device__ __forceinline__ void store_wgrad_g(float* dst, int ldw, float* bias_dst, const f32x4 (&accw)[NJ], int D, int ones,
+                                              int wave, int half) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = 16 * (NJ * half + j) + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * wave + 4 * lg + r;
+            if (col < D) {
+                if (k < D) dst[k * ldw + col] = accw[j][r];
+                else if (k == ones) bias_dst[col] = accw[j][r];
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float colsum64(const float* Ts, int col) {   // D == 64 fallback: one thread sums one column
     float s = 0.0f;
 #pragma unroll 8
@@ -795,8 +847,14 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
     const float gam_v = d.ln2_g[threadIdx.x < D ? threadIdx.x : 0];
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-    f32x4 aw1[4], aw2[4];
-    zero_acc(aw1); zero_acc(aw2);
+    // weight-gradient accumulators: with two tile groups each wave owns a k-strip x one HALF of the columns over the
+    // rows of both groups (tile_wgrad_g): final sums, no cross-group fold
+    constexpr int NJ = (NG == 2) ? 2 : 4;
+    constexpr int GST = 3 * 64 * F3_P + 64;          // LDS distance between the groups' tile sets
+    float* Tg0 = sb + 256 * NG;                       // group 0's tiles
+    const int half = (NG == 2) ? grp : 0;
+    f32x4 aw1[NJ], aw2[NJ];
+    zero_acc_n<NJ>(aw1); zero_acc_n<NJ>(aw2);
     float b1s = 0.0f, b2s = 0.0f;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     Stream4 sdy, shid, sfin;
@@ -841,8 +899,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         __syncthreads();
         if (base + 64 * NG < me) fetch(m0 + 64 * NG);              // next tile's loads fly under this tile's MFMAs
         // dW2 (+ db2 in row `ones`) += hid^T g2
-        tile_wgrad(aw2, T2, T1, F3_P, w4);
-        if (ones < 0 && gtid < 64) b2s += colsum64(T1, gtid);
+        tile_wgrad_g<NJ, NG>(aw2, Tg0 + 64 * F3_P, Tg0, GST, F3_P, w4, half);
+        if (ones < 0 && threadIdx.x < 64) {
+            b2s += colsum64(Tg0, threadIdx.x);
+            if (NG == 2) b2s += colsum64(Tg0 + GST, threadIdx.x);
+        }
         __syncthreads();
         if (base == mb) BK_TSG(gm, 7);
         // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (in place over hid, own rows)
@@ -862,8 +923,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         __syncthreads();
         if (base == mb) BK_TSG(gm, 8);
         // dW1 (+ db1) += f_in^T g1
-        tile_wgrad(aw1, T3, T2, F3_P, w4);
-        if (ones < 0 && gtid < 64) b1s += colsum64(T2, gtid);
+        tile_wgrad_g<NJ, NG>(aw1, Tg0 + 2 * 64 * F3_P, Tg0 + 64 * F3_P, GST, F3_P, w4, half);
+        if (ones < 0 && threadIdx.x < 64) {
+            b1s += colsum64(Tg0 + 64 * F3_P, threadIdx.x);
+            if (NG == 2) b1s += colsum64(Tg0 + GST + 64 * F3_P, threadIdx.x);
+        }
         // df = g1 W1^T + dy*mask  (residual of modules.py:313; g1 rows of masked positions are 0) -> T1 (own rows)
         {
             // residual dy * mask in the accumulator layout, re-read from L2 (this tile's dy was streamed a moment ago)
@@ -917,39 +981,10 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_ffn_bwd(cr_block_bwd_desc
         if (base == mb) BK_TSG(gm, 10);
     }
     BK_TSG(gm, 14);
-    // fold the groups' weight-gradient strips through LDS (group 1's tile area is free now), fixed order
-    if (NG == 2) {
-        float* xch = sb + 256 * NG + (3 * 64 * F3_P + 64);         // group 1's tiles: 12736 floats >= 4 * 34 * 64
-        if (grp == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xch[((w4 * 34 + 4 * j + r) * 64) + lane] = aw1[j][r];
-                    xch[((w4 * 34 + 16 + 4 * j + r) * 64) + lane] = aw2[j][r];
-                }
-            xch[(w4 * 34 + 32) * 64 + lane] = b1s;
-            xch[(w4 * 34 + 33) * 64 + lane] = b2s;
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    aw1[j][r] += xch[((w4 * 34 + 4 * j + r) * 64) + lane];
-                    aw2[j][r] += xch[((w4 * 34 + 16 + 4 * j + r) * 64) + lane];
-                }
-            b1s += xch[(w4 * 34 + 32) * 64 + lane];
-            b2s += xch[(w4 * 34 + 33) * 64 + lane];
-        }
-    }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    if (grp == 0) {
-        store_wgrad(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, ones, w4);
-        store_wgrad(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, ones, w4);
-        if (ones < 0 && threadIdx.x < D) { bd.g_b1[so + threadIdx.x] = b1s; bd.g_b2[so + threadIdx.x] = b2s; }
-    }
+    store_wgrad_g<NJ>(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, ones, w4, half);
+    store_wgrad_g<NJ>(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, ones, w4, half);
+    if (ones < 0 && threadIdx.x < D) { bd.g_b1[so + threadIdx.x] = b1s; bd.g_b2[so + threadIdx.x] = b2s; }
     store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
     BK_TSG(gm, 15);
 }
@@ -990,8 +1025,13 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
     fetch_w<NT, true>(vk, d.wqkv, 3 * D, D, D);
     fetch_w<NT, true>(vv, d.wqkv, 3 * D, 2 * D, D);
     const float gam_v = d.ln1_g[threadIdx.x < D ? threadIdx.x : 0];
-    f32x4 awq[4], awk[4], awv[4];
-    zero_acc(awq); zero_acc(awk); zero_acc(awv);
+    // weight-gradient accumulators as in the FFN backward: k-strip x column half over the rows of both groups
+    constexpr int NJ = (NG == 2) ? 2 : 4;
+    constexpr int GST = 3 * 64 * F3_P;               // LDS distance between the groups' tile sets
+    float* TG0 = sb + 256 * NG;                       // group 0's TG; its TA follows at + 64 * F3_P
+    const int half = (NG == 2) ? grp : 0;
+    f32x4 awq[NJ], awk[NJ], awv[NJ];
+    zero_acc_n<NJ>(awq); zero_acc_n<NJ>(awk); zero_acc_n<NJ>(awv);
     float bqs = 0.0f, bks = 0.0f, bvs = 0.0f;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     Stream4 s0, s1, s2, s3, sp;             // dQ, q_in, dK, x  (then s0, s1 again: dV, d_o); sp: second partial of dQ
@@ -1027,8 +1067,11 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         if (base == mb) BK_TSG(gm, 3);
         __syncthreads();
         if (base == mb) BK_TSG(gm, 4);
-        tile_wgrad(awq, TA, TG, F3_P, w4);
-        if (ones < 0 && gtid < 64) bqs += colsum64(TG, gtid);
+        tile_wgrad_g<NJ, NG>(awq, TG0 + 64 * F3_P, TG0, GST, F3_P, w4, half);
+        if (ones < 0 && threadIdx.x < 64) {
+            bqs += colsum64(TG0, threadIdx.x);
+            if (NG == 2) bqs += colsum64(TG0 + GST, threadIdx.x);
+        }
         f32x4 acc[4], dxa[4];
         zero_acc(acc); zero_acc(dxa);
         tile_mma<4>(acc, TG, F3_P, Wqt, ks, w4);
@@ -1039,16 +1082,22 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         stream_put(ta, s3, D, tot, gm.invD, PutPlain());
         plant_ones(ta, ones, nr);
         __syncthreads();
-        tile_wgrad(awk, TA, TG, F3_P, w4);
-        if (ones < 0 && gtid < 64) bks += colsum64(TG, gtid);
+        tile_wgrad_g<NJ, NG>(awk, TG0 + 64 * F3_P, TG0, GST, F3_P, w4, half);
+        if (ones < 0 && threadIdx.x < 64) {
+            bks += colsum64(TG0, threadIdx.x);
+            if (NG == 2) bks += colsum64(TG0 + GST, threadIdx.x);
+        }
         tile_mma<4>(dxa, TG, F3_P, Wkt, ks, w4);
         if (base == mb) BK_TSG(gm, 6);
         __syncthreads();                                           // all rows of TG (dK) have been read
         // ---- phase 3: dV -> dWv (+ dbv), dx_part += dV Wv^T
         stream_put(tg, s0, D, tot, gm.invD, PutPlain());
         __syncthreads();
-        tile_wgrad(awv, TA, TG, F3_P, w4);
-        if (ones < 0 && gtid < 64) bvs += colsum64(TG, gtid);
+        tile_wgrad_g<NJ, NG>(awv, TG0 + 64 * F3_P, TG0, GST, F3_P, w4, half);
+        if (ones < 0 && threadIdx.x < 64) {
+            bvs += colsum64(TG0, threadIdx.x);
+            if (NG == 2) bvs += colsum64(TG0 + GST, threadIdx.x);
+        }
         tile_mma<4>(dxa, TG, F3_P, Wvt, ks, w4);
         if (base == mb) BK_TSG(gm, 7);
         __syncthreads();                                           // all rows of TG (dV) and TA (x) have been read
@@ -1117,54 +1166,14 @@ __global__ __launch_bounds__(256 * NG) void k_block_ln_qkv_bwd(cr_block_bwd_desc
         if (base == mb) BK_TSG(gm, 9);
     }
     BK_TSG(gm, 14);
-    // fold the groups' weight-gradient strips through LDS (group 1's tile area: 12672 floats), fixed order, ONE
-    // exchange for all three accumulators: 4 waves x 48 rows x 64 lanes = 12288 floats, the three bias column sums
-    // (D == 64 only; held by the first wave of a group) behind them.  (Two rounds with five barriers measured the same.)
-    if (NG == 2) {
-        __syncthreads();
-        float* xch = sb + 256 * NG + (3 * 64 * F3_P);
-        if (grp == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xch[((w4 * 48 + 4 * j + r) * 64) + lane] = awq[j][r];
-                    xch[((w4 * 48 + 16 + 4 * j + r) * 64) + lane] = awk[j][r];
-                    xch[((w4 * 48 + 32 + 4 * j + r) * 64) + lane] = awv[j][r];
-                }
-            if (w4 == 0) {
-                xch[12288 + lane] = bqs;
-                xch[12288 + 64 + lane] = bks;
-                xch[12288 + 128 + lane] = bvs;
-            }
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    awq[j][r] += xch[((w4 * 48 + 4 * j + r) * 64) + lane];
-                    awk[j][r] += xch[((w4 * 48 + 16 + 4 * j + r) * 64) + lane];
-                    awv[j][r] += xch[((w4 * 48 + 32 + 4 * j + r) * 64) + lane];
-                }
-            if (w4 == 0) {
-                bqs += xch[12288 + lane];
-                bks += xch[12288 + 64 + lane];
-                bvs += xch[12288 + 128 + lane];
-            }
-        }
-    }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    if (grp == 0) {
-        store_wgrad(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, ones, w4);
-        store_wgrad(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, ones, w4);
-        store_wgrad(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, ones, w4);
-        if (ones < 0 && threadIdx.x < D) {
-            bd.g_bqkv[so + threadIdx.x] = bqs;
-            bd.g_bqkv[so + D + threadIdx.x] = bks;
-            bd.g_bqkv[so + 2 * D + threadIdx.x] = bvs;
-        }
+    store_wgrad_g<NJ>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, ones, w4, half);
+    store_wgrad_g<NJ>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, ones, w4, half);
+    store_wgrad_g<NJ>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, ones, w4, half);
+    if (ones < 0 && threadIdx.x < D) {
+        bd.g_bqkv[so + threadIdx.x] = bqs;
+        bd.g_bqkv[so + D + threadIdx.x] = bks;
+        bd.g_bqkv[so + 2 * D + threadIdx.x] = bvs;
     }
     store_ln_grads<4 * NG>(sg, sb, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
     BK_TSG(gm, 15);
