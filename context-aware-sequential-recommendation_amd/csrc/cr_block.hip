@@ -158,30 +158,9 @@ __device__ __forceinline__ void tile_mma(f32x4 (&acc)[4], const float* As, int P
     }
 }
 
-// accw[j] += sum_m As[m][16w + li] * Gs[m][16j + li] over the 64 rows of the tile (A^T G: weight-gradient
-// strip of k-rows [16w, 16w+16) owned by wave w; with a ones column in As, row `ones` is the bias gradient).
-// Operand reads batched CH steps at a time like tile_mma.
-template <int CH = 4>
-__device__ __forceinline__ void tile_wgrad(f32x4 (&accw)[4], const float* As, const float* Gs, int P, int wave) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const float* ap = As + lg * P + 16 * wave + li;
-    const float* gp = Gs + lg * P + li;
-#pragma unroll 1
-    for (int m0 = 0; m0 < 16; m0 += CH) {
-        float a[CH], b[CH][4];
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            a[s] = ap[4 * (m0 + s) * P];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[s][j] = gp[4 * (m0 + s) * P + 16 * j];
-        }
-#pragma unroll
-        for (int s = 0; s < CH; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) accw[j] = mfma16(a[s], b[s][j], accw[j]);
-    }
-}
-
+// accw[j] += sum_m As[m][16w + li] * Gs[m][16j + li] over the 64 rows of a tile (A^T G: weight-gradient strip of
+// k-rows [16w, 16w+16) owned by wave w; with a ones column in As, row `ones` is the bias gradient).  Operand reads
+// batched CH steps at a time like tile_mma.
 // Weight-gradient strip over the tiles of NGRP tile groups at once (group g's tiles at + g * gstride): wave `wave`
 // owns k-rows [16 wave, 16 wave + 16) and the NJ n-tiles starting at n-tile NJ * half, summed over ALL rows of all
 // groups.  With two groups per workgroup (NJ = 2: each group's waves take one half of the columns) every accumulator is
@@ -697,22 +676,6 @@ __device__ __forceinline__ void zero_rows(float* Ts) {
 
 // strip of a [D,D] weight gradient held as (wave, lg, r) x (j, li) accumulators -> slab (row pitch ldw);
 // with the ones-column trick accumulator row `ones` (== D) is the bias gradient
-__device__ __forceinline__ void store_wgrad(float* dst, int ldw, float* bias_dst, const f32x4 (&accw)[4], int D, int ones, int wave) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = 16 * j + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 16 * wave + 4 * lg + r;
-            if (col < D) {
-                if (k < D) dst[k * ldw + col] = accw[j][r];
-                else if (k == ones) bias_dst[col] = accw[j][r];
-            }
-        }
-    }
-}
-
 template <int NJ>
 __device__ __forceinline__ void store_wgrad_g(float* dst, int ldw, float* bias_dst, const f32x4 (&accw)[NJ], int D, int ones,
                                               int wave, int half) {
