@@ -220,7 +220,7 @@ int cr_attn_bwd(const cr_attn_bwd_desc* d, void* stream);
 /* ---- fused row-phase kernels of one transformer block, hidden size D <= 64 ---------------------
  * The block of sasrec.py:65-83 is, apart from the attention core, row-local: a 64-row tile of the
  * activations stays in LDS across LayerNorm -> projections (and back).  These four entry points replace
- * chains of cr_layernorm / cr_gemm_rows / cr_eltwise / cr_gemm_wgrad launches; results are identical.
+ * chains of cr_layernorm / cr_gemm_rows / cr_eltwise / cr_gemm_wgrad launches; same results up to fp32 rounding.
  *   cr_block_ln_qkv_fwd : q_in = LN1(x) (+ key/query masks); Q = q_in Wq + bq; K = x Wk + bk; V = x Wv + bv
  *   cr_block_ln_ffn_fwd : f_in = LN2(o); hid = drop(relu(f_in W1 + b1)); y = (drop(hid W2 + b2) + f_in) * mask
  *   cr_block_ln_ffn_bwd : dy -> d_o, and slabs of dW2 db2 dW1 db1 dgamma2 dbeta2
@@ -245,13 +245,14 @@ int cr_block_ln_ffn_fwd(const cr_block_desc* d, void* stream);
 /* cr_block_ln_qkv_fwd of a stack's FIRST block with the stack input composed in the same kernel: `e` is the
  * cr_embed_fwd call that would have produced d->x (sasrec.py:27-62 / cast_1.py:30-38,86-91); it must describe
  * exactly that matrix (e->out == d->x, ld_out == D, col_off == 0, same M and D).  x is still written (the backward
- * and the residual read it); results are identical to cr_embed_fwd followed by cr_block_ln_qkv_fwd. */
+ * and the residual read it); results equal cr_embed_fwd followed by cr_block_ln_qkv_fwd. */
 int cr_block_ln_qkv_fwd_gather(const cr_block_desc* d, const cr_embed_desc* e, void* stream);
 
 /* cr_block_ln_ffn_fwd with a tail stage applied to the output rows while they are still on chip:
  *   kind 1: the NEXT block's cr_block_ln_qkv_fwd (next->x must be this block's y) -- one launch per block boundary less;
  *   kind 2: the stack's final LayerNorm (sasrec.py:85): out[:, col_out : col_out + D] = LN(y; lnf_gamma, lnf_beta).
- * y is written in both cases (the backward needs it); results are identical to the separate calls. */
+ * y is written in both cases (the backward needs it); results equal the separate calls up to fp32 rounding
+ * (the final LayerNorm divides by the standard deviation here, cr_layernorm_fwd multiplies by its reciprocal). */
 typedef struct {
     int kind;                                  /* 0 none, 1 next block's LN1 + QKV, 2 final LayerNorm */
     const cr_block_desc* next;                 /* kind 1 */
@@ -280,7 +281,7 @@ int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
  * descriptor that call would have taken (sc->f.out is ignored; no small-table slabs; d_addend dense [M, D]);
  * bd->dx may be NULL and bd->dx_accumulate must be 0.  One difference: sc->pos_grad is ACCUMULATED with float
  * atomics here (cr_embed_bwd writes it), so it must be zero on entry -- cr_adam_step leaves the table section
- * zeroed.  Otherwise results are identical to cr_block_ln_qkv_bwd followed by cr_embed_bwd up to the order of the
+ * zeroed.  Otherwise results equal cr_block_ln_qkv_bwd followed by cr_embed_bwd up to the order of the
  * float atomics. */
 int cr_block_ln_qkv_bwd_scatter(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, void* stream);
 
@@ -299,8 +300,8 @@ int cr_head_fwd_bwd(const cr_head_desc* d, void* stream);
 
 /* cr_head_fwd_bwd with the backward of the LayerNorm that produced seq_emb (sasrec.py:85) applied to each gradient
  * row while it is still in registers: `n` is the cr_layernorm_bwd call that would have followed (n->dy is ignored,
- * n->accumulate must be 0); d->d_seq_emb may be NULL (the gradient row is then never stored).  Results are identical
- * to cr_head_fwd_bwd followed by cr_layernorm_bwd. */
+ * n->accumulate must be 0); d->d_seq_emb may be NULL (the gradient row is then never stored).  Results equal
+ * cr_head_fwd_bwd followed by cr_layernorm_bwd. */
 int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream);
 
 /* test_logits (sasrec.py:93-97): logits[b, j] = seq_emb[b*T + T-1, :] . table'[cand[b, j], :] */

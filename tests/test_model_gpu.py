@@ -179,6 +179,38 @@ def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     _other_shapes(E, "cast_1", 50, 1, 40, 2)
 
 
+@pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_NO_EMBED_FUSION", "CASTREC_NO_HEAD_LN"])
+@pytest.mark.parametrize("model", ["cast_1", "sasrec"])
+def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, monkeypatch):
+    """include/castrec.h promises that the fused entries (FFN tails, stack input composed in the first block's kernels,
+    final-LayerNorm backward inside the head) give the results of the calls they replace: the same engine built with
+    and without them, same parameters, same batch, dropout on.  Same mathematics; the fused forms round differently in the
+    last bit in places (e.g. x / sd against x * rstd in the final LayerNorm) and the table scatter's float atomics
+    reorder, so the comparison is to 2e-6 of the tensor's scale -- two orders below the parity bound."""
+    rs = np.random.RandomState(17)
+    B, T, D, itemnum, max_bins = 6, 40, 50, 45, 9
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=max_bins, seed=13)
+    a = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=4)
+    monkeypatch.setenv(env, "1")
+    b = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=4)
+    monkeypatch.delenv(env)
+    assert a.n_launches() < b.n_launches()
+    a.P.add_(0.05 * torch.randn(a.P.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
+    b.P.copy_(a.P)
+    batch = make_batch(rs, B, T, itemnum, max_bins)
+    for eng in (a, b):
+        eng.set_batch(*batch)
+        eng.launch_step(apply=False)
+    torch.cuda.synchronize()
+    assert float((a.seq_emb - b.seq_emb).abs().max()) <= 2e-6 * float(b.seq_emb.abs().max())
+    sa, sb = a.state.cpu().numpy(), b.state.cpu().numpy()
+    assert sa[2] == sb[2] and sa[0] == pytest.approx(sb[0], rel=1e-6)
+    ga, gb = a.grads(), b.grads()
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * gmax, k
+
+
 def _other_shapes(E, model, D, H, T, L, B=3):
     rs = np.random.RandomState(D + T)
     itemnum, max_bins = 41, 9
