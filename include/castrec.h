@@ -252,7 +252,7 @@ int cr_block_ln_qkv_fwd_gather(const cr_block_desc* d, const cr_embed_desc* e, v
  *   kind 1: the NEXT block's cr_block_ln_qkv_fwd (next->x must be this block's y) -- one launch per block boundary less;
  *   kind 2: the stack's final LayerNorm (sasrec.py:85): out[:, col_out : col_out + D] = LN(y; lnf_gamma, lnf_beta).
  * y is written in both cases (the backward needs it); results equal the separate calls up to fp32 rounding
- * (the final LayerNorm divides by the standard deviation here, cr_layernorm_fwd multiplies by its reciprocal). */
+ * (the row mean of the final LayerNorm is sum * (1/D) here and sum / D in cr_layernorm_fwd). */
 typedef struct {
     int kind;                                  /* 0 none, 1 next block's LN1 + QKV, 2 final LayerNorm */
     const cr_block_desc* next;                 /* kind 1 */

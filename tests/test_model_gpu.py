@@ -185,7 +185,7 @@ def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, m
     """include/castrec.h promises that the fused entries (FFN tails, stack input composed in the first block's kernels,
     final-LayerNorm backward inside the head) give the results of the calls they replace: the same engine built with
     and without them, same parameters, same batch, dropout on.  Same mathematics; the fused forms round differently in the
-    last bit in places (e.g. x / sd against x * rstd in the final LayerNorm) and the table scatter's float atomics
+    last bit in places (e.g. the row mean as sum * (1/D) against sum / D in the final LayerNorm) and the table scatter's float atomics
     reorder, so the comparison is to 2e-6 of the tensor's scale -- two orders below the parity bound."""
     rs = np.random.RandomState(17)
     B, T, D, itemnum, max_bins = 6, 40, 50, 45, 9
