@@ -358,6 +358,13 @@ __global__ __launch_bounds__(256) void k_attn_zero_cols(float* p, int ld, int M,
         p[(size_t)(i / C) * ld + (i % C)] = 0.0f;
 }
 
+int cr_attn_zero_cols_launch(float* p, int ld, int M, int C, hipStream_t s) {
+    int grid = cr_ceil_div(M * C, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_attn_zero_cols, dim3(grid), dim3(256), 0, s, p, ld, M, C);
+    return cr_check_launch("cr_attn_bwd(zero dQ_part)");
+}
+
 extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd != nullptr, "cr_attn_bwd: NULL desc");
     const cr_attn_desc* d = &bd->f;
@@ -367,6 +374,13 @@ extern "C" int cr_attn_bwd(const cr_attn_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd->dout && bd->dQ && bd->dK && bd->dV && bd->stats, "cr_attn_bwd: NULL pointer");
     CR_REQUIRE(bd->ldg >= d->H * d->d && bd->lddo >= d->H * d->d, "cr_attn_bwd: ldg / lddo too small");
     hipStream_t s = cr_stream(stream);
+    if (d->precision != CR_PREC_F32 && cr_attn_bf_supported_bwd(d)) {
+        if (bd->dQ_part) {                              // the bf16 kernels return the whole dQ: the second partial is zero
+            rc = cr_attn_zero_cols_launch(bd->dQ_part, bd->ldg, d->B * d->T, d->H * d->d, s);
+            if (rc) return rc;
+        }
+        return cr_attn_bf_bwd_launch(bd, s);
+    }
     if (!attn_lds_envelope(d)) {
         if (bd->dQ_part) {
             const int M = d->B * d->T, Cc = d->H * d->d;

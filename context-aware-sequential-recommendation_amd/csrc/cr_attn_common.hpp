@@ -365,6 +365,13 @@ int cr_attn_wide_supported(const cr_attn_desc* d);
 int cr_attn_wide_fwd_launch(const cr_attn_desc* d, hipStream_t s);
 int cr_attn_wide_bwd_launch(const cr_attn_bwd_desc* bd, hipStream_t s);
 
+// bf16-MFMA kernels (cr_attn_bf.hip): CR_PREC_BF16X3 / CR_PREC_BF16
+bool cr_attn_bf_supported_fwd(const cr_attn_desc* d);
+bool cr_attn_bf_supported_bwd(const cr_attn_desc* d);
+int cr_attn_bf_fwd_launch(const cr_attn_desc* d, hipStream_t s);
+int cr_attn_bf_bwd_launch(const cr_attn_bwd_desc* bd, hipStream_t s);
+int cr_attn_zero_cols_launch(float* p, int ld, int M, int C, hipStream_t s);
+
 static int attn_validate(const cr_attn_desc* d, const char* who) {
     CR_REQUIRE(d->Q && d->K && d->V && d->k_valid && d->q_valid, "%s: NULL pointer", who);
     CR_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->d > 0, "%s: bad shape B=%d T=%d H=%d d=%d", who, d->B, d->T, d->H, d->d);
@@ -372,6 +379,7 @@ static int attn_validate(const cr_attn_desc* d, const char* who) {
         return cr_set_error(CR_ERR_UNSUPPORTED, "%s: T=%d (max 1024) / head dim %d (max 256) not supported", who, d->T, d->d);
     CR_REQUIRE(d->ld >= d->H * d->d, "%s: ld too small", who);
     CR_REQUIRE(d->batch_global >= d->B, "%s: batch_global < B", who);
+    CR_REQUIRE(d->precision >= CR_PREC_F32 && d->precision <= CR_PREC_BF16, "%s: unknown precision %d", who, d->precision);
     return CR_OK;
 }
 // the MFMA kernels keep K and V of one (sample, head) resident in LDS: T <= 256, head dim <= 64

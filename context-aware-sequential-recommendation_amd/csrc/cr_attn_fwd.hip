@@ -172,6 +172,7 @@ extern "C" int cr_attn_fwd(const cr_attn_desc* d, void* stream) {
     if (rc) return rc;
     CR_REQUIRE(d->out && d->residual, "cr_attn_fwd: NULL out/residual");
     hipStream_t s = cr_stream(stream);
+    if (d->precision != CR_PREC_F32 && cr_attn_bf_supported_fwd(d)) return cr_attn_bf_fwd_launch(d, s);
     if (!attn_lds_envelope(d)) return cr_attn_wide_fwd_launch(d, s);
     rc = attn_geom(d, &g, "cr_attn_fwd");
     if (rc) return rc;

@@ -26,6 +26,7 @@ c_p = C.c_void_p
 
 CR_MAX_BATCH = 4
 CR_STATE_FLOATS = 16
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 ELT_COPY, ELT_ADD, ELT_DROPOUT, ELT_RELU_BWD, ELT_ROWMASK, ELT_GRADPREP = 0, 1, 2, 3, 4, 5
 
 
@@ -75,7 +76,7 @@ class AttnDesc(C.Structure):
     _fields_ = [("Q", c_p), ("K", c_p), ("V", c_p), ("ld", c_i), ("k_valid", c_p), ("q_valid", c_p),
                 ("residual", c_p), ("ldr", c_i), ("dead_ids", c_p), ("out", c_p), ("ldo", c_i),
                 ("attn_weights", c_p), ("B", c_i), ("T", c_i), ("H", c_i), ("d", c_i), ("drop", Rng),
-                ("batch_global", c_i), ("row_stats", c_p)]
+                ("batch_global", c_i), ("row_stats", c_p), ("precision", c_i)]
 
 
 class AttnBwdDesc(C.Structure):

@@ -98,9 +98,10 @@ def eltwise(op, x, ldx, y, ldy, M, N, aux=None, ldaux=0, rng=NO_DROP, mask_ids=N
 
 
 def attn_desc(Q, K, V, ld, k_valid, q_valid, residual, ldr, out, ldo, B, T, H, d, rng=NO_DROP, batch_global=None,
-              dead_ids=None, attn_weights=None, row_stats=None):
+              dead_ids=None, attn_weights=None, row_stats=None, precision=0):
     return L.AttnDesc(_p(Q), _p(K), _p(V), ld, _p(k_valid), _p(q_valid), _p(residual), ldr, _p(dead_ids), _p(out), ldo,
-                      _p(attn_weights), B, T, H, d, rng, B if batch_global is None else batch_global, _p(row_stats))
+                      _p(attn_weights), B, T, H, d, rng, B if batch_global is None else batch_global, _p(row_stats),
+                      int(precision))
 
 
 def attn_fwd(desc):

@@ -179,6 +179,17 @@ typedef struct {
 } cr_elt_desc;
 int cr_eltwise(const cr_elt_desc* d, void* stream);
 
+/* Arithmetic of the attention products (cr_attn_desc.precision).  The reference is fp32 end to end
+ * (modules.py:203-262); BASELINE.json configs[1] names bf16.
+ *   CR_PREC_F32     v_mfma_f32_16x16x4_f32: exact fp32 fma chains (T <= 256, head dim <= 64; other shapes: general kernels)
+ *   CR_PREC_BF16X3  v_mfma_f32_16x16x32_bf16 on operands split into bf16 hi + lo, three products per term
+ *                   (hi*hi + hi*lo + lo*hi): ~1e-5 relative, inside the 1e-3 fp32 bound; forward T <= 256,
+ *                   backward T <= 1024 (needs row_stats), head dim <= 64
+ *   CR_PREC_BF16    the same kernels on the hi halves only: plain bf16 operands, fp32 accumulation */
+#define CR_PREC_F32 0
+#define CR_PREC_BF16X3 1
+#define CR_PREC_BF16 2
+
 /* ---- causal multi-head self-attention core (modules.py:208-269) ---------------------
  * Per head j (columns [j*d, (j+1)*d) of Q/K/V, d = D/H):
  *   S = Q K^T / sqrt(d); masked (key invalid or key > query) -> -2^32+1; softmax over all T keys
@@ -199,6 +210,7 @@ typedef struct {
     int batch_global;          /* Bglobal (>= B) for shard-invariant dropout indices */
     float* row_stats;          /* optional [H*B*T*4]: the forward saves {row max (base-2 units), 1/sum, flag, 0} per
                                   query row (flag 0 normal, 1 uniform row, 2 dead row) for the single-pass backward */
+    int precision;             /* CR_PREC_*: arithmetic of the score / A V / dS K products (accumulation is fp32 in all) */
 } cr_attn_desc;
 int cr_attn_fwd(const cr_attn_desc* d, void* stream);
 
