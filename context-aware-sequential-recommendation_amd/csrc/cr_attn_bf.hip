@@ -28,12 +28,19 @@
 // (k index 8 lg + j  <->  key tile j >> 2, key 4 lg + (j & 3)), and the matching B operand (V or K rows in that
 // order, one output column per lane) is exactly what two ds_read_b64_tr_b16 deliver.  The key-owner kernel uses the
 // mirrored form (S[query][key] = Q K^T, lane = key, two query tiles per k-step).
+#include <stdlib.h>
+
 #include "cr_attn_common.hpp"
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf4 lds_bf4;
 
+#ifndef BF_NO_SGB
+#define BF_SGB(mask, n, id) __builtin_amdgcn_sched_group_barrier(mask, n, id)
+#else
+#define BF_SGB(mask, n, id) do { } while (0)
+#endif
 #define BF_CH 256                 // rows of one LDS chunk (K/V rows in the query-owner kernels, Q/dOut rows in the key-owner one)
 #define BF_IMG (BF_CH * 64)       // bf16 elements of one image
 
@@ -42,7 +49,18 @@ struct BfGeom {
     int nch, ch_rows;             // chunks, rows per chunk (T16 when nch == 1, else 256)
     int M;                        // rows of the operand matrices (B * T): the vector loads may run into the NEXT row, never past the last
     float isd, isd_log2e, invT;
+    unsigned long long* ts;       // debug: per-wave phase stamps [waves][16] (tools/attn_bf_ts.py); NULL in production
 };
+#ifdef CR_TIMELINE
+#define BT_TS(slot)                                                                                          \
+    do {                                                                                                     \
+        if (g.ts && (threadIdx.x & 63) == 0)                                                                 \
+            g.ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = \
+                ((slot) == 0 || (slot) == 15) ? wall_clock64() : clock64();                                  \
+    } while (0)
+#else
+#define BT_TS(slot) do { } while (0)
+#endif
 
 // element offset of 16-byte chunk `ch` (0..7) of row `row`
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + ((ch ^ (row & 6)) << 3); }
@@ -81,72 +99,114 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf8& hi, bf8& lo) {
     }
 }
 
-// 8 consecutive floats of a row, columns c .. c+7 of a d-column head block.  A chunk that crosses column d is
-// read whole (it runs into the next row: inside the matrix for every row but the last) and masked; the last row
-// of the matrix takes clamped dword loads.  Chunks beyond d are not read.
+// ---- global -> register / LDS traffic -------------------------------------------------------------------
+// An item is 8 consecutive floats of a row: columns c .. c+7 of a d-column head block, two dword-aligned 16-byte
+// loads.  Nothing here branches, so every load of a batch is in flight before the first use: a chunk that crosses
+// column d is read whole (it runs into the next row of the matrix) and masked; a chunk beyond d, and the one chunk
+// in the whole matrix whose overrun would leave it (the partial chunk of the LAST row), read the 8 floats that end
+// at column d instead -- always inside the matrix, the host checks it holds 8 floats -- and are masked to zero;
+// the thread that owns that last-row chunk then re-reads its valid columns one by one (a divergent branch that a
+// single wave of the grid ever takes).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ void load8(const float* p, int c, int d, bool row_ok, bool not_last, float (&v)[8]) {
-    if (c < d) {
-        if (c + 8 <= d || not_last) {
-            const f4u a = *reinterpret_cast<const f4u*>(p + c), b = *reinterpret_cast<const f4u*>(p + c + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
+__device__ __forceinline__ bool item_fix(bool rok, bool last_row, int c, int d) { return rok && last_row && c < d && c + 8 > d; }
+__device__ __forceinline__ void item_issue(float (&v)[8], const float* p, int c, int d, bool fix) {
+    const int cl = (c >= d || fix) ? d - 8 : c;
+    const f4u a = *reinterpret_cast<const f4u*>(p + cl), b = *reinterpret_cast<const f4u*>(p + cl + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// (only the eight floats stay live between issue and mask: row / column facts are recomputed)
+__device__ __forceinline__ void item_mask(float (&v)[8], int c, int d, bool rok, bool fix) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = p[c + j < d ? c + j : d - 1];
-        }
+    for (int j = 0; j < 8; ++j) v[j] = (rok && !fix && c + j < d) ? v[j] : 0.0f;
+}
+// the partial chunk of the matrix's last row, re-read column by column (behind branches one wave of the grid takes)
+__device__ __forceinline__ void item_refill(float (&v)[8], const float* p, int c, int d) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (row_ok && c + j < d) ? v[j] : 0.0f;
-    } else {
+    for (int j = 0; j < 8; ++j) v[j] = p[c + j < d ? c + j : d - 1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-    }
+    for (int j = 0; j < 8; ++j) v[j] = (c + j < d) ? v[j] : 0.0f;
 }
 
 // Register fragment of the wave's own 16-row tile straight from global memory (operand with k = head dim):
-// lane (li, lg) holds row row0 + li, columns 32 ks + 8 lg + j.
-template <bool SPLIT, int NKS>
-__device__ __forceinline__ void gfrag(const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M,
-                                      bf8 (&hi)[NKS], bf8 (&lo)[NKS]) {
+// lane (li, lg) holds row grow0 + li, columns 32 ks + 8 lg + j.  Issue early, finish (mask, split) at first use.
+template <int NKS>
+struct GFrag { float v[NKS][8]; };
+template <int NKS>
+__device__ __forceinline__ void gfrag_issue(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const bool rok = li < nvalid;
     const int grow = grow0 + (rok ? li : 0);
     const float* p = src + (size_t)grow * ld + hoff;
 #pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) item_issue(f.v[ks], p, 32 * ks + 8 * lg, d, item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d));
+}
+template <int NKS>
+__device__ __forceinline__ void gfrag_mask(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const bool rok = li < nvalid;
+    const int grow = grow0 + (rok ? li : 0);
+    bool any_fix = false;
+#pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        float v[8];
-        load8(p, 32 * ks + 8 * lg, d, rok, grow < M - 1, v);
-        split8<SPLIT>(v, hi[ks], lo[ks]);
+        const bool fix = item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d);
+        item_mask(f.v[ks], 32 * ks + 8 * lg, d, rok, fix);
+        any_fix |= fix;
     }
+    if (__builtin_expect(grow0 + 16 >= M && __any(any_fix ? 1 : 0), 0)) {        // wave-uniform, true for one tile of the grid
+        const float* p = src + (size_t)grow * ld + hoff;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            if (item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d)) item_refill(f.v[ks], p, 32 * ks + 8 * lg, d);
+    }
+}
+template <bool SPLIT, int NKS>
+__device__ __forceinline__ void gfrag_finish(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M,
+                                             bf8 (&hi)[NKS], bf8 (&lo)[NKS]) {
+    gfrag_mask<NKS>(f, src, ld, grow0, hoff, nvalid, d, M);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) split8<SPLIT>(f.v[ks], hi[ks], lo[ks]);
 }
 
 // Stage rows [crow0, crow0 + nrows) of two [T, d] head blocks into their LDS images (chunk-relative rows).
-// An item is (row, 16-byte chunk); the 2 x U loads of a batch are issued before the first conversion.
+// An item is (row, 16-byte chunk); the 4 x U loads of a batch are issued before the first conversion
+// (U = 4: the 208 x 8 items of the headline shape are ONE batch for 512 threads, one memory latency).
 template <bool SPLIT, int NKS>
 __device__ __forceinline__ void stage_pair_bf(__bf16* ah, __bf16* al, const float* srcA, int ldA, __bf16* bh, __bf16* bl,
                                               const float* srcB, int ldB, int base_row, int crow0, int nrows, int T,
                                               int hoff, int d, int M) {
     constexpr int CPR = 4 * NKS;                         // chunks per row that MFMAs read (columns < 32 NKS)
     const int total = nrows * CPR;
-    constexpr int U = 2;
+    constexpr int U = 4;
+    const bool wg_has_last = base_row + T == M;          // only the last sample's workgroups can meet the matrix's last row
     for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * U) {
         float va[U][8], vb[U][8];
-        int rr[U], cc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int item = min(i0 + u * (int)blockDim.x, total - 1);
             const int r = item / CPR, ch = item - r * CPR;
-            rr[u] = r; cc[u] = ch;
             const int t = crow0 + r;
             const bool rok = t < T;
             const int grow = base_row + (rok ? t : 0);
-            load8(srcA + (size_t)grow * ldA + hoff, 8 * ch, d, rok, grow < M - 1, va[u]);
-            load8(srcB + (size_t)grow * ldB + hoff, 8 * ch, d, rok, grow < M - 1, vb[u]);
+            const bool fix = item_fix(rok, grow == M - 1, 8 * ch, d);
+            item_issue(va[u], srcA + (size_t)grow * ldA + hoff, 8 * ch, d, fix);
+            item_issue(vb[u], srcB + (size_t)grow * ldB + hoff, 8 * ch, d, fix);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (i0 + u * (int)blockDim.x < total) {
+                const int item = i0 + u * (int)blockDim.x;
+                const int r = item / CPR, ch = item - r * CPR;
+                const int t = crow0 + r;
+                const bool rok = t < T;
+                const bool fix = wg_has_last && item_fix(rok, t == T - 1, 8 * ch, d);
+                const int o = img_off(r, ch);
                 bf8 h, l;
-                const int o = img_off(rr[u], cc[u]);
+                item_mask(va[u], 8 * ch, d, rok, fix);
+                item_mask(vb[u], 8 * ch, d, rok, fix);
+                if (__builtin_expect(wg_has_last && fix, 0)) {           // one thread of the grid
+                    item_refill(va[u], srcA + (size_t)(M - 1) * ldA + hoff, 8 * ch, d);
+                    item_refill(vb[u], srcB + (size_t)(M - 1) * ldB + hoff, 8 * ch, d);
+                }
                 split8<SPLIT>(va[u], h, l);
                 *reinterpret_cast<bf8*>(ah + o) = h;
                 if (SPLIT) *reinterpret_cast<bf8*>(al + o) = l;
@@ -174,11 +234,16 @@ __device__ __forceinline__ int first_valid_key(const float* k_valid, int base_ro
     return wave_min_i(f);
 }
 
-// tile owned by a wave in a round: one chunk -> serpentine deal over the sample's workgroups (cr_attn_common.hpp);
-// several chunks -> workgroup y owns the 8 consecutive tiles 8y .. 8y+7 (their causal extents are alike, and the
-// chunk loop with its barriers is workgroup-wide)
-__device__ __forceinline__ int rounds_of(const BfGeom& g, int nw) {
-    return g.nch > 1 ? 1 : (g.nkt + (int)gridDim.y * nw - 1) / ((int)gridDim.y * nw);
+// the same from the additive key bias of a staged chunk (0 = valid), rows [0, n16): one 16-byte LDS read per lane
+__device__ __forceinline__ int first_valid_key_lds(const float* kb, int n16, int T) {
+    const int lane = threadIdx.x & 63;
+    int f = T;
+    if (4 * lane < n16) {
+        const float4 b = *reinterpret_cast<const float4*>(kb + 4 * lane);
+        const int i = b.x == 0.0f ? 0 : (b.y == 0.0f ? 1 : (b.z == 0.0f ? 2 : (b.w == 0.0f ? 3 : 1 << 20)));
+        f = min(T, 4 * lane + i);
+    }
+    return wave_min_i(f);
 }
 
 // =====================================================================================================
@@ -187,6 +252,7 @@ __device__ __forceinline__ int rounds_of(const BfGeom& g, int nw) {
 template <int NKT, int NKS, bool SPLIT>
 __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
     constexpr int NDT = 2 * NKS;                         // 16-column output tiles
+    constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Kl = Kh + (SPLIT ? g.T16 * 64 : 0);
@@ -198,21 +264,42 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    BT_TS(0); BT_TS(1);
     const DropCtx dc = drop_ctx(d.drop);
     TileSched sch = sched_init(nw, wave);
     int qi = sched_rank(sch);
-    const int fvk = first_valid_key(d.k_valid, base_row, T);
+    // the wave's next tile: Q fragment and row flags, requested ahead (during the staging / the previous tile)
+    GFrag<NKS> qn;
+    float qv_n = 0.0f;
+    int id_n = 1;
+    auto issue_tile = [&](int rank) {
+        const int q0n = 16 * (g.nkt - 1 - rank);
+        gfrag_issue<NKS>(qn, d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, g.M);
+        const int qc = min(q0n + li, T - 1);
+        qv_n = d.q_valid[base_row + qc];
+        id_n = d.dead_ids ? d.dead_ids[base_row + qc] : 1;
+    };
+    const int qi_first = qi;
+    if (qi < g.nkt) issue_tile(qi);
+    const int t0 = threadIdx.x;
+    const float kv0 = d.k_valid[base_row + min(t0, T - 1)];
     stage_pair_bf<SPLIT, NKS>(Kh, Kl, d.K, d.ld, Vh, Vl, d.V, d.ld, base_row, 0, g.T16, T, hoff, d.d, g.M);
-    for (int t = threadIdx.x; t < g.T16; t += blockDim.x)
-        kb[t] = (t < T && d.k_valid[base_row + t] != 0.0f) ? 0.0f : -INFINITY;
+    if (t0 < g.T16) kb[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;
+    BT_TS(2);
     __syncthreads();
+    BT_TS(3);
+    const int fvk = first_valid_key_lds(kb, g.T16, T);
     const int kt_first = min(fvk >> 4, NKT - 1);         // tiles below hold no valid key: probabilities exactly 0
     const float c2 = g.isd_log2e;
-    for (; qi < g.nkt; qi = sched_next(sch)) {
-        const int qt = g.nkt - 1 - qi;                   // heaviest tiles first
+    // one tile per wave: the host sizes the grid so (a second round of tiles kept the fragments of both rounds live and
+    // spilled: 170 -> 256 VGPRs + scratch, and a spilled value is a ~1 us scratch round trip here)
+    for (bool once = qi < g.nkt; once; once = false) {
+        const int qt = g.nkt - 1 - qi;                   // rank 0 = heaviest tile
         const int q0 = 16 * qt, q = q0 + li;
-        const int qc = q < T ? q : T - 1;
-        const bool is_dead = q >= T || (d.dead_ids && d.dead_ids[base_row + qc] == 0);
+        bf8 qh[NKS], ql[NKS];
+        gfrag_finish<SPLIT, NKS>(qn, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M, qh, ql);
+        const bool is_dead = q >= T || id_n == 0;
+        const float qvq = q < T ? qv_n : 0.0f;
         if (__all(is_dead ? 1 : 0) && d.attn_weights == nullptr) {
             // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
             if (d.row_stats && lg == 0 && q < T) {
@@ -228,35 +315,50 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
             }
             continue;
         }
-        bf8 qh[NKS], ql[NKS];
-        gfrag<SPLIT, NKS>(d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M, qh, ql);
-        const float qvq = d.q_valid[base_row + qc] * (q < T ? 1.0f : 0.0f);
-        // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block
+        // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block; two key tiles per batch of reads
         f32x4 st[NKT];
         float mx = -INFINITY;
+        auto finish = [&](int kt, f32x4 acc) {
+            const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);   // key mask (modules.py:222-229)
+            acc[0] = fmaf(acc[0], c2, b4.x); acc[1] = fmaf(acc[1], c2, b4.y);
+            acc[2] = fmaf(acc[2], c2, b4.z); acc[3] = fmaf(acc[3], c2, b4.w);
+            if (kt == qt) {                              // causal mask on the diagonal tile (modules.py:232-241)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4 acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (kt >= kt_first && kt <= qt) {            // wave-uniform
-                acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) acc[r] = (4 * lg + r <= li) ? acc[r] : -INFINITY;
+            }
+            mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+            return acc;
+        };
+        const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt += 2) {
+            const bool c0 = kt >= kt_first && kt <= qt;                         // wave-uniform
+            const bool c1 = (kt + 1 < NKT) && kt + 1 >= kt_first && kt + 1 <= qt;
+            f32x4 a0 = ninf, a1 = ninf;
+            if (c0 || c1) {
+                const int r0 = 16 * (c0 ? kt : kt + 1), r1 = 16 * (c1 ? kt + 1 : kt);
+                bf8 k0h[NKS], k0l[NKS], k1h[NKS], k1l[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const bf8 ah = row_frag(Kh, 16 * kt, ks);
-                    const bf8 al = SPLIT ? row_frag(Kl, 16 * kt, ks) : ah;
-                    acc = mma<SPLIT>(ah, al, qh[ks], ql[ks], acc);
+                    k0h[ks] = row_frag(Kh, r0, ks); k1h[ks] = row_frag(Kh, r1, ks);
+                    k0l[ks] = SPLIT ? row_frag(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag(Kl, r1, ks) : k1h[ks];
                 }
-                const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);   // key mask (modules.py:222-229)
-                acc[0] = fmaf(acc[0], c2, b4.x); acc[1] = fmaf(acc[1], c2, b4.y);
-                acc[2] = fmaf(acc[2], c2, b4.z); acc[3] = fmaf(acc[3], c2, b4.w);
-                if (kt == qt) {                          // causal mask on the diagonal tile (modules.py:232-241)
+                f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = (4 * lg + r <= li) ? acc[r] : -INFINITY;
+                for (int ks = 0; ks < NKS; ++ks) {
+                    x0 = mma<SPLIT>(k0h[ks], k0l[ks], qh[ks], ql[ks], x0);
+                    x1 = mma<SPLIT>(k1h[ks], k1l[ks], qh[ks], ql[ks], x1);
                 }
-                mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);   // the pair's operand reads as one batch,
+                BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);   // then its MFMAs
+                if (c0) a0 = finish(kt, c0 ? x0 : x1);
+                if (c1) a1 = finish(kt + 1, x1);
             }
-            st[kt] = acc;
+            st[kt] = a0;
+            if (kt + 1 < NKT) st[kt + 1] = a1;
         }
         mx = grp_max(mx);
+        if (qi == qi_first) BT_TS(4);
         const bool uniform = (mx == -INFINITY) && !is_dead && q < T;
         const float off = (mx == -INFINITY) ? 0.0f : mx;
         float sum = 0.0f;
@@ -277,32 +379,33 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
         float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
         if (is_dead) inv = 0.0f;
         const bool any_uni = __any(uniform ? 1 : 0) != 0;
-        if (any_uni) {                                   // rare: a row with no valid key at all (modules.py:227-244)
-            const float uni = uniform ? g.invT : 0.0f;
-            const float sc = uniform ? 0.0f : inv;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * sc + ((16 * kt + 4 * lg + r < T) ? uni : 0.0f);
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) st[kt] *= inv;
-        }
         if (d.row_stats && lg == 0 && q < T) {           // for the backward kernels
             float* sp = d.row_stats + ((size_t)blockIdx.x * T + q) * 4;
             sp[0] = mx; sp[1] = inv; sp[2] = is_dead ? 2.0f : (uniform ? 1.0f : 0.0f); sp[3] = 0.0f;
         }
-        // ---- query mask, dropout (modules.py:248-257)
+        // ---- softmax scale, query mask, dropout (modules.py:244-257) folded into one factor per element
+        const float wq = inv * qvq;
         const uint32_t ridx = attn_row_idx(d, head, n, q);
         const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
-        if (dc.on) {
+        if (any_uni) {                                   // rare: a row with no valid key at all (modules.py:227-244)
+            const float uni = uniform ? g.invT * qvq : 0.0f;
+            const float sc = uniform ? 0.0f : wq;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][r] *= qvq * drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                for (int r = 0; r < 4; ++r) {
+                    float w = 1.0f;
+                    if (dc.on) w = drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                    st[kt][r] = (st[kt][r] * sc + ((16 * kt + 4 * lg + r < T) ? uni : 0.0f)) * w;
+                }
+        } else if (dc.on) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][r] *= wq * drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
         } else {
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) st[kt] *= qvq;
+            for (int kt = 0; kt < NKT; ++kt) st[kt] *= wq;
         }
         if (d.attn_weights) {                            // modules.py:259 (on request only)
 #pragma unroll
@@ -313,7 +416,9 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
                     if (q < T && key < T) d.attn_weights[((size_t)blockIdx.x * T + q) * T + key] = st[kt][r];
                 }
         }
+        if (qi == qi_first) BT_TS(5);
         // ---- out = A V + residual (modules.py:262-269): two key tiles per k-step, V through transposed reads
+        // residual requested ahead of the MFMAs that hide its latency
         float resid[NDT][4];
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt)
@@ -341,13 +446,21 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
                 split8<SPLIT>(x, ph, pl);
                 const int ra = 16 * k0, rb = 16 * (k1 < g.nkt ? k1 : k0);   // tiles beyond T16 are not staged (their A is 0)
 #pragma unroll
-                for (int jt = 0; jt < NDT; ++jt) {
-                    const bf8 bh = tr_frag(Vh, ra, rb, jt);
-                    const bf8 bl = SPLIT ? tr_frag(Vl, ra, rb, jt) : bh;
-                    acc[jt] = mma<SPLIT>(ph, pl, bh, bl, acc[jt]);
+                for (int j0 = 0; j0 < NDT; j0 += JB) {                   // JB column tiles per batch of transposed reads
+                    bf8 bh[JB], bl[JB];
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        bh[jt] = tr_frag(Vh, ra, rb, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag(Vl, ra, rb, j0 + jt) : bh[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) acc[j0 + jt] = mma<SPLIT>(ph, pl, bh[jt], bl[jt], acc[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
                 }
             }
         }
+        if (qi == qi_first) BT_TS(6);
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt)
 #pragma unroll
@@ -355,15 +468,204 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
                 const int qq = q0 + 4 * lg + r, c = 16 * jt + li;
                 if (qq < T && c < d.d) d.out[(size_t)(base_row + qq) * d.ldo + hoff + c] = acc[jt][r] + resid[jt][r];
             }
+        if (qi == qi_first) BT_TS(7);
+    }
+    BT_TS(15);
+}
+
+// =====================================================================================================
+// forward, 256 < T <= 1024: K / V stream through LDS in 256-key chunks, online softmax across the chunks
+// (running row maximum m and sum l; the output accumulator is rescaled when m grows; probabilities are used
+// un-normalised and the row is divided by l once at the end).  Workgroup y owns query tiles 8y .. 8y+7, one per
+// wave.  Rows without any valid key (modules.py:227-244) are known up front from the sample's first valid key:
+// they take 1/T on EVERY key of EVERY chunk, so a workgroup that holds such a row walks all chunks.
+// attention_weights are not produced here (a caller that wants them at T > 256 gets the general kernels).
+// =====================================================================================================
+template <int NKS, bool SPLIT>
+__global__ __launch_bounds__(512) void k_bf_fwd_long(cr_attn_desc d, BfGeom g) {
+    constexpr int NDT = 2 * NKS;
+    constexpr int JB = SPLIT ? 2 : NDT;
+    constexpr int NKT = BF_CH / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Kl = Kh + (SPLIT ? BF_IMG : 0);
+    __bf16* Vh = Kl + BF_IMG;
+    __bf16* Vl = Vh + (SPLIT ? BF_IMG : 0);
+    float* kb = reinterpret_cast<float*>(Vl + BF_IMG);   // [256] additive key bias of the staged chunk
+    const int nw = blockDim.x >> 6;
+    const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
+    const int base_row = n * d.T, hoff = head * d.d;
+    const int T = d.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const DropCtx dc = drop_ctx(d.drop);
+    const int qt = (int)blockIdx.y * nw + wave;
+    const bool have = qt < g.nkt;
+    const int q0 = 16 * (have ? qt : 0), q = q0 + li;
+    const int qc = min(q, T - 1);
+    GFrag<NKS> qn;
+    if (have) gfrag_issue<NKS>(qn, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M);
+    const float qv_ = d.q_valid[base_row + qc];
+    const int id_ = d.dead_ids ? d.dead_ids[base_row + qc] : 1;
+    const int fvk = first_valid_key(d.k_valid, base_row, T);
+    const int kt_first = fvk >> 4;
+    const bool is_dead = !have || q >= T || id_ == 0;
+    const float qvq = (have && q < T) ? qv_ : 0.0f;
+    const bool uniform = have && q < T && !is_dead && q < fvk;             // no valid key at or before q
+    const bool any_uni = __any(uniform ? 1 : 0) != 0;
+    const bool tile_dead = __all(is_dead ? 1 : 0) != 0;
+    bf8 qh[NKS], ql[NKS];
+    if (have) gfrag_finish<SPLIT, NKS>(qn, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M, qh, ql);
+    const float c2 = g.isd_log2e;
+    const uint32_t ridx = attn_row_idx(d, head, n, q);
+    const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 acc[NDT];
+#pragma unroll
+    for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // chunks this workgroup walks: up to the chunk of its last query row; all of them when it may hold a uniform row
+    const int blk_q0 = 16 * (int)blockIdx.y * nw;
+    const int c_hi = (blk_q0 < fvk) ? g.nch - 1 : min(g.nch - 1, (blk_q0 + 16 * nw - 1) / BF_CH);
+    for (int c = 0; c <= c_hi; ++c) {
+        __syncthreads();
+        {
+            const int crow0 = c * BF_CH, t0 = threadIdx.x;
+            const float kv0 = d.k_valid[base_row + min(crow0 + t0, T - 1)];
+            stage_pair_bf<SPLIT, NKS>(Kh, Kl, d.K, d.ld, Vh, Vl, d.V, d.ld, base_row, crow0, BF_CH, T, hoff, d.d, g.M);
+            if (t0 < BF_CH) kb[t0] = (crow0 + t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;
+        }
+        __syncthreads();
+        if (!have || tile_dead) continue;
+        const int kt_c0 = c * NKT;
+        // live score tiles of this chunk (global tile index in [kt_first, qt]); uniform rows need every tile below T16
+        const int lo = max(kt_first, kt_c0) - kt_c0, hi = min(qt, kt_c0 + NKT - 1) - kt_c0;      // chunk-local, may be empty
+        const int nt_c = min(NKT, g.nkt - kt_c0);                                                 // tiles of the chunk that exist
+        if (lo > hi && !any_uni) continue;
+        f32x4 st[NKT];
+        float mx = -INFINITY;
+        const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt += 2) {
+            const bool c0 = kt >= lo && kt <= hi;
+            const bool c1 = kt + 1 >= lo && kt + 1 <= hi;
+            f32x4 a0 = ninf, a1 = ninf;
+            if (c0 || c1) {
+                const int r0 = 16 * (c0 ? kt : kt + 1), r1 = 16 * (c1 ? kt + 1 : kt);
+                bf8 k0h[NKS], k0l[NKS], k1h[NKS], k1l[NKS];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    k0h[ks] = row_frag(Kh, r0, ks); k1h[ks] = row_frag(Kh, r1, ks);
+                    k0l[ks] = SPLIT ? row_frag(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag(Kl, r1, ks) : k1h[ks];
+                }
+                f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    x0 = mma<SPLIT>(k0h[ks], k0l[ks], qh[ks], ql[ks], x0);
+                    x1 = mma<SPLIT>(k1h[ks], k1l[ks], qh[ks], ql[ks], x1);
+                }
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                auto finish = [&](int ktl, f32x4 a) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * ktl + 4 * lg);
+                    a[0] = fmaf(a[0], c2, b4.x); a[1] = fmaf(a[1], c2, b4.y);
+                    a[2] = fmaf(a[2], c2, b4.z); a[3] = fmaf(a[3], c2, b4.w);
+                    if (kt_c0 + ktl == qt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = (4 * lg + r <= li) ? a[r] : -INFINITY;
+                    }
+                    mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+                    return a;
+                };
+                if (c0) a0 = finish(kt, c0 ? x0 : x1);
+                if (c1) a1 = finish(kt + 1, x1);
+            }
+            st[kt] = a0;
+            st[kt + 1] = a1;
+        }
+        mx = grp_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float off = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m_run - off);   // rescale of what is accumulated so far
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[kt][r] - off);    // exp2(-inf) = 0: masked entries and tiles not computed
+                sum += p;
+                float w = qvq;
+                if (dc.on) w *= drop_factor_x(dc, xrow + (uint32_t)(16 * (kt_c0 + kt) + r) * CR_PHI);
+                const float pu = (16 * (kt_c0 + kt) + 4 * lg + r < T) ? g.invT : 0.0f;              // uniform rows: 1/T on every key
+                st[kt][r] = (uniform ? pu : p) * w;
+            }
+        sum = grp_sum(sum);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        // accumulator rows are queries 4 lg + r, alpha lives on the lane of ITS query: one cross-lane read per row
+        // (uniform rows keep their sum: their factor is 1)
+        const float a_eff = uniform ? 1.0f : alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(a_eff, 4 * lg + r, 64);
+#pragma unroll
+            for (int jt = 0; jt < NDT; ++jt) acc[jt][r] *= ar;
+        }
+        const int p_lo = any_uni ? 0 : lo, p_end = any_uni ? nt_c : hi + 1;
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const int k0 = 2 * kp, k1 = 2 * kp + 1;
+            if (k1 >= p_lo && k0 < p_end) {
+                float x[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x[r] = st[k0][r]; x[4 + r] = st[k1][r]; }
+                bf8 ph, pl;
+                split8<SPLIT>(x, ph, pl);
+                const int ra = 16 * k0, rb = 16 * k1;                        // all 16 tiles of a chunk are staged (zeros beyond T)
+#pragma unroll
+                for (int j0 = 0; j0 < NDT; j0 += JB) {
+                    bf8 bh[JB], bl[JB];
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        bh[jt] = tr_frag(Vh, ra, rb, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag(Vl, ra, rb, j0 + jt) : bh[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) acc[j0 + jt] = mma<SPLIT>(ph, pl, bh[jt], bl[jt], acc[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                }
+            }
+        }
+    }
+    if (!have) return;
+    float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    if (is_dead) inv = 0.0f;
+    if (d.row_stats && lg == 0 && q < T) {
+        float* sp = d.row_stats + ((size_t)blockIdx.x * T + q) * 4;
+        sp[0] = m_run; sp[1] = uniform ? 0.0f : inv; sp[2] = is_dead ? 2.0f : (uniform ? 1.0f : 0.0f); sp[3] = 0.0f;
+    }
+    const float fin = uniform ? 1.0f : inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float fr = __shfl(fin, 4 * lg + r, 64);
+        const int qq = q0 + 4 * lg + r;
+#pragma unroll
+        for (int jt = 0; jt < NDT; ++jt) {
+            const int cidx = 16 * jt + li;
+            if (qq < T && cidx < d.d) {
+                const size_t row = (size_t)(base_row + qq);
+                d.out[row * d.ldo + hoff + cidx] = acc[jt][r] * fr + d.residual[row * d.ldr + hoff + cidx];
+            }
+        }
     }
 }
 
 // =====================================================================================================
 // backward, query-owner pass: dQ (and delta, when the caller did not supply it)
 // =====================================================================================================
-template <int NKS, bool SPLIT>
-__global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g, float* delta_out) {
+template <int NKS, bool SPLIT, bool MULTI, bool PAIRED>
+__device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const BfGeom& g, float* delta_out) {
     constexpr int NDT = 2 * NKS;
+    constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
@@ -376,62 +678,96 @@ __global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g,
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    BT_TS(0); BT_TS(1);
     const DropCtx dc = drop_ctx(d.drop);
     TileSched sch = sched_init(nw, wave);
-    const int fvk = first_valid_key(d.k_valid, base_row, T);
-    const int kt_first = fvk >> 4;
-    const bool multi = g.nch > 1;
+    constexpr bool multi = MULTI;                        // several 256-row chunks (T > 256): compiled as its own kernel
     auto stage = [&](int c) {
         const int crow0 = c * BF_CH;
+        const int t0 = threadIdx.x;
+        const float kv0 = d.k_valid[base_row + min(crow0 + t0, T - 1)];
         stage_pair_bf<SPLIT, NKS>(Kh, Kl, d.K, d.ld, Vh, Vl, d.V, d.ld, base_row, crow0, g.ch_rows, T, hoff, d.d, g.M);
-        for (int t = threadIdx.x; t < g.ch_rows; t += blockDim.x)
-            kb[t] = (crow0 + t < T && d.k_valid[base_row + crow0 + t] != 0.0f) ? 0.0f : -INFINITY;
+        if (t0 < g.ch_rows) kb[t0] = (crow0 + t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;
     };
+    // Tiles of this wave.  Separate kernels: ONE tile (serpentine rank over the sample's workgroups, or block y's tile
+    // `wave` when T > 256).  PAIRED (the fused kernel: this workgroup runs the whole pass of its sample): tiles w and
+    // nkt-1-w, a heavy and a light one -- nkt + 1 tile pairs for every wave.
+    const int rank = sched_rank(sch);
+    int tiles[2];
+    int ntile = 1;
+    if (PAIRED) {
+        tiles[0] = g.nkt - 1 - wave; tiles[1] = wave;                     // heavy one first
+        ntile = tiles[0] > tiles[1] ? 2 : (tiles[0] == tiles[1] ? 1 : 0);
+    } else {
+        tiles[0] = multi ? (int)blockIdx.y * nw + wave : rank; tiles[1] = -1;
+    }
+    // the first tile's fragments and row constants, requested ahead of the staging
+    GFrag<NKS> qn, on, un, rn;                           // Q, dOut and (delta formed here) out, residual
+    typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+    f4s st_n = (f4s){0.f, 0.f, 2.0f, 0.f};
+    float qv_n = 0.0f, dl_n = 0.0f;
+    auto issue_tile = [&](int qt) {
+        const int q0n = 16 * qt;
+        gfrag_issue<NKS>(qn, d.Q, d.ld, base_row + q0n, hoff, T - q0n, d.d, g.M);
+        gfrag_issue<NKS>(on, bd.dout, bd.lddo, base_row + q0n, hoff, T - q0n, d.d, g.M);
+        const int qc = min(q0n + li, T - 1);
+        st_n = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)blockIdx.x * T + qc) * 4);
+        qv_n = d.q_valid[base_row + qc];
+        if (bd.delta) {
+            dl_n = bd.delta[(size_t)blockIdx.x * T + qc];
+        } else {
+            gfrag_issue<NKS>(un, d.out, d.ldo, base_row + q0n, hoff, T - q0n, d.d, g.M);
+            gfrag_issue<NKS>(rn, d.residual, d.ldr, base_row + q0n, hoff, T - q0n, d.d, g.M);
+        }
+    };
+    if (!PAIRED && tiles[0] >= 0 && tiles[0] < g.nkt) issue_tile(tiles[0]);
+    int kt_first = 0;
     if (!multi) {
         stage(0);
+        BT_TS(2);
         __syncthreads();
+        BT_TS(3);
+        kt_first = first_valid_key_lds(kb, g.ch_rows, T) >> 4;
+    } else {
+        kt_first = first_valid_key(d.k_valid, base_row, T) >> 4;
     }
-    const int nrounds = rounds_of(g, nw);
-    int rank = sched_rank(sch);
-    for (int round = 0; round < nrounds; ++round, rank = sched_next(sch)) {
-        const int qt = multi ? (int)blockIdx.y * nw + wave : g.nkt - 1 - rank;
-        const bool have = qt >= 0 && qt < g.nkt;
+#pragma unroll 1
+    for (int ti = 0; ti < (PAIRED ? ntile : 1); ++ti) {
+        const int round = ti;
+        const int qt = tiles[ti];
+        const bool have = (PAIRED || ntile > 0) && qt >= 0 && qt < g.nkt;
         const int q0 = 16 * (have ? qt : 0), q = q0 + li;
-        const int qc = q < T ? q : T - 1;
+        if (PAIRED && have) issue_tile(qt);             // paired tiles are not prefetched: a fragment live across the loop spills
         // forward statistics of this lane's query row
-        float mrow = 1e30f, inv = 0.0f, flag = 2.0f;
-        if (have && q < T) {
-            const float* sp = d.row_stats + ((size_t)blockIdx.x * T + q) * 4;
-            flag = sp[2];
-            if (flag == 0.0f) { mrow = sp[0]; inv = sp[1]; }
-        }
-        const bool tile_live = __any(flag == 0.0f ? 1 : 0) != 0;      // uniform and dead rows carry no score gradient
+        float mrow = 1e30f, inv = 0.0f;
         bf8 qh[NKS], ql[NKS], oh[NKS], ol[NKS];
-        float delta = 0.0f;
+        float delta = 0.0f, qvq = 0.0f;
+        bool normal = false;
         if (have) {
-            gfrag<SPLIT, NKS>(d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M, qh, ql);
-            gfrag<SPLIT, NKS>(bd.dout, bd.lddo, base_row + q0, hoff, T - q0, d.d, g.M, oh, ol);
+            normal = q < T && st_n.z == 0.0f;
+            if (normal) { mrow = st_n.x; inv = st_n.y; }
+            qvq = q < T ? qv_n : 0.0f;
+            gfrag_finish<SPLIT, NKS>(qn, d.Q, d.ld, base_row + q0, hoff, T - q0, d.d, g.M, qh, ql);
             if (bd.delta) {
-                delta = bd.delta[(size_t)blockIdx.x * T + qc];
+                delta = dl_n;
+                gfrag_finish<SPLIT, NKS>(on, bd.dout, bd.lddo, base_row + q0, hoff, T - q0, d.d, g.M, oh, ol);
             } else {
                 // delta[q] = sum_c dO[q][c] (O[q][c] - residual[q][c])  ==  sum_k dA[q][k] A[q][k] (mask and dropout included)
-                const bool rok = q < T;
-                const size_t row = (size_t)(base_row + qc);
+                gfrag_mask<NKS>(on, bd.dout, bd.lddo, base_row + q0, hoff, T - q0, d.d, g.M);
+                gfrag_mask<NKS>(un, d.out, d.ldo, base_row + q0, hoff, T - q0, d.d, g.M);
+                gfrag_mask<NKS>(rn, d.residual, d.ldr, base_row + q0, hoff, T - q0, d.d, g.M);
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int c = 32 * ks + 8 * lg + j;
-                        const int cc = c < d.d ? c : 0;
-                        const float go = bd.dout[row * bd.lddo + hoff + cc];
-                        const float oo = d.out[row * d.ldo + hoff + cc] - d.residual[row * d.ldr + hoff + cc];
-                        delta += (rok && c < d.d) ? go * oo : 0.0f;
-                    }
+                    for (int j = 0; j < 8; ++j) delta = fmaf(on.v[ks][j], un.v[ks][j] - rn.v[ks][j], delta);
                 delta = grp_sum(delta);
                 if (lg == 0 && q < T) delta_out[(size_t)blockIdx.x * T + q] = delta;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) split8<SPLIT>(on.v[ks], oh[ks], ol[ks]);
             }
         }
-        const float qvq = have ? d.q_valid[base_row + qc] * (q < T ? 1.0f : 0.0f) : 0.0f;
+        const bool tile_live = __any(normal ? 1 : 0) != 0;              // uniform and dead rows carry no score gradient
+        if (round == 0) BT_TS(4);
         const uint32_t ridx = attn_row_idx(d, head, n, q);
         const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
         f32x4 dq[NDT];
@@ -452,25 +788,51 @@ __global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g,
                 const int k0 = 2 * kp, k1 = 2 * kp + 1;
                 const int l0 = k0 - kt_c0, l1 = (k1 <= hi ? k1 : k0) - kt_c0;   // chunk-local tiles (l1 clamped: zeros below)
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                {
+                    bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf8 a0h = row_frag(Kh, 16 * l0, ks), a1h = row_frag(Kh, 16 * l1, ks);
-                    const bf8 a0l = SPLIT ? row_frag(Kl, 16 * l0, ks) : a0h, a1l = SPLIT ? row_frag(Kl, 16 * l1, ks) : a1h;
-                    s0 = mma<SPLIT>(a0h, a0l, qh[ks], ql[ks], s0);
-                    s1 = mma<SPLIT>(a1h, a1l, qh[ks], ql[ks], s1);
-                    const bf8 v0h = row_frag(Vh, 16 * l0, ks), v1h = row_frag(Vh, 16 * l1, ks);
-                    const bf8 v0l = SPLIT ? row_frag(Vl, 16 * l0, ks) : v0h, v1l = SPLIT ? row_frag(Vl, 16 * l1, ks) : v1h;
-                    p0 = mma<SPLIT>(v0h, v0l, oh[ks], ol[ks], p0);      // dA^T[key][q] = V dO^T
-                    p1 = mma<SPLIT>(v1h, v1l, oh[ks], ol[ks], p1);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        a0h[ks] = row_frag(Kh, 16 * l0, ks); a1h[ks] = row_frag(Kh, 16 * l1, ks);
+                        a0l[ks] = SPLIT ? row_frag(Kl, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag(Kl, 16 * l1, ks) : a1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s0 = mma<SPLIT>(a0h[ks], a0l[ks], qh[ks], ql[ks], s0);
+                        s1 = mma<SPLIT>(a1h[ks], a1l[ks], qh[ks], ql[ks], s1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                }
+                {
+                    bf8 v0h[NKS], v0l[NKS], v1h[NKS], v1l[NKS];
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        v0h[ks] = row_frag(Vh, 16 * l0, ks); v1h[ks] = row_frag(Vh, 16 * l1, ks);
+                        v0l[ks] = SPLIT ? row_frag(Vl, 16 * l0, ks) : v0h[ks]; v1l[ks] = SPLIT ? row_frag(Vl, 16 * l1, ks) : v1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        p0 = mma<SPLIT>(v0h[ks], v0l[ks], oh[ks], ol[ks], p0);      // dA^T[key][q] = V dO^T
+                        p1 = mma<SPLIT>(v1h[ks], v1l[ks], oh[ks], ol[ks], p1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                }
+                // the dQ product's K operand (transposed reads): first batch requested before the element-wise phase that hides it
+                bf8 bh[JB], bl[JB];
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    bh[jt] = tr_frag(Kh, 16 * l0, 16 * l1, jt);
+                    bl[jt] = SPLIT ? tr_frag(Kl, 16 * l0, 16 * l1, jt) : bh[jt];
                 }
                 float x[8];
-                auto finish = [&](int kt, int lt, const f32x4& s, const f32x4& p, bool on, int xo) {
+                auto finish = [&](int kt, int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
                     const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * lt + 4 * lg);
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = 16 * kt + 4 * lg + r;
-                        const bool valid = on && key <= q && bb[r] == 0.0f;              // causal + key mask
+                        const bool valid = on_ && key <= q && bb[r] == 0.0f;             // causal + key mask
                         const float e = __builtin_amdgcn_exp2f(fmaf(s[r], g.isd_log2e, -mrow)) * inv;
                         const float pn = valid ? e : 0.0f;
                         float w = qvq;
@@ -483,13 +845,22 @@ __global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g,
                 bf8 ah, al;
                 split8<SPLIT>(x, ah, al);
 #pragma unroll
-                for (int jt = 0; jt < NDT; ++jt) {
-                    const bf8 bh = tr_frag(Kh, 16 * l0, 16 * l1, jt);
-                    const bf8 bl = SPLIT ? tr_frag(Kl, 16 * l0, 16 * l1, jt) : bh;
-                    dq[jt] = mma<SPLIT>(ah, al, bh, bl, dq[jt]);                         // dQ += dS K
+                for (int jt = 0; jt < JB; ++jt) dq[jt] = mma<SPLIT>(ah, al, bh[jt], bl[jt], dq[jt]);    // dQ += dS K
+#pragma unroll
+                for (int j0 = JB; j0 < NDT; j0 += JB) {
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        bh[jt] = tr_frag(Kh, 16 * l0, 16 * l1, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag(Kl, 16 * l0, 16 * l1, j0 + jt) : bh[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(ah, al, bh[jt], bl[jt], dq[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
                 }
             }
         }
+        if (round == 0) BT_TS(5);
         if (have) {
 #pragma unroll
             for (int jt = 0; jt < NDT; ++jt)
@@ -499,15 +870,17 @@ __global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g,
                     if (qq < T && cidx < d.d) bd.dQ[(size_t)(base_row + qq) * bd.ldg + hoff + cidx] = dq[jt][r];
                 }
         }
+        if (round == 0) BT_TS(6);
     }
 }
 
 // =====================================================================================================
 // backward, key-owner pass: dK, dV of the wave's 16 keys, summed over queries in registers
 // =====================================================================================================
-template <int NKS, bool SPLIT>
-__global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g, const float* delta_in) {
+template <int NKS, bool SPLIT, bool MULTI, bool PAIRED>
+__device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const BfGeom& g, const float* delta_in) {
     constexpr int NDT = 2 * NKS;
+    constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Qh = reinterpret_cast<__bf16*>(smem_raw);
@@ -528,32 +901,32 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    BT_TS(8);
     const DropCtx dc = drop_ctx(d.drop);
     TileSched sch = sched_init(nw, wave);
-    const bool multi = g.nch > 1;
-    const int fvk = first_valid_key(d.k_valid, base_row, T);
+    constexpr bool multi = MULTI;                        // several 256-row chunks (T > 256): compiled as its own kernel
+    typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
     auto stage = [&](int c) {
         const int crow0 = c * BF_CH;
+        const int t = threadIdx.x, tq = crow0 + t;                       // ch_rows <= 256 < blockDim: one row per thread
+        const int tc = min(tq, T - 1);
+        const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)blockIdx.x * T + tc) * 4);
+        const float del = delta_in[(size_t)blockIdx.x * T + tc];
+        const float qv = d.q_valid[base_row + tc];
         stage_pair_bf<SPLIT, NKS>(Qh, Ql, d.Q, d.ld, Oh, Ol, bd.dout, bd.lddo, base_row, crow0, g.ch_rows, T, hoff, d.d, g.M);
-        for (int t = threadIdx.x; t < g.ch_rows; t += blockDim.x) {
-            const int tq = crow0 + t;
-            float flag = 2.0f, mx_ = 0.0f, inv_ = 0.0f, del_ = 0.0f, qv_ = 0.0f;
-            if (tq < T) {
-                const float* sp = d.row_stats + ((size_t)blockIdx.x * T + tq) * 4;
-                mx_ = sp[0]; inv_ = sp[1]; flag = sp[2];
-                del_ = delta_in[(size_t)blockIdx.x * T + tq];
-                qv_ = d.q_valid[base_row + tq];
-            }
+        if (t < g.ch_rows) {
+            const float flag = tq < T ? st.z : 2.0f;
             const bool normal = flag == 0.0f;
-            smx[t] = normal ? mx_ : 1e30f;
-            sinv[t] = normal ? inv_ : 0.0f;
-            sdel[t] = normal ? del_ : 0.0f;
+            smx[t] = normal ? st.x : 1e30f;
+            sinv[t] = normal ? st.y : 0.0f;
+            sdel[t] = normal ? del : 0.0f;
             suni[t] = (flag == 1.0f) ? g.invT : 0.0f;
-            sqv[t] = qv_;
+            sqv[t] = tq < T ? qv : 0.0f;
         }
     };
     auto stage_flags = [&]() {                                           // after a barrier: per query tile of the chunk
-        for (int t = threadIdx.x; t < g.ch_rows / 16; t += blockDim.x) {
+        const int t = threadIdx.x;
+        if (t < g.ch_rows / 16) {
             float f = 0.0f;
             for (int i = 0; i < 16; ++i) {
                 if (sinv[16 * t + i] != 0.0f && f < 1.0f) f = 1.0f;
@@ -562,26 +935,51 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
             tile_flag[t] = f;
         }
     };
+    const int rank = sched_rank(sch);
+    int tiles[2];
+    int ntile = 1;
+    if (PAIRED) {                                        // see bf_bwd_q_pass
+        tiles[0] = wave; tiles[1] = g.nkt - 1 - wave;                     // heavy one (low key tile) first
+        ntile = tiles[0] < tiles[1] ? 2 : (tiles[0] == tiles[1] ? 1 : 0);
+    } else {
+        tiles[0] = multi ? (int)blockIdx.y * nw + wave : rank; tiles[1] = -1;   // key tile 0 meets every query tile: rank == kt
+    }
+    GFrag<NKS> kn, vn;                                   // K / V fragments of the wave's next key tile, requested ahead
+    float kvn = 0.0f;
+    auto issue_tile = [&](int kt) {
+        gfrag_issue<NKS>(kn, d.K, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, g.M);
+        gfrag_issue<NKS>(vn, d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, g.M);
+        kvn = d.k_valid[base_row + min(16 * kt + li, T - 1)];
+    };
+    if (!PAIRED && tiles[0] >= 0 && tiles[0] < g.nkt) issue_tile(tiles[0]);
+    int fvk = 0;
     if (!multi) {
         stage(0);
+        BT_TS(9);
         __syncthreads();
         stage_flags();
         __syncthreads();
+        BT_TS(10);
+    } else {
+        fvk = first_valid_key(d.k_valid, base_row, T);
     }
-    const int nrounds = rounds_of(g, nw);
-    int rank = sched_rank(sch);
-    for (int round = 0; round < nrounds; ++round, rank = sched_next(sch)) {
-        const int kt = multi ? (int)blockIdx.y * nw + wave : rank;      // key tile 0 meets every query tile: rank == kt
-        const bool have = kt >= 0 && kt < g.nkt;
+#pragma unroll 1
+    for (int ti = 0; ti < (PAIRED ? ntile : 1); ++ti) {
+        const int round = ti;
+        const int kt = tiles[ti];
+        const bool have = (PAIRED || ntile > 0) && kt >= 0 && kt < g.nkt;
         const int key0 = 16 * (have ? kt : 0), key = key0 + li;
         const float key_in_T = (have && key < T) ? 1.0f : 0.0f;
         const uint32_t drop_base = attn_row_idx(d, head, n, 0) + (uint32_t)key;
         bf8 kh[NKS], kl[NKS], vh[NKS], vl[NKS];
+        bool kvk = false;
+        if (PAIRED && have) issue_tile(kt);             // paired tiles are not prefetched (see bf_bwd_q_pass)
         if (have) {
-            gfrag<SPLIT, NKS>(d.K, d.ld, base_row + key0, hoff, T - key0, d.d, g.M, kh, kl);
-            gfrag<SPLIT, NKS>(d.V, d.ld, base_row + key0, hoff, T - key0, d.d, g.M, vh, vl);
+            gfrag_finish<SPLIT, NKS>(kn, d.K, d.ld, base_row + key0, hoff, T - key0, d.d, g.M, kh, kl);
+            gfrag_finish<SPLIT, NKS>(vn, d.V, d.ld, base_row + key0, hoff, T - key0, d.d, g.M, vh, vl);
+            kvk = key < T && kvn != 0.0f;
         }
-        const bool kvk = have && key < T && d.k_valid[base_row + (key < T ? key : 0)] != 0.0f;
+        if (round == 0) BT_TS(11);
         const bool tile_has_key = __any(kvk ? 1 : 0) != 0;              // all-padding key tile: only uniform rows reach it
         f32x4 dk[NDT], dv[NDT];
 #pragma unroll
@@ -614,19 +1012,45 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
                 const bool w0 = wanted(l0), w1 = two && wanted(l1);
                 if (!w0 && !w1) continue;
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                {
+                    bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf8 a0h = row_frag(Qh, 16 * l0, ks), a1h = row_frag(Qh, 16 * l1, ks);
-                    const bf8 a0l = SPLIT ? row_frag(Ql, 16 * l0, ks) : a0h, a1l = SPLIT ? row_frag(Ql, 16 * l1, ks) : a1h;
-                    s0 = mma<SPLIT>(a0h, a0l, kh[ks], kl[ks], s0);      // S[q][key]
-                    s1 = mma<SPLIT>(a1h, a1l, kh[ks], kl[ks], s1);
-                    const bf8 o0h = row_frag(Oh, 16 * l0, ks), o1h = row_frag(Oh, 16 * l1, ks);
-                    const bf8 o0l = SPLIT ? row_frag(Ol, 16 * l0, ks) : o0h, o1l = SPLIT ? row_frag(Ol, 16 * l1, ks) : o1h;
-                    p0 = mma<SPLIT>(o0h, o0l, vh[ks], vl[ks], p0);      // dA[q][key] = dO V^T
-                    p1 = mma<SPLIT>(o1h, o1l, vh[ks], vl[ks], p1);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        a0h[ks] = row_frag(Qh, 16 * l0, ks); a1h[ks] = row_frag(Qh, 16 * l1, ks);
+                        a0l[ks] = SPLIT ? row_frag(Ql, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag(Ql, 16 * l1, ks) : a1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s0 = mma<SPLIT>(a0h[ks], a0l[ks], kh[ks], kl[ks], s0);      // S[q][key]
+                        s1 = mma<SPLIT>(a1h[ks], a1l[ks], kh[ks], kl[ks], s1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                }
+                {
+                    bf8 o0h[NKS], o0l[NKS], o1h[NKS], o1l[NKS];
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        o0h[ks] = row_frag(Oh, 16 * l0, ks); o1h[ks] = row_frag(Oh, 16 * l1, ks);
+                        o0l[ks] = SPLIT ? row_frag(Ol, 16 * l0, ks) : o0h[ks]; o1l[ks] = SPLIT ? row_frag(Ol, 16 * l1, ks) : o1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        p0 = mma<SPLIT>(o0h[ks], o0l[ks], vh[ks], vl[ks], p0);      // dA[q][key] = dO V^T
+                        p1 = mma<SPLIT>(o1h[ks], o1l[ks], vh[ks], vl[ks], p1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                }
+                // dOut columns for the dV product: first batch requested before the element-wise phase that hides it
+                bf8 oth[JB], otl[JB];
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    oth[jt] = tr_frag(Oh, 16 * l0, 16 * l1, jt);
+                    otl[jt] = SPLIT ? tr_frag(Ol, 16 * l0, 16 * l1, jt) : oth[jt];
                 }
                 float xa[8], xd[8];
-                auto finish = [&](int lt, const f32x4& s, const f32x4& p, bool on, int xo) {
+                auto finish = [&](int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
                     const int ql4 = 16 * lt + 4 * lg;                            // chunk-local index of this lane's 4 query rows
                     const int q4 = 16 * qt_c0 + ql4;
                     const float4 m4 = *reinterpret_cast<const float4*>(smx + ql4), i4 = *reinterpret_cast<const float4*>(sinv + ql4);
@@ -639,12 +1063,12 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
                     const uint32_t xT = (uint32_t)T * CR_PHI;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool valid = on && (key <= q4 + r) && kvk;          // causal + key mask
+                        const bool valid = on_ && (key <= q4 + r) && kvk;         // causal + key mask
                         const float e = __builtin_amdgcn_exp2f(fmaf(s[r], g.isd_log2e, -mm[r])) * ii[r];
                         const float pn = valid ? e : 0.0f;
                         float w = ww[r];
                         if (dc.on) w *= drop_factor_x(dc, x0 + (uint32_t)r * xT);
-                        xa[xo + r] = on ? (pn + key_in_T * uu[r]) * w : 0.0f;    // A after mask + dropout
+                        xa[xo + r] = on_ ? (pn + key_in_T * uu[r]) * w : 0.0f;   // A after mask + dropout
                         xd[xo + r] = pn * (p[r] * w - dd[r]) * g.isd;            // dS / sqrt(d)
                     }
                 };
@@ -654,16 +1078,34 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
                 split8<SPLIT>(xa, ah, al);
                 split8<SPLIT>(xd, dh, dl);
 #pragma unroll
-                for (int jt = 0; jt < NDT; ++jt) {
-                    const bf8 oh_ = tr_frag(Oh, 16 * l0, 16 * l1, jt);
-                    const bf8 ol_ = SPLIT ? tr_frag(Ol, 16 * l0, 16 * l1, jt) : oh_;
-                    dv[jt] = mma<SPLIT>(ah, al, oh_, ol_, dv[jt]);               // dV += A^T dO
-                    const bf8 qh_ = tr_frag(Qh, 16 * l0, 16 * l1, jt);
-                    const bf8 ql_ = SPLIT ? tr_frag(Ql, 16 * l0, 16 * l1, jt) : qh_;
-                    dk[jt] = mma<SPLIT>(dh, dl, qh_, ql_, dk[jt]);               // dK += dS^T Q
+                for (int jt = 0; jt < JB; ++jt) dv[jt] = mma<SPLIT>(ah, al, oth[jt], otl[jt], dv[jt]);    // dV += A^T dO
+#pragma unroll
+                for (int j0 = JB; j0 < NDT; j0 += JB) {
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        oth[jt] = tr_frag(Oh, 16 * l0, 16 * l1, j0 + jt);
+                        otl[jt] = SPLIT ? tr_frag(Ol, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(ah, al, oth[jt], otl[jt], dv[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                }
+#pragma unroll
+                for (int j0 = 0; j0 < NDT; j0 += JB) {
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        oth[jt] = tr_frag(Qh, 16 * l0, 16 * l1, j0 + jt);
+                        otl[jt] = SPLIT ? tr_frag(Ql, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(dh, dl, oth[jt], otl[jt], dk[j0 + jt]);   // dK += dS^T Q
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
                 }
             }
         }
+        if (round == 0) BT_TS(12);
         if (have) {
 #pragma unroll
             for (int jt = 0; jt < NDT; ++jt)
@@ -676,7 +1118,32 @@ __global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g,
                     }
                 }
         }
+        if (round == 0) BT_TS(13);
     }
+}
+
+template <int NKS, bool SPLIT, bool MULTI>
+__global__ __launch_bounds__(512) void k_bf_bwd_q(cr_attn_bwd_desc bd, BfGeom g, float* delta_out) {
+    bf_bwd_q_pass<NKS, SPLIT, MULTI, false>(bd, g, delta_out);
+    BT_TS(15);
+}
+template <int NKS, bool SPLIT, bool MULTI>
+__global__ __launch_bounds__(512) void k_bf_bwd_k(cr_attn_bwd_desc bd, BfGeom g, const float* delta_in) {
+    bf_bwd_k_pass<NKS, SPLIT, MULTI, false>(bd, g, delta_in);
+    BT_TS(15);
+}
+// Both passes in ONE launch (T <= 256, delta supplied by the caller): workgroup y = 0 of a sample runs the whole
+// query-owner pass, workgroup y = 1 the whole key-owner pass, side by side on two CUs.  Inside a pass the wave w owns
+// tiles w and nkt-1-w (a heavy and a light one): nkt + 1 tile pairs for EVERY wave, where the separate kernels --
+// one tile per wave, the two passes one after the other -- each end on the wave that owns the heaviest tile (13 pairs
+// at T = 200 against an average of 7).  A first fused form (both passes in every workgroup, the K / V images replaced
+// by the Q / dOut images in between) gained nothing: the barrier between the passes re-synchronises the waves at the
+// heaviest tile of EACH pass (profiles/r02_*: 34.4 against 35.6 us).
+template <int NKS, bool SPLIT>
+__global__ __launch_bounds__(512) void k_bf_bwd_fused(cr_attn_bwd_desc bd, BfGeom g) {
+    if (blockIdx.y == 0) bf_bwd_q_pass<NKS, SPLIT, false, true>(bd, g, nullptr);
+    else bf_bwd_k_pass<NKS, SPLIT, false, true>(bd, g, bd.delta);
+    BT_TS(15);
 }
 
 // =====================================================================================================
@@ -691,19 +1158,17 @@ static int bf_geom(const cr_attn_desc* d, BfGeom* g) {
     g->isd = (float)(1.0 / sqrt((double)d->d));
     g->isd_log2e = (float)(1.4426950408889634 / sqrt((double)d->d));
     g->invT = 1.0f / (float)d->T;
+    g->ts = nullptr;
     return CR_OK;
 }
 
-bool cr_attn_bf_supported_fwd(const cr_attn_desc* d) { return d->T <= 256 && d->d >= 1 && d->d <= 64; }
-bool cr_attn_bf_supported_bwd(const cr_attn_desc* d) { return d->T <= 1024 && d->d >= 1 && d->d <= 64 && d->row_stats != nullptr; }
-
-static int bf_nsplit(const cr_attn_desc* d, const BfGeom& g) {
-    if (g.nch > 1) return (g.nkt + 7) / 8;                               // one workgroup per block of 8 tiles
-    int want = (256 + d->B * d->H - 1) / (d->B * d->H);
-    const int maxs = (g.nkt + 7) / 8;
-    if (want > maxs) want = maxs;
-    return want < 1 ? 1 : want;
+bool cr_attn_bf_supported_fwd(const cr_attn_desc* d) {
+    return d->d >= 8 && d->d <= 64 && (d->T <= 256 || (d->T <= 1024 && d->attn_weights == nullptr));
 }
+bool cr_attn_bf_supported_bwd(const cr_attn_desc* d) { return d->T <= 1024 && d->d >= 8 && d->d <= 64 && d->row_stats != nullptr; }
+
+// workgroups per (sample, head): every wave owns ONE 16-row tile (8 waves per workgroup)
+static int bf_nsplit(const cr_attn_desc* d, const BfGeom& g) { (void)d; return (g.nkt + 7) / 8; }
 
 template <int NKT, int NKS, bool SPLIT>
 static int launch_bf_fwd(const cr_attn_desc* d, const BfGeom& g, hipStream_t s) {
@@ -711,7 +1176,9 @@ static int launch_bf_fwd(const cr_attn_desc* d, const BfGeom& g, hipStream_t s) 
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_fwd<NKT, NKS, SPLIT>), &attr_set);
     if (rc) return rc;
     const size_t lds = (size_t)g.T16 * 128 * 2 * (SPLIT ? 2 : 1) + (size_t)g.T16 * 4;
-    hipLaunchKernelGGL((k_bf_fwd<NKT, NKS, SPLIT>), dim3(d->B * d->H, bf_nsplit(d, g)), dim3(512), lds, s, *d, g);
+    BfGeom gg = g;
+    if (g_attn_ts_which == 4) gg.ts = g_attn_ts;
+    hipLaunchKernelGGL((k_bf_fwd<NKT, NKS, SPLIT>), dim3(d->B * d->H, bf_nsplit(d, g)), dim3(512), lds, s, *d, gg);
     return cr_check_launch("cr_attn_fwd(bf16)");
 }
 
@@ -722,30 +1189,59 @@ static int dispatch_bf_fwd(const cr_attn_desc* d, const BfGeom& g, hipStream_t s
     return split ? launch_bf_fwd<NKT, 2, true>(d, g, s) : launch_bf_fwd<NKT, 2, false>(d, g, s);
 }
 
+template <int NKS, bool SPLIT>
+static int launch_bf_fwd_long(const cr_attn_desc* d, const BfGeom& g, hipStream_t s) {
+    static cr_devmask attr_set = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_fwd_long<NKS, SPLIT>), &attr_set);
+    if (rc) return rc;
+    const size_t lds = (size_t)BF_CH * 128 * 2 * (SPLIT ? 2 : 1) + (size_t)BF_CH * 4;
+    hipLaunchKernelGGL((k_bf_fwd_long<NKS, SPLIT>), dim3(d->B * d->H, bf_nsplit(d, g)), dim3(512), lds, s, *d, g);
+    return cr_check_launch("cr_attn_fwd(bf16, long)");
+}
+
 int cr_attn_bf_fwd_launch(const cr_attn_desc* d, hipStream_t s) {
     BfGeom g;
     bf_geom(d, &g);
+    if (g.nch > 1) {
+        const bool split = d->precision == CR_PREC_BF16X3;
+        if (d->d <= 32) return split ? launch_bf_fwd_long<1, true>(d, g, s) : launch_bf_fwd_long<1, false>(d, g, s);
+        return split ? launch_bf_fwd_long<2, true>(d, g, s) : launch_bf_fwd_long<2, false>(d, g, s);
+    }
     if (g.nkt <= 4) return dispatch_bf_fwd<4>(d, g, s);
     if (g.nkt <= 13) return dispatch_bf_fwd<13>(d, g, s);
     return dispatch_bf_fwd<16>(d, g, s);
 }
 
-template <int NKS, bool SPLIT>
+static const bool g_bf_two_kernels = getenv("CASTREC_BF_TWO_KERNELS") != nullptr;   // debugging: never fuse the backward passes
+
+template <int NKS, bool SPLIT, bool MULTI>
 static int launch_bf_bwd(const cr_attn_bwd_desc* bd, const BfGeom& g, hipStream_t s) {
     static cr_devmask attr_q = 0, attr_k = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_q<NKS, SPLIT>), &attr_q);
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_q<NKS, SPLIT, MULTI>), &attr_q);
     if (rc) return rc;
-    rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_k<NKS, SPLIT>), &attr_k);
+    rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_k<NKS, SPLIT, MULTI>), &attr_k);
     if (rc) return rc;
     const cr_attn_desc* d = &bd->f;
     const size_t img = (size_t)g.ch_rows * 128 * 2 * (SPLIT ? 2 : 1);
     const dim3 grid(d->B * d->H, bf_nsplit(d, g));
     float* dws = bd->stats;                                              // delta workspace [H*B*T] when the caller gave none
-    hipLaunchKernelGGL((k_bf_bwd_q<NKS, SPLIT>), grid, dim3(512), img + (size_t)g.ch_rows * 4, s, *bd, g, dws);
+    if (!MULTI && bd->delta && !g_bf_two_kernels) {
+        static cr_devmask attr_f = 0;
+        rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_fused<NKS, SPLIT>), &attr_f);
+        if (rc) return rc;
+        BfGeom gf = g;
+        if (g_attn_ts_which == 5) gf.ts = g_attn_ts;
+        hipLaunchKernelGGL((k_bf_bwd_fused<NKS, SPLIT>), dim3(d->B * d->H, 2), dim3(512), img + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4, s, *bd, gf);
+        return cr_check_launch("cr_attn_bwd(bf16, fused)");
+    }
+    BfGeom gq = g, gk = g;
+    if (g_attn_ts_which == 5) gq.ts = g_attn_ts;
+    if (g_attn_ts_which == 6) gk.ts = g_attn_ts;
+    hipLaunchKernelGGL((k_bf_bwd_q<NKS, SPLIT, MULTI>), grid, dim3(512), img + (size_t)g.ch_rows * 4, s, *bd, gq, dws);
     rc = cr_check_launch("cr_attn_bwd(bf16, q)");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_bf_bwd_k<NKS, SPLIT>), grid, dim3(512), img + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4, s,
-                       *bd, g, bd->delta ? bd->delta : dws);
+    hipLaunchKernelGGL((k_bf_bwd_k<NKS, SPLIT, MULTI>), grid, dim3(512), img + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4, s,
+                       *bd, gk, bd->delta ? bd->delta : dws);
     return cr_check_launch("cr_attn_bwd(bf16, k)");
 }
 
@@ -755,6 +1251,11 @@ int cr_attn_bf_bwd_launch(const cr_attn_bwd_desc* bd, hipStream_t s) {
     bf_geom(d, &g);
     const bool split = d->precision == CR_PREC_BF16X3;
     if (!bd->delta) CR_REQUIRE(d->out && d->residual, "cr_attn_bwd(bf16): out / residual needed to form delta");
-    if (d->d <= 32) return split ? launch_bf_bwd<1, true>(bd, g, s) : launch_bf_bwd<1, false>(bd, g, s);
-    return split ? launch_bf_bwd<2, true>(bd, g, s) : launch_bf_bwd<2, false>(bd, g, s);
+    const bool multi = g.nch > 1;
+    if (d->d <= 32) {
+        if (multi) return split ? launch_bf_bwd<1, true, true>(bd, g, s) : launch_bf_bwd<1, false, true>(bd, g, s);
+        return split ? launch_bf_bwd<1, true, false>(bd, g, s) : launch_bf_bwd<1, false, false>(bd, g, s);
+    }
+    if (multi) return split ? launch_bf_bwd<2, true, true>(bd, g, s) : launch_bf_bwd<2, false, true>(bd, g, s);
+    return split ? launch_bf_bwd<2, true, false>(bd, g, s) : launch_bf_bwd<2, false, false>(bd, g, s);
 }

@@ -19,10 +19,12 @@ pytestmark = pytest.mark.gpu
 TOL = {1: 2e-4, 2: 3e-2}
 
 CASES = [  # B, T, H, d, rate
-    (3, 8, 1, 6, 0.0), (2, 50, 1, 50, 0.0), (2, 200, 1, 50, 0.2), (3, 37, 2, 32, 0.0), (2, 50, 4, 32, 0.5),
+    (3, 8, 1, 8, 0.0), (2, 50, 1, 50, 0.0), (2, 200, 1, 50, 0.2), (3, 37, 2, 32, 0.0), (2, 50, 4, 32, 0.5),
     (1, 256, 1, 64, 0.0), (2, 100, 2, 25, 0.3), (5, 16, 1, 50, 0.0), (5, 24, 1, 20, 0.0), (4, 20, 1, 50, 0.2),
     (130, 50, 1, 50, 0.2),          # more (sample, head) pairs than CUs: one workgroup per sample, two rounds of tiles
     (2, 200, 4, 32, 0.2),           # config C4's head geometry (D = 128, 4 heads)
+    # T > 256: K / V (Q / dOut) stream through LDS in 256-row chunks, online softmax in the forward
+    (3, 257, 1, 50, 0.0), (2, 300, 1, 50, 0.2), (2, 512, 2, 64, 0.0), (2, 512, 4, 64, 0.2), (1, 1024, 1, 16, 0.1),
 ]
 
 
@@ -69,14 +71,15 @@ def test_attention_bf16_mfma_fwd_bwd(ops, B, T, H, d, rate, prec):
     wts = torch.full((H * B, T, T), float("nan"), device="cuda")
     rst = torch.full((H * B * T * 4,), float("nan"), device="cuda")
     kvd, qvd = dev(kvalid.reshape(-1)), dev(qvalid.reshape(-1))
-    desc = ops.attn_desc(Qd, Kd, Vd, ld, kvd, qvd, Rd, ld, out, ld, B, T, H, d, rng=drop.rng(21), attn_weights=wts,
-                         row_stats=rst, precision=prec)
+    long_t = T > 256                                     # the chunked forward does not materialise attention_weights
+    desc = ops.attn_desc(Qd, Kd, Vd, ld, kvd, qvd, Rd, ld, out, ld, B, T, H, d, rng=drop.rng(21),
+                         attn_weights=None if long_t else wts, row_stats=rst, precision=prec)
     ops.attn_fwd(desc)
     dQ, dK, dV = (torch.full((M, ld), float("nan"), device="cuda") for _ in range(3))
     stats = torch.full((H * B * T * 4,), float("nan"), device="cuda")
     ops.attn_bwd(desc, dOd, ld, dQ, dK, dV, ld, stats)           # delta formed inside (from out and residual)
     torch.cuda.synchronize()
-    errs = dict(w=relerr(wts, w.detach().numpy()), out=relerr(out[:, :Cc], ref.detach().numpy().reshape(M, Cc)),
+    errs = dict(w=0.0 if long_t else relerr(wts, w.detach().numpy()), out=relerr(out[:, :Cc], ref.detach().numpy().reshape(M, Cc)),
                 dV=relerr(dV[:, :Cc], Vt.grad.numpy().reshape(M, Cc)), dQ=relerr(dQ[:, :Cc], Qt.grad.numpy().reshape(M, Cc)),
                 dK=relerr(dK[:, :Cc], Kt.grad.numpy().reshape(M, Cc)))
     print("bf16-mfma attn errs prec=%d" % prec, errs)
