@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--num_heads", type=int, default=1)
     ap.add_argument("--dropout_rate", type=float, default=0.2)
     ap.add_argument("--n_slabs", type=int, default=0, help="gradient slabs; 0 = engine default (ceil(M/128) capped at 256)")
+    ap.add_argument("--attn_precision", default=None, choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the attention products (default: the engine's, bf16x3 = bf16 MFMA on hi+lo split operands)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel HIP-event table here")
@@ -208,7 +210,7 @@ def main():
     staged = torch.from_numpy(np.stack([np.stack([a.reshape(-1) for a in hb]) for hb in host_batches]).astype(np.int32)).cuda()
 
     eng = E.Engine(args.model, corpus.usernum, corpus.itemnum, hyper(args), B, training=True, n_slabs=args.n_slabs,
-                   batch_global=Bg, row_offset=rank * B * T)
+                   batch_global=Bg, row_offset=rank * B * T, attn_precision=args.attn_precision)
     dp = dist is not None
     if dp:
         dist.broadcast(eng.P, 0)

@@ -1165,7 +1165,8 @@ static int bf_geom(const cr_attn_desc* d, BfGeom* g) {
 bool cr_attn_bf_supported_fwd(const cr_attn_desc* d) {
     return d->d >= 8 && d->d <= 64 && (d->T <= 256 || (d->T <= 1024 && d->attn_weights == nullptr));
 }
-bool cr_attn_bf_supported_bwd(const cr_attn_desc* d) { return d->T <= 1024 && d->d >= 8 && d->d <= 64 && d->row_stats != nullptr; }
+// (the backward reads the row statistics the bf16 forward saved: same shape conditions as the forward)
+bool cr_attn_bf_supported_bwd(const cr_attn_desc* d) { return cr_attn_bf_supported_fwd(d) && d->row_stats != nullptr; }
 
 // workgroups per (sample, head): every wave owns ONE 16-row tile (8 waves per workgroup)
 static int bf_nsplit(const cr_attn_desc* d, const BfGeom& g) { (void)d; return (g.nkt + 7) / 8; }

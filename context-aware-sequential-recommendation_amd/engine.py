@@ -24,6 +24,11 @@ import torch
 from . import lib as L
 from . import ops as O
 
+# arithmetic of the attention products (castrec.h CR_PREC_*): "f32" = exact fp32 MFMA; "bf16x3" = bf16 MFMA on hi + lo
+# split operands (three products, ~1e-5 relative: inside the 1e-3 fp32 bound); "bf16" = plain bf16 operands
+ATTN_PRECISIONS = {"f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
+DEFAULT_ATTN_PRECISION = "bf16x3"
+
 MODELS = ["cast_1", "cast_2", "cast_3", "cast_4", "cast_5", "cast_6", "cast_7", "cast_8", "cast_9",
           "sasrec", "sasrec_static"]          # main.py:28
 
@@ -173,13 +178,19 @@ class ParamLayout:
 # ---------------------------------------------------------------------------------------------------
 class Engine:
     def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=None,
-                 share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda", fused=None):
+                 share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda", fused=None,
+                 attn_precision=None):
         if model not in MODELS:
             raise ValueError("model must be one of %s" % MODELS)
         if not torch.cuda.is_available():
             raise RuntimeError("castrec_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.model, self.hp, self.B, self.T, self.D = model, hp, batch_size, hp.maxlen, hp.hidden_units
         self.H = hp.num_heads
+        if attn_precision is None:
+            attn_precision = os.environ.get("CASTREC_ATTN_PRECISION") or getattr(hp, "attn_precision", None) or DEFAULT_ATTN_PRECISION
+        if attn_precision not in ATTN_PRECISIONS:
+            raise ValueError("attn_precision must be one of %s" % sorted(ATTN_PRECISIONS))
+        self.attn_precision = attn_precision
         self.M = self.B * self.T
         self.usernum, self.itemnum = usernum, itemnum
         self.training = training
@@ -438,6 +449,10 @@ class Engine:
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
                          dead_ids=None if attn_out is not None else ids, attn_weights=attn_out)
         ad.K, ad.V = qkv.data_ptr() + MD4, qkv.data_ptr() + 2 * MD4
+        ad.precision = ATTN_PRECISIONS[self.attn_precision]
+        if self.training and ad.precision != L.PREC_F32:
+            # the bf16-MFMA backward recomputes the probabilities from the forward's row statistics
+            ad.row_stats = self.vec(pfx + "row_stats", H * B * T * 4).data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         # LN2 + FFN (modules.py:280-318), residual = LN2 output, then * mask (sasrec.py:83)
         ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
@@ -539,8 +554,10 @@ class Engine:
         ad.K, ad.V = qkv.data_ptr() + MD4, qkv.data_ptr() + 2 * MD4
         # single-pass attention backward (H = 1): the forward saves its row statistics, the FFN backward emits
         # delta, the attention backward returns dQ as two partials that the QKV backward adds
-        one_pass = self.training and H == 1 and self.single_pass_bwd
-        if one_pass:
+        ad.precision = ATTN_PRECISIONS[self.attn_precision]
+        bf = ad.precision != L.PREC_F32 and 8 <= D // H <= 64 and T <= 1024     # shapes the bf16-MFMA kernels take
+        one_pass = self.training and H == 1 and self.single_pass_bwd and not bf
+        if one_pass or (self.training and bf):
             row_stats = self.vec(pfx + "row_stats", H * B * T * 4)
             ad.row_stats = row_stats.data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
@@ -576,6 +593,12 @@ class Engine:
                 dq_part = self.buf("attn_dq_part", D)
                 bbd.attn_delta, bbd.dq_part = delta.data_ptr(), dq_part.data_ptr()
                 abd.delta, abd.dQ_part = delta.data_ptr(), dq_part.data_ptr()
+            elif bf and H == 1:
+                # bf16-MFMA backward: the FFN backward emits delta (one head: its row sum IS the head's), which lets
+                # both passes run side by side in one launch; dQ comes back whole
+                delta = self.vec("attn_delta", M)
+                bbd.attn_delta = delta.data_ptr()
+                abd.delta = delta.data_ptr()
             self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             recipe = self._scatter_recipe.get(x.data_ptr())
