@@ -337,10 +337,61 @@ __global__ __launch_bounds__(256) void k_test_logits(const float* seq_emb, int l
     }
 }
 
+// The same for hidden sizes that are multiples of 4 (16-byte rows): a read-only row gather, the form the HBM-read
+// roofline of the item table is measured on (bench.py "gather" block).  16 lanes own a candidate row (float4 per lane
+// per 64 columns), a wave keeps 4 rows x NR rounds in flight, the row sum is four DPP adds.  NV = D / 64 rounded up.
+template <int NV>
+__global__ __launch_bounds__(256) void k_test_logits_v4(const float* seq_emb, int ld, const float* table, const int32_t* cand,
+                                                        int B, int T, int D, int n_cand, float* logits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, grp = (threadIdx.x >> 4);   // 16 groups per block
+    const int b = blockIdx.x;
+    const float* s = seq_emb + (size_t)(b * T + T - 1) * ld;
+    typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
+    f4a sv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * li + 64 * i;
+        sv[i] = c < D ? *reinterpret_cast<const f4a*>(s + c) : (f4a){0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int NR = 2;                                   // candidates per group and iteration
+    for (int j0 = grp * NR; j0 < n_cand; j0 += 16 * NR) {
+        int id[NR];
+        float4 rv[NR][NV];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) id[r] = (j0 + r < n_cand) ? cand[(size_t)b * n_cand + j0 + r] : 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = 4 * li + 64 * i;
+                rv[r][i] = *reinterpret_cast<const float4*>(table + (size_t)id[r] * D + (c < D ? c : 0));
+            }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool ok = 4 * li + 64 * i < D;
+                acc += ok ? (sv[i].x * rv[r][i].x + sv[i].y * rv[r][i].y + sv[i].z * rv[r][i].z + sv[i].w * rv[r][i].w) : 0.0f;
+            }
+            acc = cr_row16_sum(acc);
+            if (li == 0 && j0 + r < n_cand) logits[(size_t)b * n_cand + j0 + r] = id[r] != 0 ? acc : 0.0f;   // row 0 reads as zeros
+        }
+    }
+    (void)wave;
+}
+
 extern "C" int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand, int B, int T, int D,
                               int V, int n_cand, float* logits, void* stream) {
     CR_REQUIRE(seq_emb && table && cand && logits, "cr_test_logits: NULL pointer");
     CR_REQUIRE(B > 0 && T > 0 && D > 0 && V > 0 && n_cand > 0 && ld >= D, "cr_test_logits: bad shape");
-    hipLaunchKernelGGL(k_test_logits, dim3(B), dim3(256), 0, cr_stream(stream), seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+    hipStream_t st = cr_stream(stream);
+    if (D % 4 == 0 && D <= 256 && (reinterpret_cast<uintptr_t>(table) & 15) == 0) {
+        if (D <= 64) hipLaunchKernelGGL(k_test_logits_v4<1>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else if (D <= 128) hipLaunchKernelGGL(k_test_logits_v4<2>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else hipLaunchKernelGGL(k_test_logits_v4<4>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        return cr_check_launch("cr_test_logits");
+    }
+    hipLaunchKernelGGL(k_test_logits, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
     return cr_check_launch("cr_test_logits");
 }

@@ -10,7 +10,13 @@ The reference has no distributed code; the scheme follows SURVEY 8e:
     Adam divides by the reduced count;
   * bucket = [item/pos table grads | dense grads | loss_sum, auc_sum, n_target, pad] -- 0.9 MB for
     SASRec/CAST at D=50: one latency-bound ring all-reduce per step (xGMI links are point to point, so
-    many small collectives would each pay the ring latency).
+    many small collectives would each pay the ring latency);
+  * large item tables (config C5: 10 M x 256 fp32 = 10.24 GB) are NOT all-reduced densely: a step
+    touches at most 3*B_local*T rows per rank (seq, pos, neg ids), so the ranks all-gather their de-duplicated
+    (row id, gradient row) pairs and every rank adds them into its (otherwise zero) table gradient in rank
+    order -- the same sums in the same order everywhere, so replicas stay bit-identical -- while the small
+    rest of the bucket (positional table, dense gradients, loss statistics) takes the one all-reduce.
+    Chosen per engine from the byte counts (sparse_exchange_bytes vs dense_allreduce_bytes below).
 
 `Replica` is the minimal protocol the wrapper needs; castrec_amd.engine.Engine implements it on the GPU,
 tests/test_dist_cpu.py drives the same wrapper over gloo with an oracle-backed replica."""
@@ -45,11 +51,51 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
-class DataParallel:
-    """Drives one replica per rank: local backward -> flat all-reduce -> identical Adam on every rank."""
+def dense_allreduce_bytes(n_floats, world):
+    """Bytes a rank sends in a ring all-reduce of n_floats fp32 (reduce-scatter + all-gather)."""
+    return 2.0 * (world - 1) / world * n_floats * 4
 
-    def __init__(self, replica, rank, world, process_group=None):
+
+def sparse_exchange_bytes(n_slots, D, world):
+    """Bytes a rank receives in the all-gather of n_slots (int32 row id, fp32 gradient row of D) pairs per rank."""
+    return (world - 1) * n_slots * (4 + 4 * D)
+
+
+def exchange_table_rows(table, ids, world, group=None):
+    """Sums over ranks the rows of `table` ([V, D] view of this rank's table-gradient bucket) that this step touched.
+    ids: 1-D integer tensor of this rank's contributing row ids (duplicates and the zero-pad id 0 allowed; every row
+    outside it must be zero).  On return `table` equals what a dense all-reduce would have produced, bit-identical on
+    all ranks: a row's partial sums are added in rank order and a rank's list holds a row once."""
+    import torch.distributed as dist
+    srt = torch.sort(ids.to(torch.int64)).values
+    first = torch.ones_like(srt, dtype=torch.bool)
+    first[1:] = srt[1:] != srt[:-1]
+    idu = torch.where(first, srt, torch.zeros_like(srt))          # later duplicates -> row 0, whose gradient is always zero
+    rows = table.index_select(0, idu) * first.unsqueeze(1).to(table.dtype)
+    ids32 = idu.to(torch.int32)
+    all_ids = [torch.empty_like(ids32) for _ in range(world)]
+    all_rows = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(all_ids, ids32, group=group)
+    dist.all_gather(all_rows, rows, group=group)
+    table.index_fill_(0, idu, 0.0)                                # this rank's share travels in `rows` like everyone's
+    for r in range(world):                                        # fixed order: the sums match on every rank
+        table.index_add_(0, all_ids[r].to(torch.int64), all_rows[r])
+
+
+class DataParallel:
+    """Drives one replica per rank: local backward -> gradient exchange -> identical Adam on every rank.
+
+    sparse: None = choose from the byte counts when the replica offers sparse_spec(); True / False force it."""
+
+    def __init__(self, replica, rank, world, process_group=None, sparse=None):
         self.replica, self.rank, self.world, self.pg = replica, rank, world, process_group
+        self.sparse = False
+        spec = replica.sparse_spec() if hasattr(replica, "sparse_spec") else None
+        if world > 1 and spec is not None and sparse is not False:
+            dense = dense_allreduce_bytes(spec["n_item"], world)
+            sp = sparse_exchange_bytes(spec["n_slots"], spec["D"], world)
+            self.sparse = True if sparse else (sp < 0.5 * dense)   # only when it at least halves the traffic
+            self.exchange_bytes = dict(dense_allreduce=dense, sparse_allgather=sp)
         if world > 1:
             import torch.distributed as dist
             dist.broadcast(replica.param_vector(), 0, group=process_group)       # same start everywhere
@@ -58,10 +104,21 @@ class DataParallel:
         """batch_global: tuple of [B_global, T] int arrays (seq, pos, neg, time, hours, days)."""
         lo, hi = shard_rows(len(batch_global[0]), self.rank, self.world)
         bucket = self.replica.backward_to_flat(tuple(a[lo:hi] for a in batch_global))
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(bucket, group=self.pg)                                # sum of grads and of loss statistics
+        self.exchange(bucket)
         self.replica.adam_from_flat()
+
+    def exchange(self, bucket):
+        """Sums `bucket` ([item table grads | small part]) over the ranks, in place."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        if self.sparse:
+            spec = self.replica.sparse_spec()
+            n_item, D = spec["n_item"], spec["D"]
+            exchange_table_rows(bucket[:n_item].view(-1, D), spec["ids"]().to(bucket.device), self.world, self.pg)
+            dist.all_reduce(bucket[n_item:], group=self.pg)                       # positional table, dense grads, loss statistics
+        else:
+            dist.all_reduce(bucket, group=self.pg)                                # sum of grads and of loss statistics
 
 
 class EngineReplica:
@@ -85,3 +142,9 @@ class EngineReplica:
 
     def adam_from_flat(self):
         self.e.launch_adam_from_flat()
+
+    def sparse_spec(self):
+        """The item table leads the bucket; its gradient rows of a step are those of the seq / pos / neg ids
+        (embedding backward: modules.py:157; head: sasrec.py:89-90)."""
+        e = self.e
+        return dict(n_item=(e.itemnum + 1) * e.D, D=e.D, n_slots=3 * e.M, ids=lambda: e.ids_all[:3].reshape(-1))

@@ -19,16 +19,19 @@ from oracle import fpmodel as fm
 
 MODEL = "cast_1"
 HP = fm.Hyper(maxlen=10, hidden_units=8, num_blocks=1, num_heads=2, dropout_rate=0.0, max_bins=6, lr=1e-2)
+ITEMS = 20
 
 
 class OracleReplica:
-    def __init__(self, seed=0):
-        self.P = fm.init_params(MODEL, 7, 20, HP, seed=seed)
-        self.names = sorted(self.P)
+    def __init__(self, seed=0, itemnum=ITEMS):
+        self.itemnum = itemnum
+        self.P = fm.init_params(MODEL, 7, itemnum, HP, seed=seed)
+        self.names = ["item_emb"] + sorted(k for k in self.P if k != "item_emb")     # the item table leads the bucket, as in the engine
         self.sizes = [self.P[k].numel() for k in self.names]
         self.vec = torch.cat([self.P[k].reshape(-1) for k in self.names])
         self.bucket = torch.zeros(self.vec.numel() + 4, dtype=torch.float64)
         self.opt = fm.AdamTF(self.P, lr=HP.lr)
+        self.shard_ids = torch.zeros(3 * 4 * HP.maxlen, dtype=torch.int64)
 
     def param_vector(self):
         return self.vec
@@ -38,7 +41,12 @@ class OracleReplica:
         for k, n in zip(self.names, self.sizes):
             self.P[k] = self.vec[off:off + n].reshape(self.P[k].shape).clone(); off += n
 
+    def sparse_spec(self):
+        return dict(n_item=(self.itemnum + 1) * HP.hidden_units, D=HP.hidden_units, n_slots=3 * self.shard_ids.numel() // 3,
+                    ids=lambda: self.shard_ids)
+
     def backward_to_flat(self, shard):
+        self.shard_ids = torch.tensor(np.concatenate([np.asarray(a).reshape(-1) for a in shard[:3]]))
         self._sync_from_vec()
         out, G = fm.loss_and_grads(MODEL, self.P, HP, fm.to_batch(*shard))
         n = float(out["istarget"].sum())
@@ -58,9 +66,9 @@ class OracleReplica:
         self.loss = float(self.bucket[-4]) / n
 
 
-def make_batch(B=8, T=10, seed=3):
+def make_batch(B=8, T=10, seed=3, itemnum=ITEMS):
     rs = np.random.RandomState(seed)
-    seq = rs.randint(1, 21, (B, T)); pos = rs.randint(1, 21, (B, T)); neg = rs.randint(1, 21, (B, T))
+    seq = rs.randint(1, itemnum + 1, (B, T)); pos = rs.randint(1, itemnum + 1, (B, T)); neg = rs.randint(1, itemnum + 1, (B, T))
     for b in range(B):
         n = rs.randint(0, T - 2)
         seq[b, :n] = 0; pos[b, :n] = 0; neg[b, :n] = 0          # ragged: ranks see different target counts
@@ -69,12 +77,13 @@ def make_batch(B=8, T=10, seed=3):
     return seq, pos, neg, time, z, z
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, itemnum=ITEMS, sparse=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rep = OracleReplica(seed=rank)            # different init per rank: the wrapper must broadcast rank 0's
-    dp = DataParallel(rep, rank, world)
-    batch = make_batch()
+    rep = OracleReplica(seed=rank, itemnum=itemnum)   # different init per rank: the wrapper must broadcast rank 0's
+    dp = DataParallel(rep, rank, world, sparse=sparse)
+    assert dp.sparse == bool(sparse)
+    batch = make_batch(itemnum=itemnum)
     for _ in range(2):
         dp.step(batch)
     q.put((rank, rep.param_vector().numpy().copy(), rep.loss))
@@ -88,21 +97,33 @@ def test_shard_rows():
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_step_equals_single_process():
+@pytest.mark.parametrize("itemnum,sparse", [(ITEMS, False), (ITEMS, True), (3000, True)])
+def test_two_rank_step_equals_single_process(itemnum, sparse):
+    """dense: one flat all-reduce.  sparse: all-gather of de-duplicated (row id, gradient row) pairs for the item table
+    (hot rows shared by both ranks at 20 items; V = 3001 >> 240 touched rows: the C5 regime) + all-reduce of the rest."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, itemnum, sparse)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=100) for _ in procs])
     for p in procs:
         p.join(timeout=30)
-    ref = OracleReplica(seed=0)
+    ref = OracleReplica(seed=0, itemnum=itemnum)
     one = DataParallel(ref, 0, 1)
-    batch = make_batch()
+    batch = make_batch(itemnum=itemnum)
     for _ in range(2):
         one.step(batch)
     for rank, vec, loss in res:
         np.testing.assert_allclose(vec, ref.param_vector().numpy(), rtol=0, atol=1e-12)
         assert loss == pytest.approx(ref.loss, rel=1e-12)
+    assert np.array_equal(res[0][1], res[1][1])                   # replicas bit-identical (fixed summation order)
+
+
+def test_exchange_picks_the_cheaper_form():
+    from castrec_amd.dist import dense_allreduce_bytes, sparse_exchange_bytes
+    # C3 (Beauty, V = 57 290, D = 64, B 128 x T 50 per rank, 8 ranks): dense 25.7 MB < sparse 34.9 MB
+    assert dense_allreduce_bytes(57290 * 64, 8) < sparse_exchange_bytes(3 * 128 * 50, 64, 8)
+    # C5 (V = 10 M, D = 256, B 128 x T 512 per rank): sparse 1.4 GB << dense 17.9 GB
+    assert sparse_exchange_bytes(3 * 128 * 512, 256, 8) < 0.1 * dense_allreduce_bytes(10_000_001 * 256, 8)

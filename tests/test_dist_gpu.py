@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 B, T, D, ITEMS, USERS, STEPS = 16, 24, 20, 60, 9, 3
 
 
-def make_batch(step):
+def make_batch(step, items=ITEMS):
     rs = np.random.RandomState(100 + step)
-    seq = rs.randint(1, ITEMS + 1, (B, T)); pos = rs.randint(1, ITEMS + 1, (B, T)); neg = rs.randint(1, ITEMS + 1, (B, T))
+    seq = rs.randint(1, items + 1, (B, T)); pos = rs.randint(1, items + 1, (B, T)); neg = rs.randint(1, items + 1, (B, T))
     for b in range(B):
         n = rs.randint(0, T - 2)                               # ragged: the two shards hold different target counts
         seq[b, :n] = 0; pos[b, :n] = 0; neg[b, :n] = 0
@@ -53,8 +53,11 @@ class HostBounce:
         self.inner.e.Gflat.copy_(self.host_g)
         self.inner.adam_from_flat()
 
+    def sparse_spec(self):
+        return self.inner.sparse_spec()
 
-def _worker(rank, world, port, q):
+
+def _worker(rank, world, port, q, items=ITEMS, sparse=False):
     import torch.distributed as dist
     import castrec_amd  # noqa: F401
     from castrec_amd import engine as E
@@ -64,14 +67,15 @@ def _worker(rank, world, port, q):
     lo, hi = shard_rows(B, rank, world)
     hp = hyper(E)
     hp.seed = 4                                                # same dropout key on every rank ...
-    eng = E.Engine("cast_1", USERS, ITEMS, hp, hi - lo, training=True, n_slabs=8, batch_global=B, row_offset=lo * T)
+    eng = E.Engine("cast_1", USERS, items, hp, hi - lo, training=True, n_slabs=8, batch_global=B, row_offset=lo * T)
     if rank != 0:
         eng.P.mul_(1.5)                                        # ... but a different start: the wrapper must broadcast rank 0's
     rep = HostBounce(EngineReplica(eng, use_graph=True))
-    dp = DataParallel(rep, rank, world)
+    dp = DataParallel(rep, rank, world, sparse=sparse)
+    assert dp.sparse == bool(sparse)
     rep.adopt_params()
     for s in range(STEPS):
-        dp.step(make_batch(s))
+        dp.step(make_batch(s, items))
     torch.cuda.synchronize()
     q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, eng.Gflat[eng.layout.n_total:eng.layout.n_total + 3].cpu().numpy()))
     dist.barrier()
@@ -79,23 +83,27 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch():
+@pytest.mark.parametrize("items,sparse", [(ITEMS, False), (ITEMS, True), (5000, True)])
+def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, sparse):
+    """dense: the whole bucket in one all-reduce.  sparse: the item table's touched rows as an all-gather of
+    de-duplicated (row id, gradient row) pairs -- 60 items: every row is hot and shared by both ranks; 5000 items:
+    V >> the 3 * 8 * 24 row slots a rank touches (the regime of config C5)."""
     import torch.multiprocessing as mp
     import castrec_amd  # noqa: F401
     from castrec_amd import engine as E
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, items, sparse)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    one = E.Engine("cast_1", USERS, ITEMS, hyper(E), B, training=True, n_slabs=8)
+    one = E.Engine("cast_1", USERS, items, hyper(E), B, training=True, n_slabs=8)
     for s in range(STEPS):
-        one.train_step(*make_batch(s))
+        one.train_step(*make_batch(s, items))
     torch.cuda.synchronize()
     ref = {k: v.cpu().numpy() for k, v in one.get_params().items()}
     # both ranks hold the same replica after the exchange
@@ -111,4 +119,4 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch():
     loss_one = one.loss_auc()[0]
     st = res[0][2]
     assert st[0] / st[2] == pytest.approx(loss_one, rel=1e-5)  # bucket tail: loss_sum, auc_sum, n_target of the WHOLE batch
-    assert st[2] == float((make_batch(STEPS - 1)[1] != 0).sum())
+    assert st[2] == float((make_batch(STEPS - 1, items)[1] != 0).sum())
