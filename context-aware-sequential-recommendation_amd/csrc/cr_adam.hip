@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
     const float lr_t = d.lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
     auto update = [&](int i, float g) {
         g *= inv_n;
+        if (i < d.n_l2) g = fmaf(d.l2, d.p[i], g);       // d/dp of l2 * sum(p^2) / 2 on the lookup tables (modules.py:153)
         const float m = d.beta1 * d.m[i] + (1.0f - d.beta1) * g;
         const float v = d.beta2 * d.v[i] + (1.0f - d.beta2) * g * g;
         d.m[i] = m;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.state[5] = n > 0.0f ? st[0] / n : 0.0f;        // loss  (sasrec.py:105-108)
+        d.state[5] = (n > 0.0f ? st[0] / n : 0.0f) + (d.n_l2 > 0 ? d.state[7] : 0.0f);   // loss (sasrec.py:105-110)
         d.state[6] = n > 0.0f ? st[1] / n : 0.0f;        // auc   (sasrec.py:113-115)
         if (d.step_snapshot) {                           // end of the step: no block of this kernel reads state[0..4]
             d.state[0] = 0.0f; d.state[1] = 0.0f; d.state[2] = 0.0f; d.state[3] = 0.0f;
@@ -92,6 +93,26 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     if (nb_table > 2048) nb_table = 2048;
     hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_table), dim3(256), 0, cr_stream(stream), *d, nb_dense);
     return cr_check_launch("cr_adam_step");
+}
+
+// l2 * sum(p^2) / 2 over the lookup tables: ONE workgroup, per-thread strided partial sums, then a fixed-order tree
+__global__ __launch_bounds__(1024) void k_l2_penalty(const float* p, int n, float scale, float* state) {
+    __shared__ float red[1024];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc = fmaf(p[i], p[i], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) state[7] = scale * red[0];
+}
+
+extern "C" int cr_l2_penalty(const float* p, int n, float scale, float* state, void* stream) {
+    CR_REQUIRE(p && state && n > 0, "cr_l2_penalty: bad arguments");
+    hipLaunchKernelGGL(k_l2_penalty, dim3(1), dim3(1024), 0, cr_stream(stream), p, n, scale, state);
+    return cr_check_launch("cr_l2_penalty");
 }
 
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* slabs, int n_slabs, int n_dense, float* out,

@@ -315,14 +315,38 @@ __global__ __launch_bounds__(256) void k_embed_bwd_rows16(cr_embed_bwd_desc bd) 
     }
 }
 
+__global__ __launch_bounds__(256) void k_embed_zero_slabs(float* slab0, int slab_stride, int n_slabs, long long n) {
+    const long long total = n * n_slabs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        slab0[(size_t)(i / n) * slab_stride + (size_t)(i % n)] = 0.0f;
+}
+
 extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
     CR_REQUIRE(bd && bd->f.ids && bd->f.out, "cr_embed_bwd: NULL pointer");
     const cr_embed_desc* d = &bd->f;
     CR_REQUIRE(d->M > 0 && d->T > 0 && d->D > 0 && d->M % d->T == 0, "cr_embed_bwd: bad shape");
     if (bd->n_slabs > 0) {
         CR_REQUIRE(bd->table_grad != nullptr && bd->pos_grad == nullptr, "cr_embed_bwd: small-table mode needs table_grad and no pos_grad");
-        if ((long long)d->V * d->D > EMB_SMALL_MAX)
-            return cr_set_error(CR_ERR_UNSUPPORTED, "cr_embed_bwd: small-table mode needs V*D <= %d (got %d*%d)", EMB_SMALL_MAX, d->V, d->D);
+        if ((long long)d->V * d->D > EMB_SMALL_MAX) {
+            // The table image does not fit one workgroup's LDS (e.g. time_emb at max_bins 200 and hidden_units >= 62):
+            // same contract -- every slab written, their sum is the gradient -- through the large-table kernels:
+            // all slabs zeroed, float atomics into slab 0.
+            if (d->D > 64 * EMB_MAXC) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_embed_bwd: D=%d > %d", d->D, 64 * EMB_MAXC);
+            const long long n = (long long)d->V * d->D;
+            int zgrid = (int)((n * bd->n_slabs + 255) / 256);
+            if (zgrid > 2048) zgrid = 2048;
+            hipLaunchKernelGGL(k_embed_zero_slabs, dim3(zgrid), dim3(256), 0, cr_stream(stream), bd->table_grad, bd->slab_stride, bd->n_slabs, n);
+            cr_embed_bwd_desc big = *bd;
+            big.n_slabs = 0; big.slab_stride = 0;
+            if (d->D <= 64) {
+                int grid = cr_ceil_div(d->M, 16);
+                if (grid > 2048) grid = 2048;
+                hipLaunchKernelGGL(k_embed_bwd_rows16, dim3(grid), dim3(256), 0, cr_stream(stream), big);
+            } else {
+                hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(256), 0, cr_stream(stream), big);
+            }
+            return cr_check_launch("cr_embed_bwd(small table through the large-table kernels)");
+        }
         hipLaunchKernelGGL(k_embed_bwd_small, dim3(bd->n_slabs), dim3(256), 0, cr_stream(stream), *bd);
         return cr_check_launch("cr_embed_bwd(small)");
     }

@@ -57,8 +57,6 @@ class Hyper:
                 d[k] = getattr(args, k)
         d.update(kw)
         self.__dict__.update(d)
-        if self.l2_emb != 0.0:
-            raise NotImplementedError("l2_emb != 0 is not implemented (every reference run uses 0.0, params.txt)")
         if self.hidden_units % self.num_heads != 0:
             raise ValueError("hidden_units must be divisible by num_heads (tf.split, modules.py:208)")
 
@@ -130,6 +128,9 @@ class ParamLayout:
         for (n, shape, init) in dense:
             self.entries[n] = (off, shape, init, "dense"); off += int(np.prod(shape))
         self.n_total, self.n_dense, self.D = off, off - self.n_table, D
+        # the lookup tables lead the flat vector (item_emb, pos_emb, then the small context tables): the range
+        # tf.contrib.layers.l2_regularizer(l2_emb) covers (modules.py:149-153)
+        self.n_l2 = self.n_table + sum(int(np.prod(self.entries[n][1])) for n, _ in st["small"])
 
     def logical_names(self):
         """Names as the oracle / reference variables see them (wq, wk, wv instead of the fused wqkv)."""
@@ -202,6 +203,7 @@ class Engine:
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
         self.fuse_head_ln = os.environ.get("CASTREC_NO_HEAD_LN") != "1"
+        self._check_ids = os.environ.get("CASTREC_NO_ID_CHECK") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
         if self.fused and not 4 <= hp.hidden_units <= 64:
             raise ValueError("fused block kernels need 4 <= hidden_units <= 64")
@@ -760,25 +762,41 @@ class Engine:
             # the step ends inside Adam (castrec.h, state block): sums and step number are read from the snapshot the
             # head kernel took, and the kernel zeroes the sums and advances the counter -- no cr_step_begin launch
             snap, tsnap = self.state.data_ptr() + 4 * 8, self.state.data_ptr() + 4 * 11
+            l2 = float(self.hp.l2_emb)
+            n_l2 = lay.n_l2 if l2 != 0.0 else 0
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
                             lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr(),
-                            snap, tsnap)
+                            snap, tsnap, l2, n_l2)
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
-                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap)
+                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap, l2, n_l2)
             self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
             self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
                             (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,
                              self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total))
+            # l2_emb != 0: the penalty of the CURRENT parameters, just before Adam moves them (one more launch; every
+            # reference run uses 0.0)
+            self._l2 = ("cr_l2_penalty", L.lib.cr_l2_penalty, (self.P.data_ptr(), n_l2, 0.5 * l2, self.state.data_ptr())) if n_l2 else None
             self._keep += [ad, ad1]
 
     # ---- running ---------------------------------------------------------------------------------
     def set_batch(self, seq, pos=None, neg=None, time=None, hours=None, days=None):
-        """Copies one batch ([B,T] int arrays, host or device) into the static input buffers."""
+        """Copies one batch ([B,T] int arrays, host or device) into the static input buffers.  Host arrays are range
+        checked first (the kernels index the tables with these ids unchecked; tf.nn.embedding_lookup raises
+        InvalidArgument for an id outside its table -- e.g. unsorted timestamps give negative time bins, and
+        sampler.py:66 produces bins up to 200 under --log_scale whatever --max_bins says).  CASTREC_NO_ID_CHECK=1 skips it."""
+        limits = dict(seq=self.itemnum, pos=self.itemnum, neg=self.itemnum, time=self.hp.max_bins, hours=24, days=7)
+        used = {"seq", "pos", "neg"} | ({"time"} if "time_emb" in self.layout.entries else set()) \
+            | ({"hours", "days"} if "hours_emb" in self.layout.entries else set())
         for k, a in (("seq", seq), ("pos", pos), ("neg", neg), ("time", time), ("hours", hours), ("days", days)):
             if a is None:
                 continue
+            if self._check_ids and k in used and not isinstance(a, torch.Tensor):
+                a = np.asarray(a)
+                if a.size and (int(a.min()) < 0 or int(a.max()) > limits[k]):
+                    raise ValueError("%s ids outside [0, %d] (min %d, max %d): the lookup table has %d rows"
+                                     % (k, limits[k], int(a.min()), int(a.max()), limits[k] + 1))
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32))
             self.ids[k].copy_(t.reshape(-1).to(torch.int32), non_blocking=True)
 
@@ -809,7 +827,7 @@ class Engine:
             if between is not None:
                 between()
             if apply:
-                self._run([self._adam], s)
+                self._run(([self._l2] if self._l2 else []) + [self._adam], s)
 
     # ---- data-parallel pieces (castrec_amd.dist drives them around an RCCL all-reduce) ----------
     def launch_backward_to_flat(self):
@@ -821,7 +839,7 @@ class Engine:
 
     def launch_adam_from_flat(self):
         """Adam on the (all-reduced) flat bucket; the global loss statistics are read from its tail."""
-        self._run([self._adam_flat], torch.cuda.current_stream().cuda_stream)
+        self._run(([self._l2] if self._l2 else []) + [self._adam_flat], torch.cuda.current_stream().cuda_stream)
 
     def capture(self, dp=False):
         """Captures launch_step() into a HIP graph (inputs are read from the static id buffers)."""
@@ -876,4 +894,4 @@ class Engine:
         return {k: self.layout.view(flat, k).clone() for k in self.layout.logical_names()}
 
     def n_launches(self):
-        return len(self.fwd) + len(self.bwd) + (1 if self.training else 0)
+        return len(self.fwd) + len(self.bwd) + (1 if self.training else 0) + (1 if self.training and self._l2 else 0)

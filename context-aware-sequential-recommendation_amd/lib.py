@@ -112,7 +112,7 @@ class HeadDesc(C.Structure):
 class AdamDesc(C.Structure):
     _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
                 ("n_table", c_i), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
-                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p)]
+                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", c_i)]
 
 
 def _sig(name, restype, argtypes):
@@ -147,6 +147,7 @@ _sig("cr_head_fwd_bwd_ln", c_i, [C.POINTER(HeadDesc), C.POINTER(LnBwdDesc), c_p]
 _sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 _sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
 _sig("cr_reduce_slabs", c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p])
+_sig("cr_l2_penalty", c_i, [c_p, c_i, c_f, c_p, c_p])
 _sig("cr_graph_begin", c_i, [c_p])
 _sig("cr_graph_end", c_i, [c_p, C.POINTER(c_p)])
 _sig("cr_graph_launch", c_i, [c_p, c_p])
@@ -158,7 +159,7 @@ _sig("cr_sampler_destroy", None, [c_p])
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
            "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_block_ln_qkv_bwd_scatter",
-           "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
+           "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]
 
 lib = _lib

@@ -25,6 +25,7 @@ class _Model(object):
         self.hp = Hyper(args)
         self._n_slabs, self._batch_global, self._row_offset = n_slabs, batch_global, row_offset
         self._train = None
+        self._pending_opt = None              # optimiser state loaded before the training engine exists (load / load_tf_checkpoint)
         self._eval = {}
         self._graph = bool(int(os.environ.get("CASTREC_GRAPH", "1")))
         # parameters exist from construction on (tf.global_variables_initializer, main.py:150)
@@ -39,6 +40,9 @@ class _Model(object):
             if self._graph and self._batch_global is None:
                 self._train.capture()
                 self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
+            if self._pending_opt is not None:          # a checkpoint's Adam slots and step count (saver.restore, main.py:165-175)
+                self._apply_opt(*self._pending_opt)
+                self._pending_opt = None
         if self._train.B != B:
             raise ValueError("batch size changed from %d to %d (static graph)" % (self._train.B, B))
         return self._train
@@ -89,24 +93,32 @@ class _Model(object):
         torch.save(self.state_dict(), path)
         return path
 
+    def _apply_opt(self, M, V, next_step):
+        self._train.Mom.copy_(M); self._train.Vel.copy_(V)
+        self._train.set_step(int(next_step))
+
     def load(self, path):
+        """Parameters AND optimiser state (Adam m / v, step number), like saver.restore (main.py:165-166): a training
+        step after load() continues the saved run.  The state is kept aside until the training engine exists."""
         d = torch.load(path, map_location="cpu")
         if d["model"] != self.name or d["P"].numel() != self._owner.P.numel():
             raise ValueError("checkpoint %s does not match model %s" % (path, self.name))
         self._owner.P.copy_(d["P"])
-        if "M" in d and self._train is not None:
-            self._train.Mom.copy_(d["M"]); self._train.Vel.copy_(d["V"])
+        if "M" in d:
             st = d["state"]
-            if st.numel() == self._train.state.numel():
-                self._train.state.copy_(st)
-            else:                                        # 8-float state of earlier files: [4] counted COMPLETED steps
-                self._train.set_step(int(st[4:5].view(torch.int32)[0]) + 1)
+            cur = int(st[4:5].view(torch.int32)[0])
+            nxt = cur if st.numel() == 16 else cur + 1   # 8-float state of earlier files: [4] counted COMPLETED steps
+            if self._train is not None:
+                self._apply_opt(d["M"], d["V"], nxt)
+            else:
+                self._pending_opt = (d["M"], d["V"], nxt)
 
     def load_tf_checkpoint(self, prefix):
         """Loads a checkpoint written by the reference (tf.train.Saver bundle `<prefix>.index` +
-        `<prefix>.data-00000-of-00001`, main.py:231-233 there); optimiser slots are ignored."""
+        `<prefix>.data-00000-of-00001`, main.py:231-233 there), Adam slots and step count included when the bundle
+        holds them (they then seed the next train_step, as saver.restore does before main.py:167-175's one step)."""
         from . import tf_bundle
-        params = tf_bundle.load_logical(prefix)
+        params, slot_m, slot_v, steps = tf_bundle.load_logical_with_slots(prefix)
         want = {n: tuple(self._owner.layout.view(self._owner.P, n).shape) for n in self._owner.layout.logical_names()}
         missing, extra = sorted(set(want) - set(params)), sorted(set(params) - set(want))
         if missing or extra:
@@ -115,6 +127,16 @@ class _Model(object):
             if tuple(params[n].shape) != shp:
                 raise ValueError("checkpoint %s: %s has shape %s, model expects %s" % (prefix, n, params[n].shape, shp))
         self._owner.load_params(params)
+        if steps > 0 and set(slot_m) == set(want) and set(slot_v) == set(want):
+            lay = self._owner.layout
+            M, V = torch.zeros(lay.n_total), torch.zeros(lay.n_total)
+            for n in want:
+                lay.view(M, n).copy_(torch.tensor(np.asarray(slot_m[n], np.float32)))
+                lay.view(V, n).copy_(torch.tensor(np.asarray(slot_v[n], np.float32)))
+            if self._train is not None:
+                self._apply_opt(M, V, steps + 1)
+            else:
+                self._pending_opt = (M, V, steps + 1)
 
     def get_params(self):
         return self._owner.get_params()

@@ -50,6 +50,11 @@ def get_delta_range(corpus: Corpus):
 
 class WarpSampler(object):
     def __init__(self, args, User, usernum, itemnum, sample_func=None, batch_size=64, maxlen=10, n_workers=1):
+        if args.log_scale and int(args.max_bins) < 200:
+            # sampler.py:66 calls get_timedelta_bin(..., max_bins=200, log_scale=True) whatever --max_bins says, so bins
+            # reach 200 while the models' time table has max_bins + 1 rows (cast_1.py:31): TensorFlow's lookup raises
+            # InvalidArgument on the first such batch; refuse up front instead of reading past the table
+            raise ValueError("--log_scale produces time bins up to 200 (sampler.py:66): --max_bins must be >= 200, got %d" % int(args.max_bins))
         corpus = _as_corpus(User, usernum, itemnum)
         self.corpus = corpus
         self.batch_size, self.maxlen = batch_size, maxlen

@@ -142,6 +142,12 @@ _FIXED = {"SASRec/input_embeddings/lookup_table": "item_emb", "SASRec/dec_pos/lo
           "INPUT-CONTEXT/hours_embeddings/lookup_table": "hours_emb", "INPUT-CONTEXT/days_embeddings/lookup_table": "days_emb",
           "SASRec/ln/Variable": "trunk.lnf.beta", "SASRec/ln/Variable_1": "trunk.lnf.gamma",
           "CONTEXT/ln/Variable": "ctx_time.lnf.beta", "CONTEXT/ln/Variable_1": "ctx_time.lnf.gamma",
+          # cast_8 / cast_9: the hours and days stacks share the INPUT-CONTEXT scope, their final LayerNorms are its
+          # first and second `normalize` (cast_8.py:75,95); cast_9's time stack lives under TEMPORAL-CONTEXT (cast_9.py:100-129)
+          "INPUT-CONTEXT/ln/Variable": "ctx_hours.lnf.beta", "INPUT-CONTEXT/ln/Variable_1": "ctx_hours.lnf.gamma",
+          "INPUT-CONTEXT/ln_1/Variable": "ctx_days.lnf.beta", "INPUT-CONTEXT/ln_1/Variable_1": "ctx_days.lnf.gamma",
+          "TEMPORAL-CONTEXT/ln/Variable": "ctx_time.lnf.beta", "TEMPORAL-CONTEXT/ln/Variable_1": "ctx_time.lnf.gamma",
+          "TEMPORAL-CONTEXT/time_embeddings/lookup_table": "time_emb",
           "SASRec/MLP/dense/kernel": "mlp.w1", "SASRec/MLP/dense/bias": "mlp.b1",
           "SASRec/MLP/dense_1/kernel": "mlp.w2", "SASRec/MLP/dense_1/bias": "mlp.b2"}
 _LEAF = {"self_attention/dense/kernel": "wq", "self_attention/dense/bias": "bq",
@@ -159,11 +165,15 @@ def logical_name(tf_name):
         return None
     if tf_name in _FIXED:
         return _FIXED[tf_name]
-    m = re.match(r"^(SASRec/num_blocks_|CONTEXT/timeseq_num_blocks_)(\d+)/(.+)$", tf_name)
+    m = re.match(r"^(SASRec/num_blocks_|CONTEXT/timeseq_num_blocks_|INPUT-CONTEXT/hours_seq_num_blocks_|"
+                 r"INPUT-CONTEXT/days_seq_num_blocks_|TEMPORAL-CONTEXT/timeseq_num_blocks_)(\d+)/(.+)$", tf_name)
     if not m:
         raise KeyError("unknown checkpoint variable %r" % tf_name)
-    ctx = m.group(1).startswith("CONTEXT")
-    prefix = "%s.%s." % ("ctx_time" if ctx else "trunk", m.group(2))
+    # (stack prefix, does the block create an unused LayerNorm first -- cast_1.py:45 does, cast_8 / cast_9 do not)
+    stack, ctx = {"SASRec/num_blocks_": ("trunk", False), "CONTEXT/timeseq_num_blocks_": ("ctx_time", True),
+                  "INPUT-CONTEXT/hours_seq_num_blocks_": ("ctx_hours", False), "INPUT-CONTEXT/days_seq_num_blocks_": ("ctx_days", False),
+                  "TEMPORAL-CONTEXT/timeseq_num_blocks_": ("ctx_time", False)}[m.group(1)]
+    prefix = "%s.%s." % (stack, m.group(2))
     leaf = m.group(3)
     if leaf in _LEAF:
         return prefix + _LEAF[leaf]
@@ -198,3 +208,20 @@ def to_logical(tensors):
 
 def load_logical(prefix):
     return to_logical(load(prefix))
+
+
+def load_logical_with_slots(prefix):
+    """(params, adam_m, adam_v, completed_steps): the variables plus tf.train.AdamOptimizer's slots (`<var>/Adam` = m,
+    `<var>/Adam_1` = v) under the same logical names, and the number of optimiser steps taken, recovered from
+    beta1_power = 0.9 ** t (sasrec.py:120).  Slots missing from the bundle come back as empty dicts / 0."""
+    import math
+    raw = load(prefix)
+    params = to_logical({k: v for k, v in raw.items() if not _SKIP.search(k)})
+    m = to_logical({k[:-len("/Adam")]: v for k, v in raw.items() if k.endswith("/Adam")})
+    v = to_logical({k[:-len("/Adam_1")]: a for k, a in raw.items() if k.endswith("/Adam_1")})
+    steps = 0
+    if "beta1_power" in raw:
+        b1p = float(np.asarray(raw["beta1_power"]).reshape(-1)[0])
+        if 0.0 < b1p < 1.0:
+            steps = int(round(math.log(b1p) / math.log(0.9)))
+    return params, m, v, steps

@@ -336,8 +336,15 @@ typedef struct {
     const float* stats;               /* optional [3] */
     const uint32_t* step_snapshot;    /* optional: step number t is read from here instead of state[4], and the kernel
                                          ends the step: state[0..3] = 0, state[4] = t + 1 (see the state block above) */
+    float l2; int n_l2;               /* embedding regulariser (modules.py:149-153, sasrec.py:109-110): the first n_l2
+                                         parameters (the lookup tables: they lead the flat vector) get g += l2 * p, and
+                                         the reported loss gets state[7] (written by cr_l2_penalty) added */
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
+
+/* state[7] = scale * sum_{i < n} p[i]^2  (scale = l2 / 2): the regularisation term of the loss, fixed summation order.
+ * Launched before cr_adam_step (which updates p) when l2_emb != 0; every shipped run of the reference uses 0. */
+int cr_l2_penalty(const float* p, int n, float scale, float* state, void* stream);
 
 /* Data-parallel path: collapse the dense slabs into one flat vector that is all-reduced over RCCL
  * together with the table gradient: out[i] = sum_s slabs[s*n_dense + i]; also copies the three loss

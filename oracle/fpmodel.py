@@ -41,6 +41,7 @@ class Hyper:
     max_bins: int = 200
     num_context_blocks: int = 2
     lr: float = 1e-3
+    l2_emb: float = 0.0
 
 
 # ---------------------------------------------------------------------------
@@ -183,9 +184,22 @@ def multihead_attention(queries, keys, P, pfx, num_heads, rate, drop, site):
     return out, attention_weights
 
 
+# Optional ReLU gates (test infrastructure): {site: bool tensor}.  A test that compares GRADIENTS with an implementation
+# whose activations differ by ~1e-5 (the bf16 split-precision attention) hands over that implementation's gates, exactly
+# as it hands over its dropout masks: the few units that sit within 1e-5 of the kink would otherwise flip on one side
+# only and change a row's gradient by a finite amount.  None (the default) = plain relu.
+RELU_GATES = None
+
+
+def _relu(x, site):
+    if RELU_GATES is not None and site in RELU_GATES:
+        return x * RELU_GATES[site].reshape(x.shape).to(x.dtype)
+    return torch.relu(x)
+
+
 def feedforward(x, P, pfx, rate, drop, site):
     """modules.py:280-318 (two kernel-size-1 conv1d = per-position dense)."""
-    h = torch.relu(x @ P[pfx + "w1"] + P[pfx + "b1"])                                # :300-302
+    h = _relu(x @ P[pfx + "w1"] + P[pfx + "b1"], site + ".relu")                     # :300-302
     h = _dropout(h, rate, site + ".ffn1", drop)                                      # :303-304
     y = h @ P[pfx + "w2"] + P[pfx + "b2"]                                            # :306-308
     y = _dropout(y, rate, site + ".ffn2", drop)                                      # :309-310
@@ -194,8 +208,8 @@ def feedforward(x, P, pfx, rate, drop, site):
 
 def mlp(x, P):
     """modules.py:321-335 (ReLU on BOTH layers)."""
-    h = torch.relu(x @ P["mlp.w1"] + P["mlp.b1"])
-    return torch.relu(h @ P["mlp.w2"] + P["mlp.b2"])
+    h = _relu(x @ P["mlp.w1"] + P["mlp.b1"], "mlp.relu1")
+    return _relu(h @ P["mlp.w2"] + P["mlp.b2"], "mlp.relu2")
 
 
 def transformer_stack(x, mask, P, prefix, L, hp, drop, final_ln=True):
@@ -328,6 +342,13 @@ def forward(model, P, hp: Hyper, batch, drop=None):
     loss = (-torch.log(torch.sigmoid(pos_logits) + 1e-24) * istarget
             - torch.log(1 - torch.sigmoid(neg_logits) + 1e-24) * istarget).sum() / istarget.sum()   # :105-108
     auc = (((torch.sign(pos_logits - neg_logits) + 1) / 2) * istarget).sum() / istarget.sum()      # :113-115
+    if hp.l2_emb != 0.0:
+        # modules.py:149-153: every embedding's `lookup_table` VARIABLE (row 0 included: the regulariser sits on the
+        # variable, not on the zero-padded concat) carries tf.contrib.layers.l2_regularizer(l2) = l2 * sum(w^2) / 2;
+        # sasrec.py:109-110 adds the collection to the loss
+        for k in ("item_emb", "pos_emb", "time_emb", "hours_emb", "days_emb"):
+            if k in P:
+                loss = loss + hp.l2_emb * 0.5 * (P[k] ** 2).sum()
     out = dict(loss=loss, auc=auc, seq_emb=seq_emb, pos_logits=pos_logits, neg_logits=neg_logits,
                attention_weights=ret_attn, item_table=item_table, istarget=istarget)
     if "test_item" in batch:

@@ -128,3 +128,42 @@ def test_model_loads_a_reference_tensorflow_checkpoint(tmp_path):
     other = build_model("sasrec", 6040, 3416, 5, args)
     with pytest.raises(ValueError, match="does not match model"):
         other.load_tf_checkpoint(prefix)
+
+
+def test_checkpoint_restores_the_optimiser_state(tmp_path):
+    """save -> a NEW model -> load -> train_step must equal continuing the original model: Adam's m / v and the step
+    number (bias correction, dropout keys) travel with the parameters like tf.train.Saver's slots (main.py:159-175).
+    The state is loaded BEFORE the new model's training engine exists -- the order main.py --test_model uses."""
+    import types
+    from castrec_amd import models
+    rs = np.random.RandomState(21)
+    B, T, itemnum = 6, 16, 40
+    args = types.SimpleNamespace(maxlen=T, hidden_units=16, num_blocks=1, num_heads=1, dropout_rate=0.2, l2_emb=0.0, lr=1e-2,
+                                 max_bins=8, num_context_blocks=1, seed=5)
+
+    def batch(i):
+        r = np.random.RandomState(50 + i)
+        seq = r.randint(1, itemnum + 1, (B, T)); pos = r.randint(1, itemnum + 1, (B, T)); neg = r.randint(1, itemnum + 1, (B, T))
+        seq[:, :3] = 0; pos[:, :3] = 0; neg[:, :3] = 0
+        tm = r.randint(0, 9, (B, T)) * (seq != 0)
+        z = np.zeros_like(seq)
+        return None, seq, pos, neg, tm, z, z
+    a = models.CAST1(9, itemnum, 5, args)
+    for i in range(3):
+        a.train_step(*batch(i))
+    path = a.save(str(tmp_path / "ck.pt"))
+    b = models.CAST1(9, itemnum, 5, args)
+    b.load(path)                                         # no training engine yet: the slots wait for it
+    ra = a.train_step(*batch(3))
+    rb = b.train_step(*batch(3))
+    torch.cuda.synchronize()
+    assert ra[1] == pytest.approx(rb[1], rel=1e-6)       # same loss on the same batch: same parameters, same dropout key (step 4)
+    pa, pb = a.get_params(), b.get_params()
+    for k in pa:
+        if k == "item_emb":                              # float atomics may reorder
+            assert torch.allclose(pa[k], pb[k], rtol=0, atol=1e-6), k
+        else:
+            assert torch.equal(pa[k], pb[k]), k
+    c = models.CAST1(9, itemnum, 5, args)                # without the slots the same step differs (fresh Adam at t = 1)
+    c.load_params({k: v.cpu() for k, v in a.get_params().items()})
+    assert a._train.step_number() == 5 and b._train.step_number() == 5

@@ -70,6 +70,38 @@ TOL = {"f32": dict(grad=2e-4, act=2e-5, loss=2e-5, auc=1e-6), "bf16x3": dict(gra
        "bf16": dict(grad=2e-1, act=3e-2, loss=2e-2, auc=None)}
 
 
+def engine_relu_gates(eng, B, T, drop):
+    """The ReLU gates of an engine's last forward, by the oracle's site names (fpmodel.RELU_GATES): read from the stored
+    post-ReLU activations (FFN hidden: post-dropout, so a dropped unit's gate is unknown -- and irrelevant, its mask is 0)."""
+    gates = {}
+    for name, buf in eng._bufs.items():
+        if name.endswith(".hid"):
+            site = name[:-4]                                    # "trunk.0"
+            g = buf > 0
+            if drop is not None:
+                g = g | ~drop(site + ".ffn1", (B * T, buf.shape[1])).reshape(B * T, -1).to(g.device)
+            gates[site + ".relu"] = g.reshape(B, T, -1).cpu()
+    if "mlp.h" in eng._bufs:
+        gates["mlp.relu1"] = (eng._bufs["mlp.h"] > 0).reshape(B, T, -1).cpu()
+        outb = eng._bufs["seq_emb"] if eng.model in ("cast_5", "cast_6") else eng._bufs["x0"]
+        rowlive = (eng.ids["seq"] != 0).reshape(B * T, 1) if eng.model == "cast_9" else torch.ones(B * T, 1, dtype=torch.bool, device=outb.device)
+        gates["mlp.relu2"] = ((outb > 0) | ~rowlive).reshape(B, T, -1).cpu()     # cast_9 masks the rows after the ReLU (their gradient is 0)
+    return gates
+
+
+def worst_grad_error(got, G, prec):
+    """(error, parameter name, threshold): largest element error of a parameter against that parameter's largest
+    gradient (floored at 1e-3 of the global scale; plain bf16: against the global scale).  d loss / d bk == 0
+    identically (rounding noise on both sides): not compared."""
+    gmax = max(float(G[k].abs().max()) for k in G)
+    names = [k for k in G if not k.endswith(".bk")]
+    def emax(k):
+        a = got[k].cpu().double().numpy(); b = G[k].numpy()
+        return float(np.abs(a - b).max() / (gmax if prec == "bf16" else max(np.abs(b).max(), 1e-3 * gmax)))
+    w = max((emax(k), k) for k in names)
+    return w[0], w[1], TOL[prec]["grad"]
+
+
 @pytest.mark.parametrize("model,rate,fused,prec", CASES)
 def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
     tol = TOL[prec]
@@ -92,10 +124,14 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
     opt = fm.AdamTF(P, lr=1e-3)
     for step in (1, 2):
         drop = oracle_drop(E, 7, step, rate, B, T, H) if rate > 0 else None
-        out, G = fm.loss_and_grads(model, P, ohp, batch, drop)
         eng.set_batch(seq, pos, neg, time, hours, days)
         eng.launch_step(apply=False)
         torch.cuda.synchronize()
+        fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None     # see _other_shapes
+        try:
+            out, G = fm.loss_and_grads(model, P, ohp, batch, drop)
+        finally:
+            fm.RELU_GATES = None
         st = eng.state.cpu().numpy()
         n = st[2]
         assert n == float(out["istarget"].sum())
@@ -106,12 +142,8 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
         # d loss / d bk == 0 identically (adding a per-query constant to all scores leaves softmax unchanged),
         # so both sides hold rounding noise there: errors are measured against the global gradient scale.
         gmax = max(float(G[k].abs().max()) for k in G)
-        def gerr(k):
-            a = got[k].cpu().double().numpy(); b = G[k].numpy()
-            # plain bf16: error against the global gradient scale (its noise floor does not shrink with a parameter's own gradient)
-            return float(np.abs(a - b).max() / (gmax if prec == "bf16" else max(np.abs(b).max(), 1e-3 * gmax)))
-        worst = max((gerr(k), k) for k in G if not k.endswith(".bk"))     # bk: asserted to vanish, below
-        assert worst[0] < tol["grad"], worst
+        worst = worst_grad_error(got, G, prec)                              # bk: asserted to vanish, below
+        assert worst[0] < worst[2], worst
         for k in G:
             if k.endswith(".bk"):
                 assert float(got[k].abs().max()) < max(1e-5, 0.1 * tol["grad"]) * gmax and float(G[k].abs().max()) < 1e-9 * gmax
@@ -232,10 +264,9 @@ def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, m
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * gmax, k
 
 
-def _other_shapes(E, model, D, H, T, L, B=3, prec="f32"):
+def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None):
     tol = TOL[prec]
     rs = np.random.RandomState(D + T)
-    itemnum, max_bins = 41, 9
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
                  num_context_blocks=1, lr=1e-3, seed=11)
     ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
@@ -247,18 +278,80 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32"):
     eng.load_params(P)
     P = {k: v.double().cpu() for k, v in eng.get_params().items()}
     seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, max_bins)
-    out, G = fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), oracle_drop(E, 11, 1, 0.1, B, T, H))
+    if zipf:                                             # long-tail ids: a few hot rows take most of the scatter / head atomics
+        w = 1.0 / np.arange(1, itemnum + 1, dtype=np.float64) ** zipf
+        cdf = np.cumsum(w / w.sum())
+        draw = lambda: (np.searchsorted(cdf, rs.random_sample((B, T))).clip(0, itemnum - 1) + 1)
+        live = seq != 0
+        seq, pos, neg = draw() * live, draw() * live, draw() * live
     eng.set_batch(seq, pos, neg, time, hours, days)
     eng.launch_step(apply=False)
     torch.cuda.synchronize()
+    drop = oracle_drop(E, 11, 1, 0.1, B, T, H)
+    # split-precision attention perturbs activations by ~1e-5: the oracle takes the engine's ReLU gates like it takes its
+    # dropout masks, so that units within 1e-5 of the kink do not flip on one side only (see fpmodel.RELU_GATES)
+    fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None
+    try:
+        out, G = fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), drop)
+    finally:
+        fm.RELU_GATES = None
     st = eng.state.cpu().numpy()
     assert st[0] / st[2] == pytest.approx(float(out["loss"]), rel=tol["loss"])
     got = eng.grads()
-    gmax = max(float(G[k].abs().max()) for k in G)
-    # (bk: d loss / d bk == 0 identically -- rounding noise on both sides, not compared)
-    worst = max((float((got[k].cpu().double() - G[k]).abs().max()) / max(float(G[k].abs().max()), 1e-3 * gmax), k)
-                for k in G if not k.endswith(".bk"))
-    assert worst[0] < 2 * tol["grad"], worst
+    worst = worst_grad_error(got, G, prec)
+    assert worst[0] < 2 * worst[2], worst
+    assert rel(eng.seq_emb, out["seq_emb"].reshape(B * T, -1)) < tol["act"]     # forward parity (north-star bound 1e-3)
+
+
+def test_config_c1_exact_shape(E):
+    """BASELINE configs[0]: ml-1m SASRec maxlen=50 hidden_units=50 num_blocks=2 num_heads=1 batch=128."""
+    _other_shapes(E, "sasrec", 50, 1, 50, 2, B=128, prec="f32", itemnum=3416)
+    _other_shapes(E, "sasrec", 50, 1, 50, 2, B=128, prec="bf16x3", itemnum=3416)
+
+
+def test_config_c3_long_tail_vocabulary(E):
+    """BASELINE configs[2]: Beauty, hidden 64, 2 heads, maxlen 50, the 57 289-item vocabulary with Zipf-distributed ids
+    (hot rows: the float-atomic scatters of the embedding backward and of the head see heavy collisions)."""
+    _other_shapes(E, "sasrec", 64, 2, 50, 2, B=128, prec="bf16x3", itemnum=57289, zipf=1.1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_config_c4_full_shape(E, prec):
+    """BASELINE configs[3]: Books, maxlen=200 hidden_units=128 num_blocks=4 num_heads=4 (unfused row phases, head dim 32)."""
+    _other_shapes(E, "sasrec", 128, 4, 200, 4, B=4, prec=prec, itemnum=500)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_config_c5_shape(E, prec):
+    """BASELINE configs[4]: maxlen=512 hidden_units=256 (4 heads of 64), small batch: the chunked attention kernels
+    (bf16x3) / the general kernels (f32) under the unfused row phases."""
+    _other_shapes(E, "sasrec", 256, 4, 512, 2, B=2, prec=prec, itemnum=3000)
+
+
+@pytest.mark.parametrize("model", ["cast_%d" % i for i in range(2, 10)])
+def test_every_cast_graph_at_the_headline_shape(E, model):
+    """cast_2 ... cast_9 once at D = 50, T = 200 (cast_1 is the bench workload and has its own tests)."""
+    _other_shapes(E, model, 50, 1, 200, 2, B=3, prec="bf16x3", itemnum=300, max_bins=200)
+
+
+def test_context_tables_too_large_for_one_lds_image(E):
+    """time_emb at --max_bins 200 and hidden 64 is 201 x 64 floats > the 12 288 the small-table backward keeps in
+    LDS: it must fall back to the large-table scatter (same slab contract), fused and unfused (D = 128) alike."""
+    _other_shapes(E, "cast_1", 64, 1, 40, 1, B=3, prec="f32", max_bins=200)
+    _other_shapes(E, "cast_3", 128, 2, 24, 1, B=3, prec="f32", max_bins=200)
+
+
+def test_id_range_is_checked(E):
+    hp = E.Hyper(maxlen=8, hidden_units=16, num_blocks=1, num_heads=1, dropout_rate=0.0, max_bins=5, seed=1)
+    eng = E.Engine("cast_1", 9, 20, hp, 2, training=False)
+    ok = np.ones((2, 8), np.int64)
+    eng.set_batch(ok, None, None, ok, ok, ok)
+    with pytest.raises(ValueError, match="time ids outside"):
+        eng.set_batch(ok, None, None, ok * 6, ok, ok)               # bin 6 in a 6-row table
+    with pytest.raises(ValueError, match="seq ids outside"):
+        eng.set_batch(ok * 21)
+    with pytest.raises(ValueError, match="time ids outside"):
+        eng.set_batch(ok, None, None, -ok, ok, ok)                  # unsorted timestamps give negative bins
 
 
 @pytest.mark.parametrize("model", ["sasrec", "cast_1", "cast_5", "cast_8"])
@@ -340,14 +433,48 @@ def test_trained_reference_weights_at_the_headline_shape(E, prec):
     # training step with dropout (oracle fed with the engine's masks): loss and every gradient
     eng = E.Engine("cast_1", 6040, itemnum, hp, B, training=True, n_slabs=5, attn_precision=prec)
     eng.load_params(P)
-    o2, G = fm.loss_and_grads("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros), oracle_drop(E, 5, 1, 0.2, B, T, H))
     eng.set_batch(seq, pos, neg, time, zeros, zeros)
     eng.launch_step(apply=False)
     torch.cuda.synchronize()
+    drop = oracle_drop(E, 5, 1, 0.2, B, T, H)
+    fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None         # see _other_shapes
+    try:
+        o2, G = fm.loss_and_grads("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros), drop)
+    finally:
+        fm.RELU_GATES = None
     st = eng.state.cpu().numpy()
     assert st[0] / st[2] == pytest.approx(float(o2["loss"]), rel=tol["loss"])
     got = eng.grads()
-    gmax = max(float(G[k].abs().max()) for k in G)
-    worst = max((float((got[k].cpu().double() - G[k]).abs().max()) / max(float(G[k].abs().max()), 1e-3 * gmax), k)
-                for k in G if not k.endswith(".bk"))
-    assert worst[0] < 2 * tol["grad"], worst
+    worst = worst_grad_error(got, G, prec)
+    assert worst[0] < 2 * worst[2], worst
+
+
+@pytest.mark.parametrize("model", ["sasrec", "cast_3"])
+def test_l2_emb_regulariser_matches_oracle(E, model):
+    """--l2_emb (modules.py:149-153, sasrec.py:109-110): l2 * sum(w^2) / 2 over every lookup-table VARIABLE (row 0
+    included) is added to the loss, i.e. l2 * w to the gradients.  Rows a batch never touches then still move (by
+    lr * sign(w) on the first Adam steps), which is what tells a missing term apart: three steps against the oracle."""
+    rs = np.random.RandomState(3)
+    B, T, D, H, itemnum, max_bins, l2 = 4, 12, 16, 1, 200, 6, 0.05
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=1, num_heads=H, dropout_rate=0.0, max_bins=max_bins, lr=1e-3, seed=2, l2_emb=l2)
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=1, num_heads=H, dropout_rate=0.0, max_bins=max_bins, lr=1e-3, l2_emb=l2)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=3, attn_precision="f32")
+    P = fm.init_params(model, 9, itemnum, ohp, seed=5)
+    P = {k: v + 0.05 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
+    eng.load_params(P)
+    P = {k: v.double().cpu() for k, v in eng.get_params().items()}
+    batch_np = make_batch(rs, B, T, itemnum, max_bins)
+    batch = fm.to_batch(*batch_np)
+    opt = fm.AdamTF(P, lr=1e-3)
+    for step in (1, 2, 3):
+        out, G = fm.loss_and_grads(model, P, ohp, batch)
+        P = opt.step(P, G)
+        eng.train_step(*batch_np)
+        torch.cuda.synchronize()
+        loss, _ = eng.loss_auc()
+        assert loss == pytest.approx(float(out["loss"]), rel=2e-5)           # the penalty is part of the reported loss
+    now = eng.get_params()
+    untouched = np.setdiff1d(np.arange(1, itemnum + 1), np.unique(np.concatenate([a.reshape(-1) for a in batch_np[:3]])))
+    assert len(untouched) > 50
+    for k in ("item_emb",) + (("time_emb", "hours_emb", "days_emb") if model == "cast_3" else ("pos_emb",)):
+        assert float((now[k].cpu().double() - P[k]).abs().max()) < 2e-5, k          # incl. rows the batch never touched

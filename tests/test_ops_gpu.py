@@ -431,3 +431,19 @@ def test_graph_capture_replay(ops):
             g.launch()
     s.synchronize()
     assert torch.equal(y, 6 * x)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256, 52])
+def test_test_logits_vector_path(ops, D):
+    """cr_test_logits for hidden sizes that are multiples of 4 takes the 16-lanes-per-row form (the read-only gather
+    the bench holds against the HBM read roofline): same values as the scalar path, row 0 reads as zeros."""
+    rs = np.random.RandomState(D)
+    B, T, V, nc = 5, 7, 97, 101
+    table = rs.standard_normal((V, D)); semb = rs.standard_normal((B * T, D))
+    cand = rs.randint(0, V, (B, nc)); cand[0, :3] = 0
+    t0 = table.copy(); t0[0] = 0
+    want = np.einsum("bd,bnd->bn", semb.reshape(B, T, D)[:, -1], t0[cand])
+    out = torch.full((B, nc), float("nan"), device="cuda")
+    ops.test_logits(dev(semb), D, dev(table), dev(cand, torch.int32), B, T, D, out)
+    torch.cuda.synchronize()
+    assert relerr(out, want) < 2e-6

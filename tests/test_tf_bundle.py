@@ -80,3 +80,48 @@ def test_trained_weight_fixture_is_consistent():
     assert {k: w[k].shape for k in w.files} == want
     # trained: LayerNorm offsets have left zero (the initial-point mask degeneracy of DESIGN.md section 2 is gone)
     assert float(np.abs(w["trunk.0.ln1.beta"]).max()) > 1e-3
+
+
+def _block_vars(scope):
+    out = []
+    for ln in ("ln", "ln_1"):
+        out += ["%s/%s/Variable" % (scope, ln), "%s/%s/Variable_1" % (scope, ln)]
+    for d_ in ("dense", "dense_1", "dense_2"):
+        out += ["%s/self_attention/%s/kernel" % (scope, d_), "%s/self_attention/%s/bias" % (scope, d_)]
+    for c_ in ("conv1d", "conv1d_1"):
+        out += ["%s/multihead_attention/%s/kernel" % (scope, c_), "%s/multihead_attention/%s/bias" % (scope, c_)]
+    return out
+
+
+@pytest.mark.parametrize("model", ["cast_8", "cast_9"])
+def test_variable_names_of_the_models_without_a_shipped_checkpoint(model):
+    """The reference ships no cast_7/8/9 run, so no .index fixture exists for them; their variable names are written
+    down here from the scopes of models/cast_8.py:54-95 and models/cast_9.py:56-129 (hours / days stacks under
+    INPUT-CONTEXT with its first and second `normalize` as their final LayerNorms, cast_9's time stack under
+    TEMPORAL-CONTEXT, no unused LayerNorm in these blocks) and must map one-to-one onto the model's parameters."""
+    import types
+    from castrec_amd import engine as E
+    from castrec_amd import tf_bundle as tb
+    L_, Lc = 2, 1
+    hp = E.Hyper(types.SimpleNamespace(maxlen=10, hidden_units=8, num_blocks=L_, num_heads=1, dropout_rate=0.1, l2_emb=0.0, lr=1e-3,
+                                       max_bins=5, num_context_blocks=Lc, seed=1))
+    lay = E.ParamLayout(model, 5, 11, hp)
+    names = ["INPUT-CONTEXT/hours_embeddings/lookup_table", "INPUT-CONTEXT/days_embeddings/lookup_table",
+             "INPUT-CONTEXT/ln/Variable", "INPUT-CONTEXT/ln/Variable_1", "INPUT-CONTEXT/ln_1/Variable", "INPUT-CONTEXT/ln_1/Variable_1",
+             "SASRec/input_embeddings/lookup_table", "SASRec/ln/Variable", "SASRec/ln/Variable_1",
+             "SASRec/MLP/dense/kernel", "SASRec/MLP/dense/bias", "SASRec/MLP/dense_1/kernel", "SASRec/MLP/dense_1/bias"]
+    nctx = L_ if model == "cast_8" else Lc
+    for i in range(nctx):
+        names += _block_vars("INPUT-CONTEXT/hours_seq_num_blocks_%d" % i) + _block_vars("INPUT-CONTEXT/days_seq_num_blocks_%d" % i)
+    for i in range(L_):
+        names += _block_vars("SASRec/num_blocks_%d" % i)
+    if model == "cast_9":
+        names += ["TEMPORAL-CONTEXT/time_embeddings/lookup_table", "TEMPORAL-CONTEXT/ln/Variable", "TEMPORAL-CONTEXT/ln/Variable_1",
+                  "SASRec/dec_pos/lookup_table"]
+        for i in range(Lc):
+            names += _block_vars("TEMPORAL-CONTEXT/timeseq_num_blocks_%d" % i)
+    names += [n + s for n in list(names) for s in ("/Adam", "/Adam_1")] + ["beta1_power", "beta2_power"]
+    mapped = [tb.logical_name(n) for n in names]
+    got = sorted(m for m in mapped if m is not None)
+    assert got == sorted(lay.logical_names())
+    assert len(set(got)) == len(got)

@@ -104,3 +104,15 @@ def test_attention_heat_map_svg_round_trips(tmp_path):
     assert px[3, 0, 0] == 255 and 0 < px[3, 0, 1] < 255 and px[3, 0, 2] == 0         # 18/35 = .51: red full, green partial
     with pytest.raises(ValueError):
         U.plot_attention_weights(np.zeros((2, 3, 3)), str(tmp_path))
+
+
+def test_log_scale_needs_200_bins():
+    """sampler.py:66 hard-codes max_bins=200 for log-scale bins; a smaller time table would be indexed out of range."""
+    import types
+    import pytest as _pt
+    from castrec_amd.sampler import WarpSampler
+    from castrec_amd import synth
+    corpus = synth.preset("tiny") if hasattr(synth, "preset") else None
+    args = types.SimpleNamespace(seed=1, bin_in_hours=48, max_bins=100, log_scale=True)
+    with _pt.raises(ValueError, match="max_bins must be >= 200"):
+        WarpSampler(args, corpus, 5, 5, batch_size=2, maxlen=4)
