@@ -42,8 +42,9 @@ __device__ __forceinline__ float slab_sum64(const float* slabs, int n_slabs, int
     return g;
 }
 
-// blocks [0, nb_dense): 64 dense parameters each (slab reduction + update); the rest: table entries, grid-stride
-__global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
+// blocks [0, nb_dense): 64 dense parameters each (slab reduction + update); then nb_lazy blocks (lazy item-table rows,
+// one wave per listed id); the rest: table entries, grid-stride
+__global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy) {
     __shared__ float part[16][64];
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
     const float* st = d.stats ? d.stats : d.state;
@@ -64,9 +65,29 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense) {
         const int j0 = blockIdx.x * 64;
         const float g = slab_sum64(d.dense_slabs, d.n_slabs, d.n_dense, j0, part);
         if (threadIdx.x < 64 && j0 + (int)threadIdx.x < d.n_dense) update(d.n_table + j0 + threadIdx.x, g);
+    } else if ((int)blockIdx.x < nb_dense + nb_lazy) {
+        // lazy rows: wave w of the lazy blocks walks ids w, w + W, ...; the first wave to swap the step number into a row's
+        // flag owns the row (every other occurrence of the id finds it there and moves on)
+        const int lane = threadIdx.x & 63;
+        const int W = nb_lazy * 4;
+        for (int k = ((int)blockIdx.x - nb_dense) * 4 + (threadIdx.x >> 6); k < d.n_lazy_ids; k += W) {
+            const int id = d.lazy_ids[k];
+            if (id <= 0 || id >= d.lazy_rows) continue;                       // row 0: the zero-pad row never has a gradient
+            int mine = 0;
+            if (lane == 0) mine = atomicExch(&d.lazy_flags[id], t) != t;
+            mine = __shfl(mine, 0, 64);
+            if (!mine) continue;
+            for (int c = lane; c < d.lazy_D; c += 64) {
+                const int i = id * d.lazy_D + c;
+                const float g = d.table_grad[i];
+                d.table_grad[i] = 0.0f;
+                update(i, g);
+            }
+        }
     } else {
-        const int nb_table = gridDim.x - nb_dense;
-        for (int i = (blockIdx.x - nb_dense) * 256 + threadIdx.x; i < d.n_table; i += nb_table * 256) {
+        const int nb_table = gridDim.x - nb_dense - nb_lazy;
+        const int first = nb_lazy > 0 ? d.lazy_rows * d.lazy_D : 0;          // the lazy part of the table section is not swept
+        for (int i = first + ((int)blockIdx.x - nb_dense - nb_lazy) * 256 + threadIdx.x; i < d.n_table; i += nb_table * 256) {
             const float g = d.table_grad[i];
             d.table_grad[i] = 0.0f;
             update(i, g);
@@ -89,9 +110,18 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     CR_REQUIRE(d->n_dense == 0 || (d->dense_slabs && d->n_slabs > 0), "cr_adam_step: dense_slabs missing");
     CR_REQUIRE(d->step_snapshot == nullptr || d->stats != nullptr, "cr_adam_step: step_snapshot needs stats (a copy of the sums that does not alias state[0..2])");
     const int nb_dense = cr_ceil_div(d->n_dense, 64);
-    int nb_table = cr_ceil_div(d->n_table, 256);
+    int nb_lazy = 0, n_swept = d->n_table;
+    if (d->lazy_ids) {
+        CR_REQUIRE(d->lazy_flags && d->n_lazy_ids > 0 && d->lazy_rows > 0 && d->lazy_D > 0 &&
+                   (long long)d->lazy_rows * d->lazy_D <= d->n_table, "cr_adam_step: bad lazy-row arguments");
+        nb_lazy = cr_ceil_div(d->n_lazy_ids, 4 * 8);                      // ~8 ids per wave
+        if (nb_lazy > 4096) nb_lazy = 4096;
+        n_swept = d->n_table - d->lazy_rows * d->lazy_D;
+    }
+    int nb_table = cr_ceil_div(n_swept, 256);
     if (nb_table > 2048) nb_table = 2048;
-    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_table), dim3(256), 0, cr_stream(stream), *d, nb_dense);
+    if (nb_table < 1) nb_table = 1;
+    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table), dim3(256), 0, cr_stream(stream), *d, nb_dense, nb_lazy);
     return cr_check_launch("cr_adam_step");
 }
 

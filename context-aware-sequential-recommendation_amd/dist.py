@@ -80,6 +80,7 @@ def exchange_table_rows(table, ids, world, group=None):
     table.index_fill_(0, idu, 0.0)                                # this rank's share travels in `rows` like everyone's
     for r in range(world):                                        # fixed order: the sums match on every rank
         table.index_add_(0, all_ids[r].to(torch.int64), all_rows[r])
+    return all_ids
 
 
 class DataParallel:
@@ -96,6 +97,8 @@ class DataParallel:
             sp = sparse_exchange_bytes(spec["n_slots"], spec["D"], world)
             self.sparse = True if sparse else (sp < 0.5 * dense)   # only when it at least halves the traffic
             self.exchange_bytes = dict(dense_allreduce=dense, sparse_allgather=sp)
+        if world > 1 and getattr(replica, "lazy_adam", False) and not self.sparse:
+            raise ValueError("lazy Adam under data parallelism needs the sparse table exchange (every replica must update the same rows)")
         if world > 1:
             import torch.distributed as dist
             dist.broadcast(replica.param_vector(), 0, group=process_group)       # same start everywhere
@@ -115,7 +118,9 @@ class DataParallel:
         if self.sparse:
             spec = self.replica.sparse_spec()
             n_item, D = spec["n_item"], spec["D"]
-            exchange_table_rows(bucket[:n_item].view(-1, D), spec["ids"]().to(bucket.device), self.world, self.pg)
+            all_ids = exchange_table_rows(bucket[:n_item].view(-1, D), spec["ids"]().to(bucket.device), self.world, self.pg)
+            if hasattr(self.replica, "set_lazy_ids"):
+                self.replica.set_lazy_ids(torch.cat(all_ids))                     # row-sparse Adam: the rows ANY rank touched
             dist.all_reduce(bucket[n_item:], group=self.pg)                       # positional table, dense grads, loss statistics
         else:
             dist.all_reduce(bucket, group=self.pg)                                # sum of grads and of loss statistics
@@ -142,6 +147,14 @@ class EngineReplica:
 
     def adam_from_flat(self):
         self.e.launch_adam_from_flat()
+
+    @property
+    def lazy_adam(self):
+        return self.e.lazy_adam
+
+    def set_lazy_ids(self, ids):
+        if self.e.lazy_adam:
+            self.e.lazy_ids.copy_(ids.to(self.e.lazy_ids.device, torch.int32))
 
     def sparse_spec(self):
         """The item table leads the bucket; its gradient rows of a step are those of the seq / pos / neg ids

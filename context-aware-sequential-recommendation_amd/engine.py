@@ -180,7 +180,7 @@ class ParamLayout:
 class Engine:
     def __init__(self, model, usernum, itemnum, hp, batch_size, training=True, seed=None, n_slabs=None,
                  share=None, batch_global=None, row_offset=0, want_attn=False, device="cuda", fused=None,
-                 attn_precision=None):
+                 attn_precision=None, lazy_adam=None):
         if model not in MODELS:
             raise ValueError("model must be one of %s" % MODELS)
         if not torch.cuda.is_available():
@@ -192,6 +192,9 @@ class Engine:
         if attn_precision not in ATTN_PRECISIONS:
             raise ValueError("attn_precision must be one of %s" % sorted(ATTN_PRECISIONS))
         self.attn_precision = attn_precision
+        # row-sparse Adam on the item table (DEVIATION from the reference's dense update, for tables like C5's 10 M rows;
+        # castrec.h cr_adam_desc.lazy_ids): off unless asked for
+        self.lazy_adam = bool(int(os.environ.get("CASTREC_LAZY_ADAM", "0"))) if lazy_adam is None else bool(lazy_adam)
         self.M = self.B * self.T
         self.usernum, self.itemnum = usernum, itemnum
         self.training = training
@@ -764,13 +767,21 @@ class Engine:
             snap, tsnap = self.state.data_ptr() + 4 * 8, self.state.data_ptr() + 4 * 11
             l2 = float(self.hp.l2_emb)
             n_l2 = lay.n_l2 if l2 != 0.0 else 0
+            lazy = (None, 0, 0, 0, None)
+            if self.lazy_adam:
+                self.lazy_flags = torch.zeros(self.itemnum + 1, dtype=torch.int32, device=self.dev)
+                world = max(1, self.batch_global // self.B)
+                # this step's seq | pos | neg ids; under data parallelism the ids of ALL ranks (the sparse exchange hands
+                # them over, dist.DataParallel.exchange): every replica must update the same rows
+                self.lazy_ids = self.ids_all[:3].reshape(-1) if world == 1 else torch.zeros(world * 3 * self.M, dtype=torch.int32, device=self.dev)
+                lazy = (self.lazy_ids.data_ptr(), self.lazy_ids.numel(), self.itemnum + 1, self.D, self.lazy_flags.data_ptr())
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
                             lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr(),
-                            snap, tsnap, l2, n_l2)
+                            snap, tsnap, l2, n_l2, *lazy)
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
-                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap, l2, n_l2)
+                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap, l2, n_l2, *lazy)
             self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
             self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
                             (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,

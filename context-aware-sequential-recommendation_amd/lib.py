@@ -112,7 +112,8 @@ class HeadDesc(C.Structure):
 class AdamDesc(C.Structure):
     _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
                 ("n_table", c_i), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
-                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", c_i)]
+                ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", c_i),
+                ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p)]
 
 
 def _sig(name, restype, argtypes):

@@ -127,10 +127,11 @@ def test_logits(seq_emb, ld, table, cand, B, T, D, logits):
 
 
 def adam_step(p, m, v, table_grad, dense_slabs, n_table, n_dense, n_slabs, lr, state, beta1=0.9, beta2=0.98, eps=1e-8,
-              stats=None, step_snapshot=None):
+              stats=None, step_snapshot=None, lazy_ids=None, lazy_rows=0, lazy_D=0, lazy_flags=None):
     d = L.AdamDesc(_p(p), _p(m), _p(v), _p(table_grad), _p(dense_slabs), n_table, n_dense, n_slabs, lr, beta1, beta2,
                    eps, _p(state), _p(stats) if stats is not None else None,
-                   _p(step_snapshot) if step_snapshot is not None else None, 0.0, 0)
+                   _p(step_snapshot) if step_snapshot is not None else None, 0.0, 0,
+                   _p(lazy_ids), 0 if lazy_ids is None else lazy_ids.numel(), lazy_rows, lazy_D, _p(lazy_flags))
     L.call("cr_adam_step", C.byref(d), _stream())
 
 

@@ -339,6 +339,14 @@ typedef struct {
     float l2; int n_l2;               /* embedding regulariser (modules.py:149-153, sasrec.py:109-110): the first n_l2
                                          parameters (the lookup tables: they lead the flat vector) get g += l2 * p, and
                                          the reported loss gets state[7] (written by cr_l2_penalty) added */
+    /* Lazy (row-sparse) Adam for the leading item table -- a DEVIATION from the reference, off unless lazy_ids is set.
+     * The reference's zero-padded lookup (modules.py:154-157) makes TensorFlow update EVERY table row densely each step
+     * (rows without gradient still drift on their momentum): 7 accesses x 10.24 GB at config C5.  With lazy_ids the
+     * first lazy_rows * lazy_D parameters are updated only in the rows listed (duplicates and id 0 allowed; each row
+     * is claimed once through lazy_flags[row], which must hold values != the current step number): m, v, p and the
+     * gradient of the other rows are not touched.  Rows updated in every step so far match dense Adam exactly. */
+    const int32_t* lazy_ids; int n_lazy_ids, lazy_rows, lazy_D;
+    uint32_t* lazy_flags;             /* [lazy_rows] */
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 

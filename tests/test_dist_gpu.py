@@ -120,3 +120,57 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
     st = res[0][2]
     assert st[0] / st[2] == pytest.approx(loss_one, rel=1e-5)  # bucket tail: loss_sum, auc_sum, n_target of the WHOLE batch
     assert st[2] == float((make_batch(STEPS - 1, items)[1] != 0).sum())
+
+
+def _rccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine as E
+    from castrec_amd.dist import DataParallel, EngineReplica, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    lo, hi = shard_rows(B, rank, world)
+    eng = E.Engine("cast_1", USERS, ITEMS, hyper(E), hi - lo, training=True, n_slabs=8, batch_global=B, row_offset=lo * T)
+    rep = EngineReplica(eng, use_graph=True)
+    dp = DataParallel(rep, rank, world, sparse=(rank >= 0 and os.environ.get("CASTREC_TEST_SPARSE") == "1"))
+    for s in range(STEPS):
+        dp.step(make_batch(s))
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, dist.get_backend(), dist.get_world_size()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("sparse", ["0", "1"])
+def test_two_gpus_over_rccl(sparse, monkeypatch):
+    """The same comparison with one rank per GPU and the exchange on RCCL (torch.distributed 'nccl'): needs two
+    visible devices, so it is skipped on the one-GPU test box and runs wherever the driver has a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine as E
+    monkeypatch.setenv("CASTREC_TEST_SPARSE", sparse)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] == "nccl" and res[0][3] == 2
+    one = E.Engine("cast_1", USERS, ITEMS, hyper(E), B, training=True, n_slabs=8)
+    for s_ in range(STEPS):
+        one.train_step(*make_batch(s_))
+    torch.cuda.synchronize()
+    ref = {k: v.cpu().numpy() for k, v in one.get_params().items()}
+    for k in ref:
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
+        if not k.endswith(".bk"):
+            np.testing.assert_allclose(res[0][1][k], ref[k], rtol=0, atol=5e-6, err_msg=k)

@@ -447,3 +447,54 @@ def test_test_logits_vector_path(ops, D):
     ops.test_logits(dev(semb), D, dev(table), dev(cand, torch.int32), B, T, D, out)
     torch.cuda.synchronize()
     assert relerr(out, want) < 2e-6
+
+
+def test_adam_lazy_rows_against_dense(ops):
+    """Row-sparse Adam on the leading item table (castrec.h cr_adam_desc.lazy_ids; a documented deviation for tables like
+    config C5's).  Step 1 from zero moments: identical to dense everywhere.  Step 2 with other rows: rows touched in both
+    steps or only now are identical; rows touched only in step 1 stay put under lazy Adam while dense Adam moves them by
+    their decayed momentum alone -- exactly lr_t * (b1 m) / (sqrt(b2 v) + eps); the dense section is never affected."""
+    rs = np.random.RandomState(4)
+    V, D, n_dense, lr, b1, b2, eps = 40, 12, 70, 1e-2, 0.9, 0.98, 1e-8
+    n_table = V * D + 5 * D                                  # item table + a small positional table swept densely
+    p0 = rs.standard_normal(n_table + n_dense).astype(np.float32)
+    ids1 = np.array([3, 7, 7, 0, 9, 12, 3], np.int32); ids2 = np.array([7, 9, 20, 21, 0], np.int32)
+
+    def grads(ids, seed):
+        g = np.zeros(n_table, np.float32)
+        r = np.random.RandomState(seed)
+        for i in set(ids.tolist()) - {0}:
+            g[i * D:(i + 1) * D] = r.standard_normal(D)
+        g[V * D:] = r.standard_normal(5 * D)
+        return g, r.standard_normal((3, n_dense)).astype(np.float32)
+
+    def run(lazy):
+        P, M, Vv = dev(p0.copy()), torch.zeros(n_table + n_dense, device="cuda"), torch.zeros(n_table + n_dense, device="cuda")
+        st = new_state(step=1)
+        flags = torch.zeros(V, dtype=torch.int32, device="cuda")
+        snaps = []
+        for step, (ids, seed) in enumerate(((ids1, 1), (ids2, 2)), 1):
+            g, slabs = grads(ids, seed)
+            st[0], st[1], st[2] = 5.0, 2.0, 4.0
+            st[4:5].view(torch.int32)[0] = step
+            kw = dict(lazy_ids=dev(ids, torch.int32), lazy_rows=V, lazy_D=D, lazy_flags=flags) if lazy else {}
+            ops.adam_step(P, M, Vv, dev(g), dev(slabs), n_table, n_dense, 3, lr, st, **kw)
+            torch.cuda.synchronize()
+            snaps.append((P.cpu().numpy().copy(), M.cpu().numpy().copy(), Vv.cpu().numpy().copy()))
+        return snaps
+    dense, lazy = run(False), run(True)
+    np.testing.assert_array_equal(dense[0][0], lazy[0][0])              # step 1: nothing to tell them apart
+    pd, pl = dense[1][0], lazy[1][0]
+    np.testing.assert_array_equal(pd[V * D:], pl[V * D:])               # positional table + dense section: always dense
+    row = lambda a, i: a[i * D:(i + 1) * D]
+    for i in (7, 9, 20, 21):                                            # touched now (7, 9 also before): identical
+        np.testing.assert_array_equal(row(pd, i), row(pl, i))
+    for i in (3, 12):                                                   # touched only in step 1: momentum drift under dense Adam
+        np.testing.assert_array_equal(row(pl, i), row(lazy[0][0], i))
+        m1, v1 = row(dense[0][1], i).astype(np.float64), row(dense[0][2], i).astype(np.float64)
+        lr_t = lr * math.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
+        drift = lr_t * (b1 * m1) / (np.sqrt(b2 * v1) + eps)
+        np.testing.assert_allclose(row(dense[0][0], i) - row(pd, i), drift, rtol=2e-5, atol=1e-9)
+    untouched = [i for i in range(1, V) if i not in (3, 7, 9, 12, 20, 21)]
+    for i in untouched + [0]:
+        np.testing.assert_array_equal(row(pl, i), row(p0, i)); np.testing.assert_array_equal(row(pd, i), row(p0, i))
