@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmBatch batch) {
     }
 }
 
+// bf16-MFMA forms (cr_gemm_bf.hip)
+bool cr_gemm_rows_bf_supported(const cr_gemm_desc* d, int n);
+int cr_gemm_rows_bf_launch(const cr_gemm_desc* d, int n, hipStream_t s);
+bool cr_gemm_wgrad_bf_supported(const cr_wgrad_desc* d, int n);
+int cr_gemm_wgrad_bf_launch(const cr_wgrad_desc* d, int n, int slab_stride, int n_slabs, hipStream_t s);
+
 extern "C" int cr_gemm_rows(const cr_gemm_desc* d, int n, void* stream) {
     CR_REQUIRE(d && n >= 1 && n <= CR_MAX_BATCH, "cr_gemm_rows: n_problems=%d out of [1,%d]", n, CR_MAX_BATCH);
     GemmBatch b;
@@ -111,10 +117,12 @@ extern "C" int cr_gemm_rows(const cr_gemm_desc* d, int n, void* stream) {
         CR_REQUIRE(d[i].M > 0 && d[i].N > 0 && d[i].K > 0, "cr_gemm_rows[%d]: bad shape %dx%dx%d", i, d[i].M, d[i].N, d[i].K);
         CR_REQUIRE(d[i].lda >= d[i].K && d[i].ldc >= d[i].N, "cr_gemm_rows[%d]: leading dimension too small", i);
         CR_REQUIRE(d[i].ldb >= (d[i].trans_b ? d[i].K : d[i].N), "cr_gemm_rows[%d]: ldb too small", i);
+        CR_REQUIRE(d[i].precision >= CR_PREC_F32 && d[i].precision <= CR_PREC_BF16, "cr_gemm_rows[%d]: unknown precision %d", i, d[i].precision);
         b.p[i] = d[i];
         const int tiles = cr_ceil_div(d[i].M, G_BM) * cr_ceil_div(d[i].N, G_BN);
         if (tiles > maxtiles) maxtiles = tiles;
     }
+    if (cr_gemm_rows_bf_supported(d, n)) return cr_gemm_rows_bf_launch(d, n, cr_stream(stream));
     for (int i = n; i < CR_MAX_BATCH; ++i) b.p[i] = d[0];
     hipLaunchKernelGGL(k_gemm_rows, dim3(maxtiles, n), dim3(256), 0, cr_stream(stream), b);
     return cr_check_launch("cr_gemm_rows");
@@ -213,6 +221,7 @@ extern "C" int cr_gemm_wgrad(const cr_wgrad_desc* d, int n, int slab_stride, int
         b.p[i] = d[i];
         tiles += cr_ceil_div(d[i].K, 64) * cr_ceil_div(d[i].N, 64);
     }
+    if (cr_gemm_wgrad_bf_supported(d, n)) return cr_gemm_wgrad_bf_launch(d, n, slab_stride, n_slabs, cr_stream(stream));
     for (int i = n; i < CR_MAX_BATCH; ++i) b.p[i] = d[0];
     hipLaunchKernelGGL(k_gemm_wgrad, dim3(tiles, n_slabs), dim3(256), 0, cr_stream(stream), b);
     return cr_check_launch("cr_gemm_wgrad");

@@ -282,6 +282,10 @@ class Engine:
         return 0 if first else 1
 
     def _call(self, lst, name, *args):
+        if name in ("cr_gemm_rows", "cr_gemm_wgrad"):
+            # the unfused dense layers (hidden sizes above 64, the CAST mlp) follow the engine's matmul arithmetic
+            for i in range(args[1]):
+                args[0][i].precision = ATTN_PRECISIONS[self.attn_precision]
         fn = getattr(L.lib, name)
         self._keep.append(args)
         lst.append((name, fn, args))

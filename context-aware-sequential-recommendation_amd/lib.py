@@ -59,12 +59,12 @@ class LnBwdDesc(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [("A", c_p), ("lda", c_i), ("B", c_p), ("ldb", c_i), ("bias", c_p), ("C", c_p), ("ldc", c_i),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("trans_b", c_i), ("relu", c_i), ("drop", Rng),
-                ("residual", c_p), ("ldr", c_i), ("mask_ids", c_p), ("accumulate", c_i)]
+                ("residual", c_p), ("ldr", c_i), ("mask_ids", c_p), ("accumulate", c_i), ("precision", c_i)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("A", c_p), ("lda", c_i), ("G", c_p), ("ldg", c_i), ("dW", c_p), ("ldw", c_i), ("db", c_p),
-                ("M", c_i), ("N", c_i), ("K", c_i)]
+                ("M", c_i), ("N", c_i), ("K", c_i), ("precision", c_i)]
 
 
 class EltDesc(C.Structure):

@@ -73,9 +73,9 @@ def layernorm_bwd(x, ldx, gamma, dy, lddy, dx, lddx, dgamma, dbeta, slab_stride,
 
 
 def gemm_desc(A, lda, B, ldb, Cm, ldc, M, N, K, bias=None, trans_b=False, relu=False, rng=NO_DROP, residual=None,
-              ldr=0, mask_ids=None, accumulate=False):
+              ldr=0, mask_ids=None, accumulate=False, precision=0):
     return L.GemmDesc(_p(A), lda, _p(B), ldb, _p(bias), _p(Cm), ldc, M, N, K, int(trans_b), int(relu), rng,
-                      _p(residual), ldr, _p(mask_ids), int(accumulate))
+                      _p(residual), ldr, _p(mask_ids), int(accumulate), int(precision))
 
 
 def gemm_rows(descs):
@@ -83,8 +83,8 @@ def gemm_rows(descs):
     L.call("cr_gemm_rows", arr, len(descs), _stream())
 
 
-def wgrad_desc(A, lda, G, ldg, dW, db, M, N, K, ldw=None):
-    return L.WgradDesc(_p(A), lda, _p(G), ldg, _p(dW), N if ldw is None else ldw, _p(db), M, N, K)
+def wgrad_desc(A, lda, G, ldg, dW, db, M, N, K, ldw=None, precision=0):
+    return L.WgradDesc(_p(A), lda, _p(G), ldg, _p(dW), N if ldw is None else ldw, _p(db), M, N, K, int(precision))
 
 
 def gemm_wgrad(descs, slab_stride, n_slabs):

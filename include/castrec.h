@@ -124,6 +124,17 @@ typedef struct {
 } cr_ln_bwd_desc;
 int cr_layernorm_bwd(const cr_ln_bwd_desc* d, void* stream);
 
+/* Arithmetic of the matrix products (cr_attn_desc.precision, cr_gemm_desc.precision, cr_wgrad_desc.precision).  The reference is fp32 end to end
+ * (modules.py:203-262); BASELINE.json configs[1] names bf16.
+ *   CR_PREC_F32     v_mfma_f32_16x16x4_f32: exact fp32 fma chains (T <= 256, head dim <= 64; other shapes: general kernels)
+ *   CR_PREC_BF16X3  v_mfma_f32_16x16x32_bf16 on operands split into bf16 hi + lo, three products per term
+ *                   (hi*hi + hi*lo + lo*hi): ~1e-5 relative, inside the 1e-3 fp32 bound; forward T <= 256,
+ *                   backward T <= 1024 (needs row_stats), head dim <= 64
+ *   CR_PREC_BF16    the same kernels on the hi halves only: plain bf16 operands, fp32 accumulation */
+#define CR_PREC_F32 0
+#define CR_PREC_BF16X3 1
+#define CR_PREC_BF16 2
+
 /* ---- row GEMM with fused epilogue -------------------------------------------------
  * C[M,N] = epilogue(A[M,K] @ op(B) + bias)
  *   tf.layers.dense (modules.py:203-205,333-334), conv1d k=1 (modules.py:300-310),
@@ -141,6 +152,7 @@ typedef struct {
     const float* residual; int ldr;
     const int32_t* mask_ids;   /* [M] or NULL */
     int accumulate;            /* C += value */
+    int precision;             /* CR_PREC_*: fp32 MFMA (exact), or bf16 MFMA on split / plain operands (K, N >= 8) */
 } cr_gemm_desc;
 int cr_gemm_rows(const cr_gemm_desc* d, int n_problems, void* stream);
 
@@ -153,6 +165,7 @@ typedef struct {
                                   fused [D,3D] QKV weight are addressed this way */
     float* db;                 /* slab 0 or NULL */
     int M, N, K;
+    int precision;             /* CR_PREC_* as in cr_gemm_desc */
 } cr_wgrad_desc;
 int cr_gemm_wgrad(const cr_wgrad_desc* d, int n_problems, int slab_stride, int n_slabs, void* stream);
 
@@ -179,16 +192,6 @@ typedef struct {
 } cr_elt_desc;
 int cr_eltwise(const cr_elt_desc* d, void* stream);
 
-/* Arithmetic of the attention products (cr_attn_desc.precision).  The reference is fp32 end to end
- * (modules.py:203-262); BASELINE.json configs[1] names bf16.
- *   CR_PREC_F32     v_mfma_f32_16x16x4_f32: exact fp32 fma chains (T <= 256, head dim <= 64; other shapes: general kernels)
- *   CR_PREC_BF16X3  v_mfma_f32_16x16x32_bf16 on operands split into bf16 hi + lo, three products per term
- *                   (hi*hi + hi*lo + lo*hi): ~1e-5 relative, inside the 1e-3 fp32 bound; forward T <= 256,
- *                   backward T <= 1024 (needs row_stats), head dim <= 64
- *   CR_PREC_BF16    the same kernels on the hi halves only: plain bf16 operands, fp32 accumulation */
-#define CR_PREC_F32 0
-#define CR_PREC_BF16X3 1
-#define CR_PREC_BF16 2
 
 /* ---- causal multi-head self-attention core (modules.py:208-269) ---------------------
  * Per head j (columns [j*d, (j+1)*d) of Q/K/V, d = D/H):

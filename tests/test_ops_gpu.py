@@ -498,3 +498,49 @@ def test_adam_lazy_rows_against_dense(ops):
     untouched = [i for i in range(1, V) if i not in (3, 7, 9, 12, 20, 21)]
     for i in untouched + [0]:
         np.testing.assert_array_equal(row(pl, i), row(p0, i)); np.testing.assert_array_equal(row(pd, i), row(p0, i))
+
+
+GEMM_BF_TOL = {1: 1e-4, 2: 3e-2}
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 50, 50), (333, 200, 150), (130, 128, 128), (257, 512, 128), (70, 9, 8), (1000, 128, 512)])
+@pytest.mark.parametrize("trans_b", [False, True])
+def test_gemm_rows_bf16_mfma(ops, M, N, K, trans_b, prec):
+    """cr_gemm_rows with precision CR_PREC_BF16X3 / CR_PREC_BF16 (csrc/cr_gemm_bf.hip): every tail (rows, columns, K not a
+    multiple of 8 / 32 / 64), padded leading dimensions with NaN beyond the matrices, epilogue included."""
+    rs = np.random.RandomState(M + N + K)
+    lda, ldb, ldc = K + 3, (K if trans_b else N) + 5, N + 2
+    A = rs.standard_normal((M, K)); B = rs.standard_normal((N, K) if trans_b else (K, N)); bias = rs.standard_normal(N)
+    res = rs.standard_normal((M, N)); ids = rs.randint(0, 3, M)
+
+    def pad(a, ld):
+        buf = torch.full((a.shape[0], ld), float("nan"), device="cuda")
+        buf[:, :a.shape[1]] = dev(a)
+        return buf
+    Ad, Bd, Cd, Rd = pad(A, lda), pad(B, ldb), torch.full((M, ldc), float("nan"), device="cuda"), pad(res, N)
+    want = np.maximum(A @ (B.T if trans_b else B) + bias, 0) + res
+    want = want * (ids != 0)[:, None]
+    d = ops.gemm_desc(Ad, lda, Bd, ldb, Cd, ldc, M, N, K, bias=dev(bias), trans_b=trans_b, relu=True, residual=Rd, ldr=N,
+                      mask_ids=dev(ids, torch.int32), precision=prec)
+    ops.gemm_rows([d])
+    torch.cuda.synchronize()
+    assert relerr(Cd[:, :N], want) < GEMM_BF_TOL[prec]
+    assert torch.isnan(Cd[:, N:]).all()
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K,ns", [(1000, 50, 50, 7), (257, 200, 150, 64), (64, 128, 128, 1), (25600 // 8, 128, 256, 25), (50, 64, 64, 128)])
+def test_gemm_wgrad_bf16_mfma(ops, M, N, K, ns, prec):
+    rs = np.random.RandomState(M + N + K + ns)
+    A = rs.standard_normal((M, K)); G = rs.standard_normal((M, N))
+    stride = K * N + N + 7
+    slabs = torch.full((ns, stride), float("nan"), device="cuda")
+    d = ops.wgrad_desc(dev(A), K, dev(G), N, slabs, slabs[0, K * N:], M, N, K, precision=prec)
+    ops.gemm_wgrad([d], stride, ns)
+    torch.cuda.synchronize()
+    dW = slabs[:, :K * N].double().sum(0).reshape(K, N).cpu().numpy()
+    db = slabs[:, K * N:K * N + N].double().sum(0).cpu().numpy()
+    assert relerr(dW, A.T @ G) < GEMM_BF_TOL[prec]
+    assert relerr(db, G.sum(0)) < GEMM_BF_TOL[prec]
+    assert torch.isnan(slabs[:, K * N + N:]).all()

@@ -44,18 +44,24 @@ def timeline(which, title, names):
     live = t[:, 15] > 0
     idx = np.arange(len(live))[live]
     t = t[live]
-    w0 = t[:, 0].min()
-    start, end = (t[:, 0] - w0) * 10.0, (t[:, 15] - w0) * 10.0
+    t0 = np.where(t[:, 0] > 0, t[:, 0], np.nan)             # (the key-owner workgroups of the fused kernel stamp slots 8.. only)
+    w0 = np.nanmin(t0)
+    start, end = (np.nan_to_num(t0, nan=w0) - w0) * 10.0, (t[:, 15] - w0) * 10.0
     print("==", title, " waves", len(t), " span %.1f us" % (end.max() / 1e3))
     print("wave start ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(start, [10, 50, 90, 100])))
     print("wave life  ns: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(end - start, [10, 50, 90, 100])))
-    for sel_name, sel in (("all waves", np.ones(len(t), bool)), ("heaviest-tile waves (wave 0 of workgroup y = 0)", ((idx % 8) == 0) & ((idx // 8) < B * H))):
+    for sel_name, sel in (("all waves", np.ones(len(t), bool)), ("wave 0 of workgroups y = 0", ((idx % 8) == 0) & ((idx // 8) < B * H)),
+                          ("wave 0 of workgroups y = 1", ((idx % 8) == 0) & ((idx // 8) >= B * H))):
         tt = t[sel]
+        if len(tt) == 0:
+            continue
         print(" --", sel_name, len(tt))
         used = [i for i in range(1, 15) if (tt[:, i] > 0).mean() > 0.3]
         for a, b in zip(used[:-1], used[1:]):
             ok = (tt[:, a] > 0) & (tt[:, b] > 0)
             dlt = (tt[:, b] - tt[:, a])[ok]
+            if len(dlt) == 0:
+                continue
             print("  stamp %2d -> %2d  %-40s median %6.0f ticks (%.2f us)  p90 %6.0f" % (a, b, names.get((a, b), ""), np.median(dlt), np.median(dlt) / 2.2e3, np.percentile(dlt, 90)))
 
 timeline(4, "bf fwd", {(1, 2): "issue frag + K/V staging", (2, 3): "barrier", (3, 4): "scores (tile 0)", (4, 5): "softmax, mask/dropout", (5, 6): "A V", (6, 7): "store"})
