@@ -34,7 +34,7 @@
 #include "cr_bf16.hpp"
 
 #define BF_CH 256                 // rows of one LDS chunk (K/V rows in the query-owner kernels, Q/dOut rows in the key-owner one)
-#define BF_IMG (BF_CH * 64)       // bf16 elements of one image
+#define BF_IMG (BF_CH * 32 * NKS) // bf16 elements of one image (inside a kernel templated on NKS)
 
 struct BfGeom {
     int T16, nkt;                 // padded T, 16-row tiles
@@ -126,7 +126,7 @@ __device__ __forceinline__ void stage_pair_bf(__bf16* ah, __bf16* al, const floa
                 const int t = crow0 + r;
                 const bool rok = t < T;
                 const bool fix = wg_has_last && item_fix(rok, t == T - 1, 8 * ch, d);
-                const int o = img_off(r, ch);
+                const int o = img_off<NKS>(r, ch);
                 bf8 h, l;
                 item_mask(va[u], 8 * ch, d, rok, fix);
                 item_mask(vb[u], 8 * ch, d, rok, fix);
@@ -182,10 +182,10 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
     constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* Kl = Kh + (SPLIT ? g.T16 * 64 : 0);
-    __bf16* Vh = Kl + g.T16 * 64;
-    __bf16* Vl = Vh + (SPLIT ? g.T16 * 64 : 0);
-    float* kb = reinterpret_cast<float*>(Vl + g.T16 * 64);   // [T16] additive key bias
+    __bf16* Kl = Kh + (SPLIT ? g.T16 * (32 * NKS) : 0);
+    __bf16* Vh = Kl + g.T16 * (32 * NKS);
+    __bf16* Vl = Vh + (SPLIT ? g.T16 * (32 * NKS) : 0);
+    float* kb = reinterpret_cast<float*>(Vl + g.T16 * (32 * NKS));   // [T16] additive key bias
     const int nw = blockDim.x >> 6;
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
                 bf8 k0h[NKS], k0l[NKS], k1h[NKS], k1l[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    k0h[ks] = row_frag(Kh, r0, ks); k1h[ks] = row_frag(Kh, r1, ks);
-                    k0l[ks] = SPLIT ? row_frag(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag(Kl, r1, ks) : k1h[ks];
+                    k0h[ks] = row_frag<NKS>(Kh, r0, ks); k1h[ks] = row_frag<NKS>(Kh, r1, ks);
+                    k0l[ks] = SPLIT ? row_frag<NKS>(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag<NKS>(Kl, r1, ks) : k1h[ks];
                 }
                 f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
 #pragma unroll
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(512) void k_bf_fwd(cr_attn_desc d, BfGeom g) {
                     bf8 bh[JB], bl[JB];
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        bh[jt] = tr_frag(Vh, ra, rb, j0 + jt);
-                        bl[jt] = SPLIT ? tr_frag(Vl, ra, rb, j0 + jt) : bh[jt];
+                        bh[jt] = tr_frag<NKS>(Vh, ra, rb, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag<NKS>(Vl, ra, rb, j0 + jt) : bh[jt];
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) acc[j0 + jt] = mma<SPLIT>(ph, pl, bh[jt], bl[jt], acc[j0 + jt]);
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(512) void k_bf_fwd_long(cr_attn_desc d, BfGeom g) {
                 bf8 k0h[NKS], k0l[NKS], k1h[NKS], k1l[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    k0h[ks] = row_frag(Kh, r0, ks); k1h[ks] = row_frag(Kh, r1, ks);
-                    k0l[ks] = SPLIT ? row_frag(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag(Kl, r1, ks) : k1h[ks];
+                    k0h[ks] = row_frag<NKS>(Kh, r0, ks); k1h[ks] = row_frag<NKS>(Kh, r1, ks);
+                    k0l[ks] = SPLIT ? row_frag<NKS>(Kl, r0, ks) : k0h[ks]; k1l[ks] = SPLIT ? row_frag<NKS>(Kl, r1, ks) : k1h[ks];
                 }
                 f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
 #pragma unroll
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(512) void k_bf_fwd_long(cr_attn_desc d, BfGeom g) {
                     bf8 bh[JB], bl[JB];
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        bh[jt] = tr_frag(Vh, ra, rb, j0 + jt);
-                        bl[jt] = SPLIT ? tr_frag(Vl, ra, rb, j0 + jt) : bh[jt];
+                        bh[jt] = tr_frag<NKS>(Vh, ra, rb, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag<NKS>(Vl, ra, rb, j0 + jt) : bh[jt];
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) acc[j0 + jt] = mma<SPLIT>(ph, pl, bh[jt], bl[jt], acc[j0 + jt]);
@@ -596,10 +596,10 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* Kl = Kh + (SPLIT ? g.ch_rows * 64 : 0);
-    __bf16* Vh = Kl + g.ch_rows * 64;
-    __bf16* Vl = Vh + (SPLIT ? g.ch_rows * 64 : 0);
-    float* kb = reinterpret_cast<float*>(Vl + g.ch_rows * 64);   // [ch_rows]
+    __bf16* Kl = Kh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
+    __bf16* Vh = Kl + g.ch_rows * (32 * NKS);
+    __bf16* Vl = Vh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
+    float* kb = reinterpret_cast<float*>(Vl + g.ch_rows * (32 * NKS));   // [ch_rows]
     const int nw = blockDim.x >> 6;
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
@@ -719,8 +719,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        a0h[ks] = row_frag(Kh, 16 * l0, ks); a1h[ks] = row_frag(Kh, 16 * l1, ks);
-                        a0l[ks] = SPLIT ? row_frag(Kl, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag(Kl, 16 * l1, ks) : a1h[ks];
+                        a0h[ks] = row_frag<NKS>(Kh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Kh, 16 * l1, ks);
+                        a0l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l1, ks) : a1h[ks];
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -734,8 +734,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 v0h[NKS], v0l[NKS], v1h[NKS], v1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        v0h[ks] = row_frag(Vh, 16 * l0, ks); v1h[ks] = row_frag(Vh, 16 * l1, ks);
-                        v0l[ks] = SPLIT ? row_frag(Vl, 16 * l0, ks) : v0h[ks]; v1l[ks] = SPLIT ? row_frag(Vl, 16 * l1, ks) : v1h[ks];
+                        v0h[ks] = row_frag<NKS>(Vh, 16 * l0, ks); v1h[ks] = row_frag<NKS>(Vh, 16 * l1, ks);
+                        v0l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l0, ks) : v0h[ks]; v1l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l1, ks) : v1h[ks];
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -749,8 +749,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                 bf8 bh[JB], bl[JB];
 #pragma unroll
                 for (int jt = 0; jt < JB; ++jt) {
-                    bh[jt] = tr_frag(Kh, 16 * l0, 16 * l1, jt);
-                    bl[jt] = SPLIT ? tr_frag(Kl, 16 * l0, 16 * l1, jt) : bh[jt];
+                    bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, jt);
+                    bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, jt) : bh[jt];
                 }
                 float x[8];
                 auto finish = [&](int kt, int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
@@ -777,8 +777,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = JB; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        bh[jt] = tr_frag(Kh, 16 * l0, 16 * l1, j0 + jt);
-                        bl[jt] = SPLIT ? tr_frag(Kl, 16 * l0, 16 * l1, j0 + jt) : bh[jt];
+                        bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, j0 + jt);
+                        bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, j0 + jt) : bh[jt];
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(ah, al, bh[jt], bl[jt], dq[j0 + jt]);
@@ -811,13 +811,13 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Qh = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* Ql = Qh + (SPLIT ? g.ch_rows * 64 : 0);
-    __bf16* Oh = Ql + g.ch_rows * 64;
-    __bf16* Ol = Oh + (SPLIT ? g.ch_rows * 64 : 0);
+    __bf16* Ql = Qh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
+    __bf16* Oh = Ql + g.ch_rows * (32 * NKS);
+    __bf16* Ol = Oh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
     // per-row statistics of the staged query chunk, stored so that the inner loop is branch-free:
     //   A[q][key] = valid * exp2(s c - smx) * sinv + (key < T ? suni : 0); normal row: suni = 0; uniform row: sinv = 0,
     //   suni = 1/T; dead row: both 0 (smx = 1e30 wherever sinv = 0: the exponential is exactly 0, never inf * 0)
-    float* smx = reinterpret_cast<float*>(Ol + g.ch_rows * 64);          // [ch_rows] each
+    float* smx = reinterpret_cast<float*>(Ol + g.ch_rows * (32 * NKS));          // [ch_rows] each
     float* sinv = smx + g.ch_rows;
     float* sdel = sinv + g.ch_rows;
     float* suni = sdel + g.ch_rows;
@@ -943,8 +943,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        a0h[ks] = row_frag(Qh, 16 * l0, ks); a1h[ks] = row_frag(Qh, 16 * l1, ks);
-                        a0l[ks] = SPLIT ? row_frag(Ql, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag(Ql, 16 * l1, ks) : a1h[ks];
+                        a0h[ks] = row_frag<NKS>(Qh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Qh, 16 * l1, ks);
+                        a0l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l1, ks) : a1h[ks];
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -958,8 +958,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 o0h[NKS], o0l[NKS], o1h[NKS], o1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        o0h[ks] = row_frag(Oh, 16 * l0, ks); o1h[ks] = row_frag(Oh, 16 * l1, ks);
-                        o0l[ks] = SPLIT ? row_frag(Ol, 16 * l0, ks) : o0h[ks]; o1l[ks] = SPLIT ? row_frag(Ol, 16 * l1, ks) : o1h[ks];
+                        o0h[ks] = row_frag<NKS>(Oh, 16 * l0, ks); o1h[ks] = row_frag<NKS>(Oh, 16 * l1, ks);
+                        o0l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l0, ks) : o0h[ks]; o1l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l1, ks) : o1h[ks];
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -973,8 +973,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 bf8 oth[JB], otl[JB];
 #pragma unroll
                 for (int jt = 0; jt < JB; ++jt) {
-                    oth[jt] = tr_frag(Oh, 16 * l0, 16 * l1, jt);
-                    otl[jt] = SPLIT ? tr_frag(Ol, 16 * l0, 16 * l1, jt) : oth[jt];
+                    oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, jt);
+                    otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, jt) : oth[jt];
                 }
                 float xa[8], xd[8];
                 auto finish = [&](int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
@@ -1010,8 +1010,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = JB; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        oth[jt] = tr_frag(Oh, 16 * l0, 16 * l1, j0 + jt);
-                        otl[jt] = SPLIT ? tr_frag(Ol, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, j0 + jt);
+                        otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(ah, al, oth[jt], otl[jt], dv[j0 + jt]);
@@ -1022,8 +1022,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = 0; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        oth[jt] = tr_frag(Qh, 16 * l0, 16 * l1, j0 + jt);
-                        otl[jt] = SPLIT ? tr_frag(Ql, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        oth[jt] = tr_frag<NKS>(Qh, 16 * l0, 16 * l1, j0 + jt);
+                        otl[jt] = SPLIT ? tr_frag<NKS>(Ql, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(dh, dl, oth[jt], otl[jt], dk[j0 + jt]);   // dK += dS^T Q
@@ -1103,7 +1103,7 @@ static int launch_bf_fwd(const cr_attn_desc* d, const BfGeom& g, hipStream_t s) 
     static cr_devmask attr_set = 0;
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_fwd<NKT, NKS, SPLIT>), &attr_set);
     if (rc) return rc;
-    const size_t lds = (size_t)g.T16 * 128 * 2 * (SPLIT ? 2 : 1) + (size_t)g.T16 * 4;
+    const size_t lds = (size_t)g.T16 * (64 * NKS) * 2 * (SPLIT ? 2 : 1) + (size_t)g.T16 * 4;
     BfGeom gg = g;
     if (g_attn_ts_which == 4) gg.ts = g_attn_ts;
     hipLaunchKernelGGL((k_bf_fwd<NKT, NKS, SPLIT>), dim3(d->B * d->H, bf_nsplit(d, g)), dim3(512), lds, s, *d, gg);
@@ -1122,7 +1122,7 @@ static int launch_bf_fwd_long(const cr_attn_desc* d, const BfGeom& g, hipStream_
     static cr_devmask attr_set = 0;
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_fwd_long<NKS, SPLIT>), &attr_set);
     if (rc) return rc;
-    const size_t lds = (size_t)BF_CH * 128 * 2 * (SPLIT ? 2 : 1) + (size_t)BF_CH * 4;
+    const size_t lds = (size_t)BF_CH * (64 * NKS) * 2 * (SPLIT ? 2 : 1) + (size_t)BF_CH * 4;
     hipLaunchKernelGGL((k_bf_fwd_long<NKS, SPLIT>), dim3(d->B * d->H, bf_nsplit(d, g)), dim3(512), lds, s, *d, g);
     return cr_check_launch("cr_attn_fwd(bf16, long)");
 }
@@ -1150,7 +1150,7 @@ static int launch_bf_bwd(const cr_attn_bwd_desc* bd, const BfGeom& g, hipStream_
     rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_bf_bwd_k<NKS, SPLIT, MULTI>), &attr_k);
     if (rc) return rc;
     const cr_attn_desc* d = &bd->f;
-    const size_t img = (size_t)g.ch_rows * 128 * 2 * (SPLIT ? 2 : 1);
+    const size_t img = (size_t)g.ch_rows * (64 * NKS) * 2 * (SPLIT ? 2 : 1);
     const dim3 grid(d->B * d->H, bf_nsplit(d, g));
     float* dws = bd->stats;                                              // delta workspace [H*B*T] when the caller gave none
     if (!MULTI && bd->delta && !g_bf_two_kernels) {

@@ -14,21 +14,28 @@ typedef __attribute__((address_space(3))) bf4 lds_bf4;
 #define BF_SGB(mask, n, id) do { } while (0)
 #endif
 
-// element offset of 16-byte chunk `ch` (0..7) of row `row`
-__device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + ((ch ^ (row & 6)) << 3); }
+// Element offset of 16-byte chunk `ch` of row `row` in an image of 32 * NKS columns (NKS = 2: 128-byte rows, 8 chunks,
+// chunk ^ (row & 6); NKS = 1: 64-byte rows, 4 chunks, chunk ^ ((row & 4) >> 1)).  Both maps are conflict-free for the row
+// reads and for the transposed reads (tools/lds_banks.py: brute force over the XOR-linear maps).
+template <int NKS = 2>
+__device__ __forceinline__ int img_off(int row, int ch) {
+    return NKS == 2 ? row * 64 + ((ch ^ (row & 6)) << 3) : row * 32 + ((ch ^ ((row & 4) >> 1)) << 3);
+}
 
 // A / B operand with k = head dim: row `row0 + li`, columns 32 ks + 8 lg .. + 7
+template <int NKS = 2>
 __device__ __forceinline__ bf8 row_frag(const __bf16* img, int row0, int ks) {
     const int lane = threadIdx.x & 63;
-    return *reinterpret_cast<const bf8*>(img + img_off(row0 + (lane & 15), (lane >> 4) + 4 * ks));
+    return *reinterpret_cast<const bf8*>(img + img_off<NKS>(row0 + (lane & 15), (lane >> 4) + 4 * ks));
 }
 
 // B operand with k = row: k index 8 lg + j <-> row (j < 4 ? ra : rb) + 4 lg + (j & 3), output column 16 jt + li
+template <int NKS = 2>
 __device__ __forceinline__ bf8 tr_frag(const __bf16* img, int ra, int rb, int jt) {
     const int lane = threadIdx.x & 63, lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
     const int ch = 2 * jt + (p >> 1), sub = 4 * (p & 1);
-    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off(ra + 4 * lg + q, ch) + sub));
-    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off(rb + 4 * lg + q, ch) + sub));
+    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<NKS>(ra + 4 * lg + q, ch) + sub));
+    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<NKS>(rb + 4 * lg + q, ch) + sub));
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 

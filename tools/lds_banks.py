@@ -1,47 +1,56 @@
-"""Brute-force search of the LDS swizzle used by csrc/cr_attn_bf.hip: XOR-linear maps of (row & 15) onto the 16-byte chunk index
-of a [rows][64] bf16 image, scored with the bank rules of MI355X_MICROARCH.md (ds_read_b128: 4 groups of 16 lanes, 64 banks;
-ds_read_b64_tr_b16: 2 groups of 32 lanes) for the row reads and the transposed reads.  Prints the best maps: (0, 2, 4) = chunk ^ (row & 6)
-is conflict-free on both."""
+"""Brute-force search of the LDS swizzles used by csrc/cr_bf16.hpp: XOR-linear maps of (row & 15) onto the 16-byte chunk index
+of a [rows][64] (128-byte rows) or [rows][32] (64-byte rows) bf16 image, scored with the bank rules of MI355X_MICROARCH.md
+(ds_read_b128: 4 groups of 16 lanes, 64 banks of 4 bytes; ds_read_b64_tr_b16: 2 groups of 32 lanes) for the row reads (A / B
+operand with k = head dim) and the transposed reads (operand with k = row).
+Best maps: 128-byte rows (0, 2, 4) = chunk ^ (row & 6); 64-byte rows (0, 4) = chunk ^ ((row & 4) >> 1): conflict-free on both."""
 import itertools
-G128 = [list(range(0,4))+list(range(12,16))+list(range(20,28)), list(range(4,12))+list(range(16,20))+list(range(28,32)),
-        list(range(32,36))+list(range(44,48))+list(range(52,60)), list(range(36,44))+list(range(48,52))+list(range(60,64))]
-G64 = [list(range(0,32)), list(range(32,64))]
+
+G128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+        list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+G64 = [list(range(0, 32)), list(range(32, 64))]
+
+
 def cycles(addrs, width, groups, nb=64):
+    """LDS cycles of one wave instruction: per lane group, the largest number of distinct dwords on one bank."""
     tot = 0
     for g in groups:
         banks = {}
         for l in g:
-            a = addrs[l]
             for w in range(width // 4):
-                dw = a // 4 + w
+                dw = addrs[l] // 4 + w
                 banks.setdefault(dw % nb, set()).add(dw)
         tot += max(len(s) for s in banks.values())
     return tot
-def make_g(mat):  # mat: 3 rows of 4-bit masks
+
+
+def xor_map(mat):
     def g(row):
-        r = row & 15
-        v = 0
-        for b in range(3):
-            v |= (bin(r & mat[b]).count("1") & 1) << b
+        r, v = row & 15, 0
+        for b, m in enumerate(mat):
+            v |= (bin(r & m).count("1") & 1) << b
         return v
     return g
-def off(row, ch, g, pitch=128): return row * pitch + ((ch ^ g(row)) * 16)
-best = []
-for mat in itertools.product(range(16), repeat=3):
-    g = make_g(mat)
-    worstR = 0
-    for ks in range(2):
-        addrs = [off((l & 15), (l >> 4) + 4 * ks, g) for l in range(64)]
-        worstR = max(worstR, cycles(addrs, 16, G128))
-    worstT = 0
-    for jt in range(4):
-        addrs = []
-        for l in range(64):
-            kg, idx = l >> 4, l & 15
-            q, p = idx >> 2, idx & 3
-            row = 4 * kg + q
-            addrs.append(off(row, 2 * jt + (p >> 1), g) + 8 * (p & 1))
-        worstT = max(worstT, cycles(addrs, 8, G64))
-    best.append((worstR + 2 * worstT, worstR, worstT, mat))
-best.sort()
-print(best[:10])
+
+
+def search(pitch, nbits, ksteps, ntiles):
+    best = []
+    for mat in itertools.product(range(16), repeat=nbits):
+        g = xor_map(mat)
+        off = lambda row, ch: row * pitch + ((ch ^ g(row)) * 16)
+        worst_r = max(cycles([off(l & 15, (l >> 4) + 4 * ks) for l in range(64)], 16, G128) for ks in range(ksteps))
+        worst_t = 0
+        for jt in range(ntiles):
+            addrs = []
+            for l in range(64):
+                kg, idx = l >> 4, l & 15
+                q, p = idx >> 2, idx & 3
+                addrs.append(off(4 * kg + q, 2 * jt + (p >> 1)) + 8 * (p & 1))
+            worst_t = max(worst_t, cycles(addrs, 8, G64))
+        best.append((worst_r + 2 * worst_t, worst_r, worst_t, mat))
+    best.sort()
+    return best
+
+
+if __name__ == "__main__":
+    print("128-byte rows (score, row-read cycles [min 4], transposed-read cycles [min 2], map):", search(128, 3, 2, 4)[:4])
+    print(" 64-byte rows:", search(64, 2, 1, 2)[:4])
