@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the C5-table gather block (allocates 10.24 GB)")
     ap.add_argument("--no-extra-precisions", action="store_true", help="skip the short runs in the other attention precisions")
+    ap.add_argument("--corpus", default="ml-1m", choices=["ml-1m", "beauty", "books", "c5"],
+                    help="synthetic corpus preset (castrec_amd/synth.py); the headline line is ml-1m")
+    ap.add_argument("--lazy_adam", action="store_true", help="row-sparse Adam on the item table (a deviation, DESIGN.md section 8)")
     ap.add_argument("--sparse-exchange", default="auto", choices=["auto", "on", "off"], help="DP: item-table gradient exchange")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel HIP-event table here")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
@@ -358,7 +361,7 @@ def main():
 
     B, T = args.batch_size, args.maxlen
     Bg = B * world
-    corpus = synth.preset("ml-1m")
+    corpus = synth.preset(args.corpus)
     sargs = types.SimpleNamespace(seed=42, bin_in_hours=48, max_bins=200, log_scale=False)
     smp = WarpSampler(sargs, corpus, corpus.usernum, corpus.itemnum, batch_size=Bg, maxlen=T)
     NB = 16
@@ -372,7 +375,7 @@ def main():
 
     def run(precision, steps, warmup):
         eng = E.Engine(args.model, corpus.usernum, corpus.itemnum, hyper(args), B, training=True, n_slabs=args.n_slabs,
-                       batch_global=Bg, row_offset=rank * B * T, attn_precision=precision)
+                       batch_global=Bg, row_offset=rank * B * T, attn_precision=precision, lazy_adam=args.lazy_adam)
         dp = None
         if dist is not None:
             rep = D_.EngineReplica(eng, use_graph=False)
@@ -461,9 +464,10 @@ def main():
         if args.profile_json:
             with open(args.profile_json, "w") as f:
                 json.dump(dict(per_launch=per_launch, by_name=by_name, n_launches=eng.n_launches()), f, indent=1, default=str)
-        cfg = {"workload": "ml-1m-shaped synthetic (6040 users, 3416 items), %s maxlen=%d hidden_units=%d num_blocks=%d "
-                           "num_heads=%d dropout=%.2f, batch %d/GPU (global %d), fwd+bwd+dense TF-Adam per step"
-                           % (args.model, T, args.hidden_units, args.num_blocks, args.num_heads, args.dropout_rate, B, Bg),
+        cfg = {"workload": "%s-shaped synthetic (%d users, %d items), %s maxlen=%d hidden_units=%d num_blocks=%d "
+                           "num_heads=%d dropout=%.2f, batch %d/GPU (global %d), fwd+bwd+%s TF-Adam per step"
+                           % (args.corpus, corpus.usernum, corpus.itemnum, args.model, T, args.hidden_units, args.num_blocks, args.num_heads,
+                              args.dropout_rate, B, Bg, "row-sparse (lazy)" if args.lazy_adam else "dense"),
                "parallelism": "dp%d" % world, "hip_graph": use_graph, "launches_per_step": eng.n_launches(),
                "attn_precision": prec, "final_loss": round(loss, 5), "final_auc": round(auc, 5)}
         if dist is not None:

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int 
     const float inv_n = n > 0.0f ? 1.0f / n : 0.0f;
     const float b1t = powf(d.beta1, (float)t), b2t = powf(d.beta2, (float)t);
     const float lr_t = d.lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
-    auto update = [&](int i, float g) {
+    auto update = [&](long long i, float g) {
         g *= inv_n;
         if (i < d.n_l2) g = fmaf(d.l2, d.p[i], g);       // d/dp of l2 * sum(p^2) / 2 on the lookup tables (modules.py:153)
         const float m = d.beta1 * d.m[i] + (1.0f - d.beta1) * g;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int 
             mine = __shfl(mine, 0, 64);
             if (!mine) continue;
             for (int c = lane; c < d.lazy_D; c += 64) {
-                const int i = id * d.lazy_D + c;
+                const long long i = (long long)id * d.lazy_D + c;
                 const float g = d.table_grad[i];
                 d.table_grad[i] = 0.0f;
                 update(i, g);
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int 
         }
     } else {
         const int nb_table = gridDim.x - nb_dense - nb_lazy;
-        const int first = nb_lazy > 0 ? d.lazy_rows * d.lazy_D : 0;          // the lazy part of the table section is not swept
-        for (int i = first + ((int)blockIdx.x - nb_dense - nb_lazy) * 256 + threadIdx.x; i < d.n_table; i += nb_table * 256) {
+        const long long first = nb_lazy > 0 ? (long long)d.lazy_rows * d.lazy_D : 0;   // the lazy part of the table section is not swept
+        for (long long i = first + (long long)((int)blockIdx.x - nb_dense - nb_lazy) * 256 + threadIdx.x; i < d.n_table; i += (long long)nb_table * 256) {
             const float g = d.table_grad[i];
             d.table_grad[i] = 0.0f;
             update(i, g);
@@ -110,26 +110,26 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     CR_REQUIRE(d->n_dense == 0 || (d->dense_slabs && d->n_slabs > 0), "cr_adam_step: dense_slabs missing");
     CR_REQUIRE(d->step_snapshot == nullptr || d->stats != nullptr, "cr_adam_step: step_snapshot needs stats (a copy of the sums that does not alias state[0..2])");
     const int nb_dense = cr_ceil_div(d->n_dense, 64);
-    int nb_lazy = 0, n_swept = d->n_table;
+    int nb_lazy = 0;
+    long long n_swept = d->n_table;
     if (d->lazy_ids) {
         CR_REQUIRE(d->lazy_flags && d->n_lazy_ids > 0 && d->lazy_rows > 0 && d->lazy_D > 0 &&
                    (long long)d->lazy_rows * d->lazy_D <= d->n_table, "cr_adam_step: bad lazy-row arguments");
         nb_lazy = cr_ceil_div(d->n_lazy_ids, 4 * 8);                      // ~8 ids per wave
         if (nb_lazy > 4096) nb_lazy = 4096;
-        n_swept = d->n_table - d->lazy_rows * d->lazy_D;
+        n_swept = d->n_table - (long long)d->lazy_rows * d->lazy_D;
     }
-    int nb_table = cr_ceil_div(n_swept, 256);
-    if (nb_table > 2048) nb_table = 2048;
+    int nb_table = (int)((n_swept + 255) / 256 > 2048 ? 2048 : (n_swept + 255) / 256);
     if (nb_table < 1) nb_table = 1;
     hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table), dim3(256), 0, cr_stream(stream), *d, nb_dense, nb_lazy);
     return cr_check_launch("cr_adam_step");
 }
 
 // l2 * sum(p^2) / 2 over the lookup tables: ONE workgroup, per-thread strided partial sums, then a fixed-order tree
-__global__ __launch_bounds__(1024) void k_l2_penalty(const float* p, int n, float scale, float* state) {
+__global__ __launch_bounds__(1024) void k_l2_penalty(const float* p, long long n, float scale, float* state) {
     __shared__ float red[1024];
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 1024) acc = fmaf(p[i], p[i], acc);
+    for (long long i = threadIdx.x; i < n; i += 1024) acc = fmaf(p[i], p[i], acc);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_l2_penalty(const float* p, int n, floa
     if (threadIdx.x == 0) state[7] = scale * red[0];
 }
 
-extern "C" int cr_l2_penalty(const float* p, int n, float scale, float* state, void* stream) {
+extern "C" int cr_l2_penalty(const float* p, int64_t n, float scale, float* state, void* stream) {
     CR_REQUIRE(p && state && n > 0, "cr_l2_penalty: bad arguments");
     hipLaunchKernelGGL(k_l2_penalty, dim3(1), dim3(1024), 0, cr_stream(stream), p, n, scale, state);
     return cr_check_launch("cr_l2_penalty");

@@ -47,6 +47,10 @@ PRESETS = {
     "ml-1m":  (6040, 3416, 4.6, 0.9, 2300, 0.8, 42),      # C1 / C2
     "beauty": (52000, 57289, 2.0, 0.6, 200, 1.1, 43),     # C3 (long tail)
     "books":  (600000, 368000, 2.3, 0.9, 2000, 1.0, 44),  # C4
+    # C5 item side at full size (10 M items, Zipf 1.05, half of the users longer than 512 events); the user count is cut
+    # from 10^6 to 4 000 -- the sampler draws users uniformly, so a step's work does not depend on it -- and a user's items
+    # may repeat (drawing 10^3 distinct ids per user from a 10^7-entry CDF in Python is what would take the time)
+    "c5":     (4000, 10_000_000, 6.25, 0.6, 1500, 1.05, 45),
 }
 
 
@@ -88,7 +92,7 @@ def make_corpus(n_users, n_items, mu, sigma, lmax, alpha, seed, lmin=3,
 
 def preset(name):
     n_users, n_items, mu, sigma, lmax, alpha, seed = PRESETS[name]
-    return make_corpus(n_users, n_items, mu, sigma, lmax, alpha, seed)
+    return make_corpus(n_users, n_items, mu, sigma, lmax, alpha, seed, unique_items=(name != "c5"))
 
 
 def from_dict(corpus_dict, usernum, itemnum):

@@ -333,13 +333,14 @@ typedef struct {
     float* p; float* m; float* v;     /* flat [n_table + n_dense] */
     float* table_grad;                /* [n_table] */
     const float* dense_slabs;         /* [n_slabs, n_dense] */
-    int n_table, n_dense, n_slabs;
+    int64_t n_table;                  /* 64-bit: config C5's item table alone is 2.56e9 floats */
+    int n_dense, n_slabs;
     float lr, beta1, beta2, eps;
     float* state;
     const float* stats;               /* optional [3] */
     const uint32_t* step_snapshot;    /* optional: step number t is read from here instead of state[4], and the kernel
                                          ends the step: state[0..3] = 0, state[4] = t + 1 (see the state block above) */
-    float l2; int n_l2;               /* embedding regulariser (modules.py:149-153, sasrec.py:109-110): the first n_l2
+    float l2; int64_t n_l2;           /* embedding regulariser (modules.py:149-153, sasrec.py:109-110): the first n_l2
                                          parameters (the lookup tables: they lead the flat vector) get g += l2 * p, and
                                          the reported loss gets state[7] (written by cr_l2_penalty) added */
     /* Lazy (row-sparse) Adam for the leading item table -- a DEVIATION from the reference, off unless lazy_ids is set.
@@ -355,7 +356,7 @@ int cr_adam_step(const cr_adam_desc* d, void* stream);
 
 /* state[7] = scale * sum_{i < n} p[i]^2  (scale = l2 / 2): the regularisation term of the loss, fixed summation order.
  * Launched before cr_adam_step (which updates p) when l2_emb != 0; every shipped run of the reference uses 0. */
-int cr_l2_penalty(const float* p, int n, float scale, float* state, void* stream);
+int cr_l2_penalty(const float* p, int64_t n, float scale, float* state, void* stream);
 
 /* Data-parallel path: collapse the dense slabs into one flat vector that is all-reduced over RCCL
  * together with the table gradient: out[i] = sum_s slabs[s*n_dense + i]; also copies the three loss
