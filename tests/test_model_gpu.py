@@ -153,6 +153,7 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
         eng.set_step(step)
         eng.launch_step(apply=True)
         torch.cuda.synchronize()
+        prev = {k: v.clone() for k, v in P.items()}
         P = opt.step(P, G)
         now = eng.get_params()
         # Adam divides by sqrt(v): on the zero-gradient bk it amplifies rounding noise to O(lr) moves on
@@ -175,6 +176,22 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
         if prec != "bf16":                               # (plain bf16: small gradients may change sign, i.e. a whole +-lr step)
             assert worst_big[0] < 2e-5, worst_big
         assert worst_all[0] < 2.5 * lr, worst_all
+        if prec == "f32":
+            # smaller gradients too: wherever |g| > 1e-7 (ten times Adam's eps scale at step 1) the update must have the
+            # oracle's sign and at least a third of its size -- a wrong sign on a small-gradient element would pass the
+            # 2.5 * lr bound above
+            for k in P:
+                if k.endswith(".bk"):
+                    continue
+                # (from step 2 on the update follows the moments, not g: elements whose oracle update is itself below 5 % of
+                # a step are near a zero crossing of m and carry no sign information)
+                sel = (G[k].abs() > 1e-7) & ((P[k] - prev[k]).abs() > 0.05 * lr)
+                if not bool(sel.any()):
+                    continue
+                up_e = (now[k].cpu().double() - prev[k])[sel]
+                up_o = (P[k] - prev[k])[sel]
+                assert bool((torch.sign(up_e) == torch.sign(up_o)).all()), k
+                assert bool((up_e.abs() > up_o.abs() / 3).all()), k
         # continue from the engine's parameters so step 2 compares gradients at identical points (the allowed
         # 1e-4 Adam differences would otherwise show up as 1e-4 activation differences)
         for k in P:
