@@ -8,44 +8,49 @@
 
 #include "cr_common.hpp"
 
-// Sum of the gradient slabs for 64 consecutive dense parameters [j0, j0 + 64): 256 threads = 16 slab groups x
-// 16 lanes of 4 columns.  Group q adds slabs q, q+16, q+32, ... with all its 16-byte loads independent (the old
-// one-thread-per-parameter loop had < 1 wave per SIMD and 1.7 TB/s); the 16 group partials are then added in a
-// fixed order through LDS: bitwise reproducible.  Result: thread t < 64 returns the sum of column j0 + t.
+// Sum of the gradient slabs for ADAM_COLS = 256 consecutive dense parameters [j0, j0 + 256): wave w of the block's
+// ADAM_WAVES waves adds slabs w, w + 16, w + 32, ... -- each read is 1 KiB contiguous (16 bytes per lane; the first version
+// read 256-byte pieces of each slab from 16-lane groups and reached 2.5 TB/s) -- and the wave partials are added in a
+// fixed order through LDS: bitwise reproducible.  Result: thread t < 256 returns the sum of column j0 + t.
+#define ADAM_COLS 256
+#define ADAM_WAVES 16
 typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ float slab_sum64(const float* slabs, int n_slabs, int n_dense, int j0, float (*part)[64]) {
-    const int c4 = threadIdx.x & 15, q = threadIdx.x >> 4;
-    const int j = j0 + 4 * c4;
+__device__ __forceinline__ float slab_sum256(const float* slabs, int n_slabs, int n_dense, int j0, float (*part)[ADAM_COLS]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = j0 + 4 * lane;
     f4a acc = (f4a){0.f, 0.f, 0.f, 0.f};
     if (j + 3 < n_dense) {
-        int s = q;
-        for (; s + 7 * 16 < n_slabs; s += 8 * 16) {              // 8 independent 16-byte loads in flight
-            f4a v[8];
+        // every load of the wave's share is issued before the first add (n_slabs <= 256: at most 16 per wave): one
+        // memory round trip instead of one per batch of 8
+        for (int s0 = w; s0 < n_slabs; s0 += 16 * ADAM_WAVES) {
+            f4a v[16];
+            int cnt = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4a*>(slabs + (size_t)(s + 16 * u) * n_dense + j);
+            for (int u = 0; u < 16; ++u)
+                if (s0 + ADAM_WAVES * u < n_slabs) { v[u] = *reinterpret_cast<const f4a*>(slabs + (size_t)(s0 + ADAM_WAVES * u) * n_dense + j); cnt = u + 1; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 16; ++u)
+                if (u < cnt) acc += v[u];
         }
-        for (; s < n_slabs; s += 16) acc += *reinterpret_cast<const f4a*>(slabs + (size_t)s * n_dense + j);
     } else {
-        for (int s = q; s < n_slabs; s += 16)
+        for (int s = w; s < n_slabs; s += ADAM_WAVES)
             for (int u = 0; u < 4; ++u)
                 if (j + u < n_dense) acc[u] += slabs[(size_t)s * n_dense + j + u];
     }
-    part[q][4 * c4 + 0] = acc.x; part[q][4 * c4 + 1] = acc.y; part[q][4 * c4 + 2] = acc.z; part[q][4 * c4 + 3] = acc.w;
+    part[w][4 * lane + 0] = acc.x; part[w][4 * lane + 1] = acc.y; part[w][4 * lane + 2] = acc.z; part[w][4 * lane + 3] = acc.w;
     __syncthreads();
     float g = 0.0f;
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < ADAM_COLS) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) g += part[k][threadIdx.x];
+        for (int k = 0; k < ADAM_WAVES; ++k) g += part[k][threadIdx.x];
     }
     return g;
 }
 
-// blocks [0, nb_dense): 64 dense parameters each (slab reduction + update); then nb_lazy blocks (lazy item-table rows,
+// blocks [0, nb_dense): 256 dense parameters each (slab reduction + update); then nb_lazy blocks (lazy item-table rows,
 // one wave per listed id); the rest: table entries, grid-stride
-__global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy) {
-    __shared__ float part[16][64];
+__global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy) {
+    __shared__ float part[ADAM_WAVES][ADAM_COLS];
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
     const float* st = d.stats ? d.stats : d.state;
     const float n = st[2];
@@ -62,15 +67,15 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int 
         d.p[i] -= lr_t * m / (sqrtf(v) + d.eps);
     };
     if ((int)blockIdx.x < nb_dense) {
-        const int j0 = blockIdx.x * 64;
-        const float g = slab_sum64(d.dense_slabs, d.n_slabs, d.n_dense, j0, part);
-        if (threadIdx.x < 64 && j0 + (int)threadIdx.x < d.n_dense) update(d.n_table + j0 + threadIdx.x, g);
+        const int j0 = blockIdx.x * ADAM_COLS;
+        const float g = slab_sum256(d.dense_slabs, d.n_slabs, d.n_dense, j0, part);
+        if (threadIdx.x < ADAM_COLS && j0 + (int)threadIdx.x < d.n_dense) update(d.n_table + j0 + threadIdx.x, g);
     } else if ((int)blockIdx.x < nb_dense + nb_lazy) {
         // lazy rows: wave w of the lazy blocks walks ids w, w + W, ...; the first wave to swap the step number into a row's
         // flag owns the row (every other occurrence of the id finds it there and moves on)
         const int lane = threadIdx.x & 63;
-        const int W = nb_lazy * 4;
-        for (int k = ((int)blockIdx.x - nb_dense) * 4 + (threadIdx.x >> 6); k < d.n_lazy_ids; k += W) {
+        const int W = nb_lazy * ADAM_WAVES;
+        for (int k = ((int)blockIdx.x - nb_dense) * ADAM_WAVES + (threadIdx.x >> 6); k < d.n_lazy_ids; k += W) {
             const int id = d.lazy_ids[k];
             if (id <= 0 || id >= d.lazy_rows) continue;                       // row 0: the zero-pad row never has a gradient
             int mine = 0;
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(256) void k_adam(cr_adam_desc d, int nb_dense, int 
     } else {
         const int nb_table = gridDim.x - nb_dense - nb_lazy;
         const long long first = nb_lazy > 0 ? (long long)d.lazy_rows * d.lazy_D : 0;   // the lazy part of the table section is not swept
-        for (long long i = first + (long long)((int)blockIdx.x - nb_dense - nb_lazy) * 256 + threadIdx.x; i < d.n_table; i += (long long)nb_table * 256) {
+        constexpr int NT = 64 * ADAM_WAVES;
+        for (long long i = first + (long long)((int)blockIdx.x - nb_dense - nb_lazy) * NT + threadIdx.x; i < d.n_table; i += (long long)nb_table * NT) {
             const float g = d.table_grad[i];
             d.table_grad[i] = 0.0f;
             update(i, g);
@@ -109,19 +115,20 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     CR_REQUIRE(d->n_table == 0 || d->table_grad, "cr_adam_step: table_grad is NULL");
     CR_REQUIRE(d->n_dense == 0 || (d->dense_slabs && d->n_slabs > 0), "cr_adam_step: dense_slabs missing");
     CR_REQUIRE(d->step_snapshot == nullptr || d->stats != nullptr, "cr_adam_step: step_snapshot needs stats (a copy of the sums that does not alias state[0..2])");
-    const int nb_dense = cr_ceil_div(d->n_dense, 64);
+    const int nb_dense = cr_ceil_div(d->n_dense, ADAM_COLS);
     int nb_lazy = 0;
     long long n_swept = d->n_table;
     if (d->lazy_ids) {
         CR_REQUIRE(d->lazy_flags && d->n_lazy_ids > 0 && d->lazy_rows > 0 && d->lazy_D > 0 &&
                    (long long)d->lazy_rows * d->lazy_D <= d->n_table, "cr_adam_step: bad lazy-row arguments");
-        nb_lazy = cr_ceil_div(d->n_lazy_ids, 4 * 8);                      // ~8 ids per wave
+        nb_lazy = cr_ceil_div(d->n_lazy_ids, ADAM_WAVES * 8);             // ~8 ids per wave
         if (nb_lazy > 4096) nb_lazy = 4096;
         n_swept = d->n_table - (long long)d->lazy_rows * d->lazy_D;
     }
-    int nb_table = (int)((n_swept + 255) / 256 > 2048 ? 2048 : (n_swept + 255) / 256);
+    constexpr int NT = 64 * ADAM_WAVES;
+    int nb_table = (int)((n_swept + NT - 1) / NT > 1024 ? 1024 : (n_swept + NT - 1) / NT);
     if (nb_table < 1) nb_table = 1;
-    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table), dim3(256), 0, cr_stream(stream), *d, nb_dense, nb_lazy);
+    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table), dim3(NT), 0, cr_stream(stream), *d, nb_dense, nb_lazy);
     return cr_check_launch("cr_adam_step");
 }
 
@@ -145,12 +152,12 @@ extern "C" int cr_l2_penalty(const float* p, int64_t n, float scale, float* stat
     return cr_check_launch("cr_l2_penalty");
 }
 
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* slabs, int n_slabs, int n_dense, float* out,
+__global__ __launch_bounds__(64 * ADAM_WAVES) void k_reduce_slabs(const float* slabs, int n_slabs, int n_dense, float* out,
                                                       const float* state, float* stats_out) {
-    __shared__ float part[16][64];
-    const int j0 = blockIdx.x * 64;
-    const float g = slab_sum64(slabs, n_slabs, n_dense, j0, part);
-    if (threadIdx.x < 64 && j0 + (int)threadIdx.x < n_dense) out[j0 + threadIdx.x] = g;
+    __shared__ float part[ADAM_WAVES][ADAM_COLS];
+    const int j0 = blockIdx.x * ADAM_COLS;
+    const float g = slab_sum256(slabs, n_slabs, n_dense, j0, part);
+    if (threadIdx.x < ADAM_COLS && j0 + (int)threadIdx.x < n_dense) out[j0 + threadIdx.x] = g;
     if (blockIdx.x == 0 && threadIdx.x < 3 && stats_out) stats_out[threadIdx.x] = state[threadIdx.x];
 }
 
@@ -158,7 +165,7 @@ extern "C" int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dens
                                float* stats_out, void* stream) {
     CR_REQUIRE(dense_slabs && out && n_slabs > 0 && n_dense > 0, "cr_reduce_slabs: bad arguments");
     CR_REQUIRE(stats_out == nullptr || state != nullptr, "cr_reduce_slabs: state is NULL");
-    const int grid = cr_ceil_div(n_dense, 64);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid), dim3(256), 0, cr_stream(stream), dense_slabs, n_slabs, n_dense, out, state, stats_out);
+    const int grid = cr_ceil_div(n_dense, ADAM_COLS);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid), dim3(64 * ADAM_WAVES), 0, cr_stream(stream), dense_slabs, n_slabs, n_dense, out, state, stats_out);
     return cr_check_launch("cr_reduce_slabs");
 }
