@@ -4,7 +4,9 @@ logits -- for all eleven graphs, with and without dropout (the oracle is fed the
 counter-based generator).  Tolerance: 1e-3 is the north-star bound for fp32 forward logits.
   attn_precision "f32"    (exact fp32 MFMA everywhere): observed ~1e-6, asserted 2e-4 (relative)
   attn_precision "bf16x3" (attention products on bf16 MFMA, hi + lo split operands, the engine's default):
-                          observed ~1e-5, asserted 5e-4 on gradients / 2e-4 on activations -- inside the 1e-3 bound
+                          activations (the quantity the 1e-3 bound is stated on): observed ~1e-5, asserted 2e-4; gradients,
+                          against each parameter's own largest gradient: typically 1e-4, up to 9e-4 over 144 surveyed draws of
+                          the unfused dropout case (dense layers on the split form as well), asserted 2e-3
   attn_precision "bf16"   (plain bf16 attention operands; BASELINE.json configs[1] names bf16, the reference is fp32):
                           asserted 3e-2 on activations and the loss, 2e-1 of the gradient scale on gradients (score errors of
                           2^-8 |s| are exponentiated by the softmax): the throughput option, not a parity claim"""
@@ -66,7 +68,7 @@ CASES = [c + ("f32",) for c in CASES]
 # the bf16-MFMA attention kernels (csrc/cr_attn_bf.hip), fused and unfused row phases, one and two heads
 CASES += [("sasrec", 0.3, True, "bf16x3"), ("cast_1", 0.3, True, "bf16x3"), ("cast_5", 0.0, True, "bf16x3"), ("cast_9", 0.2, True, "bf16x3"),
           ("cast_1", 0.3, False, "bf16x3"), ("sasrec", 0.0, False, "bf16x3"), ("cast_1", 0.3, True, "bf16"), ("sasrec", 0.0, False, "bf16")]
-TOL = {"f32": dict(grad=2e-4, act=2e-5, loss=2e-5, auc=1e-6), "bf16x3": dict(grad=5e-4, act=2e-4, loss=2e-4, auc=1e-6),
+TOL = {"f32": dict(grad=2e-4, act=2e-5, loss=2e-5, auc=1e-6), "bf16x3": dict(grad=2e-3, act=2e-4, loss=2e-4, auc=1e-6),
        "bf16": dict(grad=2e-1, act=3e-2, loss=2e-2, auc=None)}
 
 
@@ -89,6 +91,9 @@ def engine_relu_gates(eng, B, T, drop):
     return gates
 
 
+SEED_SHIFT = 0          # tools: shift to survey other draws
+
+
 def worst_grad_error(got, G, prec):
     """(error, parameter name, threshold): largest element error of a parameter against that parameter's largest
     gradient (floored at 1e-3 of the global scale; plain bf16: against the global scale).  d loss / d bk == 0
@@ -105,7 +110,9 @@ def worst_grad_error(got, G, prec):
 @pytest.mark.parametrize("model,rate,fused,prec", CASES)
 def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
     tol = TOL[prec]
-    rs = np.random.RandomState(abs(hash(model)) % 1000 + int(rate * 100))
+    # (zlib.crc32, not hash(): str hashes are salted per process, which made this test draw different data in every run)
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(model.encode()) % 1000 + int(rate * 100) + SEED_SHIFT)
     B, T, D, H, itemnum, max_bins = 5, 24, 20, 2, 37, 12
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=rate, max_bins=max_bins,
                  num_context_blocks=1, lr=1e-3, seed=7)
