@@ -145,34 +145,6 @@ __device__ __forceinline__ void stage_pair_bf(__bf16* ah, __bf16* al, const floa
     }
 }
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// index of the first valid key of the sample (T if none): rows before it that are not known-dead are the
-// "uniform" rows of modules.py:227-244
-__device__ __forceinline__ int first_valid_key(const float* k_valid, int base_row, int T) {
-    const int lane = threadIdx.x & 63;
-    int f = T;
-    for (int t = lane; t < T; t += 64)
-        if (k_valid[base_row + t] != 0.0f) f = min(f, t);
-    return wave_min_i(f);
-}
-
-// the same from the additive key bias of a staged chunk (0 = valid), rows [0, n16): one 16-byte LDS read per lane
-__device__ __forceinline__ int first_valid_key_lds(const float* kb, int n16, int T) {
-    const int lane = threadIdx.x & 63;
-    int f = T;
-    if (4 * lane < n16) {
-        const float4 b = *reinterpret_cast<const float4*>(kb + 4 * lane);
-        const int i = b.x == 0.0f ? 0 : (b.y == 0.0f ? 1 : (b.z == 0.0f ? 2 : (b.w == 0.0f ? 3 : 1 << 20)));
-        f = min(T, 4 * lane + i);
-    }
-    return wave_min_i(f);
-}
-
 // =====================================================================================================
 // forward, T <= 256 (one chunk): the whole score row block of a query tile lives in registers
 // =====================================================================================================

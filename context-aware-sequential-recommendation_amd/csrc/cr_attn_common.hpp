@@ -56,13 +56,49 @@ static unsigned long long* const g_attn_ts = nullptr;
 static const int g_attn_ts_which = 0;
 #endif
 
-__device__ __forceinline__ float grp_max(float v) {   // over the 4 lanes that share (lane & 15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions over the 4 lanes that share (lane & 15): v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd
+// rows of 16 lanes with the even ones and the upper half of the wave with the lower -- two register-file instructions
+// instead of the LDS round trip (address arithmetic + ds_bpermute) __shfl_xor compiles to.
+typedef unsigned cr_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float grp_max(float v) {
+    cr_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 __device__ __forceinline__ float grp_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    cr_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// index of the first valid key of the sample (T if none): rows before it that are not known-dead are the
+// "uniform" rows of modules.py:227-244
+__device__ __forceinline__ int first_valid_key(const float* k_valid, int base_row, int T) {
+    const int lane = threadIdx.x & 63;
+    int f = T;
+    for (int t = lane; t < T; t += 64)
+        if (k_valid[base_row + t] != 0.0f) f = min(f, t);
+    return wave_min_i(f);
+}
+
+// the same from the additive key bias of a staged chunk (0 = valid), rows [0, n16): one 16-byte LDS read per lane
+__device__ __forceinline__ int first_valid_key_lds(const float* kb, int n16, int T) {
+    const int lane = threadIdx.x & 63;
+    int f = T;
+    if (4 * lane < n16) {
+        const float4 b = *reinterpret_cast<const float4*>(kb + 4 * lane);
+        const int i = b.x == 0.0f ? 0 : (b.y == 0.0f ? 1 : (b.z == 0.0f ? 2 : (b.w == 0.0f ? 3 : 1 << 20)));
+        f = min(T, 4 * lane + i);
+    }
+    return wave_min_i(f);
 }
 
 // dropout element index of attention_weights[(j*Bglobal + n), q, 0]

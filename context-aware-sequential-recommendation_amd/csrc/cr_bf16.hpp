@@ -48,13 +48,23 @@ __device__ __forceinline__ f32x4 mma(const bf8& ah, const bf8& al, const bf8& bh
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
 
+// hi = bf16(x), lo = bf16(x - hi), two elements at a time: v_cvt_pk_bf16_f32, the bf16 pair widened with a shift and a
+// mask, v_pk_add_f32, v_cvt_pk_bf16_f32 -- 2.5 instructions per element (the element-wise form compiled to 5)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 template <bool SPLIT>
 __device__ __forceinline__ void split8(const float (&x)[8], bf8& hi, bf8& lo) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        hi[j] = h;
-        if (SPLIT) lo[j] = (__bf16)(x[j] - (float)h);
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 v = {x[j], x[j + 1]};
+        const bf2 h = __builtin_convertvector(v, bf2);
+        hi[j] = h[0];
+        hi[j + 1] = h[1];
+        if (SPLIT) {
+            const bf2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), bf2);
+            lo[j] = l[0];
+            lo[j + 1] = l[1];
+        }
     }
 }
 

@@ -1,0 +1,687 @@
+// A whole transformer stack (sasrec.py:65-85: per block LN1 -> Q/K/V -> causal attention -> LN2 -> feed-forward,
+// then the final LayerNorm) forward in ONE launch, one workgroup per sequence.
+//
+// Why.  At the headline shape (T = 200, D = 50, B = 128) a block's row phases are 25 600 x 50 matrices: the separate
+// kernels (cr_block_ln_qkv_fwd, cr_attn_fwd, cr_block_ln_ffn_fwd) each run 15-30 us of which launch ramp, weight staging
+// and the first HBM round trip are the larger part -- ten launches per step forward.  Everything a sequence needs is
+// 200 rows: its K / V images (bf16 hi + lo, 104 KB) and one phase's weights (48 KB) fit the 160 KB LDS of a CU, and
+// all row-local work stays in the registers of the wave that owns the 16-row tile.
+//
+// Register layout R.  A wave owns 16-row tiles; lane (li = lane & 15, lg = lane >> 4) holds row li of the tile, columns
+// 16 ct + 4 lg + r (ct, r = 0..3) -- the D-operand layout of v_mfma_f32_16x16x32_bf16 for the TRANSPOSED product
+// out^T = W^T x^T:  A = W^T (out column = li, k = input column; two ds_read_b64_tr_b16 of the [in][out] weight image),
+// B = x^T (lane = row li, k-elements = its own registers: k index 8 lg + j <-> column 32 ks + 16 (j >> 2) + 4 lg + (j & 3)),
+// D[out column 16 ct + 4 lg + r][row li] -- again layout R.  So LayerNorm -> projection -> ... -> feed-forward chain
+// through registers with no transposition; the attention core takes Q the same way (B operand of S^T = K Q^T, the K
+// image stored in that k order), and its output product is formed as O^T = V^T P^T, which lands in layout R too.
+//
+// Every intermediate the backward kernels read (q_in, Q K V, row statistics, o, f_in, hid, y) is written to HBM as
+// before; tiles are re-read from there (L2) across the phase barriers, by the wave that wrote them.
+// Arithmetic: bf16 MFMA on split (hi + lo, three products) or plain bf16 operands, fp32 accumulation
+// (cr_attn_desc.precision of the blocks); element-wise work in fp32.  Counter-based dropout: same element indices as
+// the separate kernels, so the backward kernels regenerate the same masks.
+#include <math.h>
+#include <stdlib.h>
+
+#include "cr_attn_common.hpp"
+#include "cr_bf16.hpp"
+
+#define ST_WAVES 8
+#define ST_THREADS (64 * ST_WAVES)
+#define ST_WIMG 4096              // bf16 elements of one [64][64] weight image
+#define ST_NVEC 11                // zero-padded 64-float vectors: ln1 g b, bq bk bv, ln2 g b, b1 b2, lnf g b
+
+struct StackBlk { cr_block_desc bd; cr_attn_desc ad; };
+struct StackArgs {
+    int nb, T16, nkt;
+    float isd_log2e, invT;
+    const float* lnf_g; const float* lnf_b; float* out; int ld_out, col_out;
+    unsigned long long* ts;       // debug: per-wave phase stamps [B][8 waves][64] (tools/stack_ts.py); NULL in production
+    StackBlk blk[CR_STACK_MAX_BLOCKS];
+};
+
+#ifdef CR_TIMELINE
+#define SK_TS(slot)                                                                                          \
+    do {                                                                                                     \
+        if (a.ts && (threadIdx.x & 63) == 0)                                                                 \
+            a.ts[((size_t)blockIdx.x * ST_WAVES + (threadIdx.x >> 6)) * 64 + (slot)] =                       \
+                ((slot) == 0 || (slot) == 63) ? wall_clock64() : clock64();                                  \
+    } while (0)
+#else
+#define SK_TS(slot) do { } while (0)
+#endif
+
+// ---- layout R <-> rows of a dense [*, ld] matrix ----------------------------------------------------------
+// Whole 16-byte pieces are one load; the piece that crosses column D (D % 4 != 0) is read element by element with
+// clamped addresses and pieces beyond D read the window [D - 4, D) and are zeroed: no branches on the load side,
+// nothing outside the row is touched, and a lane uses only elements that r_store of the SAME lane wrote -- a tile
+// written earlier by this wave can be re-read without a barrier in between.
+struct RRaw { f4u v[4]; float p[3]; };
+// Thread / lane number the optimiser cannot hoist or share between uses: everything derived from it (column offsets, pad masks)
+// is then recomputed where it is used -- a few VALU ops -- instead of being kept live across the whole kernel (the
+// loop-invariant per-lane values of all helpers together spilled 160 registers).
+__device__ __forceinline__ int tid_now() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+__device__ __forceinline__ int lane_now() { return tid_now() & 63; }
+typedef uint32_t u32;
+// base: a wave-uniform pointer; off: the row's element offset (32 bits: the host checks M * D < 2^30)
+__device__ __forceinline__ void r_issue(RRaw& w, const float* base, u32 off, int D) {
+    const int lg = lane_now() >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) w.v[ct] = *reinterpret_cast<const f4u*>(base + (off + (u32)min(16 * ct + 4 * lg, D - 4)));
+    w.p[0] = w.p[1] = w.p[2] = 0.0f;
+    if (D & 3) {                                          // wave-uniform
+        const int cp = D & ~3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w.p[r] = base[off + (u32)min(cp + r, D - 1)];
+    }
+}
+__device__ __forceinline__ void r_finish(f32x4 (&x)[4], const RRaw& w, bool rok, int D) {
+    const int lg = lane_now() >> 4;
+    const int cp = D & ~3;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int c = 16 * ct + 4 * lg;
+        const bool part = c == cp;                        // the crossing piece (never true when D % 4 == 0: then cp == D)
+        x[ct][0] = (rok && c + 0 < D) ? (part ? w.p[0] : w.v[ct].x) : 0.0f;
+        x[ct][1] = (rok && c + 1 < D) ? (part ? w.p[1] : w.v[ct].y) : 0.0f;
+        x[ct][2] = (rok && c + 2 < D) ? (part ? w.p[2] : w.v[ct].z) : 0.0f;
+        x[ct][3] = (rok && c + 3 < D) ? w.v[ct].w : 0.0f;
+    }
+}
+__device__ __forceinline__ void r_store(float* base, u32 off, const f32x4 (&x)[4], bool rok, int D) {
+    const int lg = lane_now() >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int c = 16 * ct + 4 * lg;
+        if (rok && c < D) {
+            float* rowp = base + (off + (u32)c);
+            if (c + 4 <= D) {
+                *reinterpret_cast<f4u*>(rowp) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
+            } else {
+                rowp[0] = x[ct][0];
+                if (c + 1 < D) rowp[1] = x[ct][1];
+                if (c + 2 < D) rowp[2] = x[ct][2];
+            }
+        }
+    }
+}
+// a zero-padded 64-float LDS vector in layout R (the lane's 16 columns)
+__device__ __forceinline__ void r_vec(f32x4 (&v)[4], const float* vec) {
+    const int lg = lane_now() >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float4 t = *reinterpret_cast<const float4*>(vec + 16 * ct + 4 * lg);
+        v[ct] = (f32x4){t.x, t.y, t.z, t.w};
+    }
+}
+__device__ __forceinline__ float r_rowsum(const f32x4 (&x)[4]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) s += (x[ct][0] + x[ct][1]) + (x[ct][2] + x[ct][3]);
+    return grp_sum(s);
+}
+// LayerNorm of the lane's row (modules.py:74-78); gam / bet zero padded, so pad columns come out 0.
+// RECIP: y = g * (xc * (1 / sd)) + b (the block kernels' form), else g * (xc / sd) + b (cr_layernorm_fwd's)
+template <bool RECIP>
+__device__ __forceinline__ void r_layernorm(f32x4 (&y)[4], const f32x4 (&x)[4], const float* gam, const float* bet, int D) {
+    const int lg = lane_now() >> 4;
+    const float invD = 1.0f / (float)D;
+    const float mean = r_rowsum(x) * invD;
+    f32x4 xc[4];
+    float v = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xc[ct][r] = (16 * ct + 4 * lg + r < D) ? x[ct][r] - mean : 0.0f;
+            v = fmaf(xc[ct][r], xc[ct][r], v);
+        }
+    const float sd = sqrtf(grp_sum(v) * invD + 1e-8f);
+    const float rs = 1.0f / sd;
+    f32x4 g[4], b[4];
+    r_vec(g, gam);
+    r_vec(b, bet);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[ct][r] = RECIP ? fmaf(g[ct][r], xc[ct][r] * rs, b[ct][r]) : fmaf(g[ct][r], xc[ct][r] / sd, b[ct][r]);
+}
+
+// cr_bf16.hpp's operand reads with the lane number passed in (an opaque copy per tile iteration: the address sums of
+// one iteration's reads are then formed where they are used instead of being hoisted out of the tile loop -- 56 of
+// them -- and spilled)
+__device__ __forceinline__ bf8 row_frag_l(const __bf16* img, int row0, int ks, int lane) {
+    return *reinterpret_cast<const bf8*>(img + img_off<2>(row0 + (lane & 15), (lane >> 4) + 4 * ks));
+}
+__device__ __forceinline__ bf8 tr_frag_l(const __bf16* img, int ra, int rb, int jt, int lane) {
+    const int lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
+    const int ch = 2 * jt + (p >> 1), sub = 4 * (p & 1);
+    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<2>(ra + 4 * lg + q, ch) + sub));
+    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<2>(rb + 4 * lg + q, ch) + sub));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---- out^T = W^T x^T on the lane's row -------------------------------------------------------------------
+template <bool SPLIT>
+__device__ __forceinline__ void r_split(const f32x4 (&x)[4], bf8 (&h)[2], bf8 (&l)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const float v[8] = {x[2 * ks][0], x[2 * ks][1], x[2 * ks][2], x[2 * ks][3],
+                            x[2 * ks + 1][0], x[2 * ks + 1][1], x[2 * ks + 1][2], x[2 * ks + 1][3]};
+        split8<SPLIT>(v, h[ks], l[ks]);
+    }
+}
+// acc (layout R) = x W for the [in][out] image W (hi, lo).  Per k-step the four output-column tiles' fragments are
+// read as one batch; consecutive MFMAs then belong to four independent accumulators (no back-to-back dependency).
+template <bool SPLIT>
+__device__ __forceinline__ void r_gemm(f32x4 (&acc)[4], const __bf16* Wh, const __bf16* Wl, const bf8 (&xh)[2], const bf8 (&xl)[2]) {
+    const int lane = lane_now();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf8 wh[4], wl[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            wh[ct] = tr_frag_l(Wh, 32 * ks, 32 * ks + 16, ct, lane);
+            wl[ct] = SPLIT ? tr_frag_l(Wl, 32 * ks, 32 * ks + 16, ct, lane) : wh[ct];
+        }
+        if (SPLIT) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], xh[ks], acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], xl[ks], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], xh[ks], acc[ct], 0, 0, 0);
+    }
+}
+
+// ---- NWT weights [D][D] (row pitch ld, column offset c0) -> [64][64] images in consecutive slots -----------
+// 512 items (row k, 16-byte chunk) per weight, spread over the NT threads of the workgroup; issue and put are apart
+// so the loads fly across a barrier.
+struct WSrc { const float* p; int ld, c0; };
+template <int NWT, int NT> struct WRegs { float v[(NWT * 512 + NT - 1) / NT][8]; };
+// (scalars, not an array of sources: an indexed array of them ended up in scratch memory)
+#define W3_PARAMS const float* p0, int ld0, int c00, const float* p1, int ld1, int c01, const float* p2, int ld2, int c02
+#define W3_ARGS p0, ld0, c00, p1, ld1, c01, p2, ld2, c02
+__device__ __forceinline__ WSrc w_pick(int wi, W3_PARAMS) {
+    WSrc s;
+    s.p = wi == 0 ? p0 : (wi == 1 ? p1 : p2);
+    s.ld = wi == 0 ? ld0 : (wi == 1 ? ld1 : ld2);
+    s.c0 = wi == 0 ? c00 : (wi == 1 ? c01 : c02);
+    return s;
+}
+template <int NWT, int NT>
+__device__ __forceinline__ void w_issue(WRegs<NWT, NT>& r, int D, W3_PARAMS) {
+#pragma unroll
+    for (int u = 0; u < (NWT * 512 + NT - 1) / NT; ++u) {
+        const int item = min(tid_now() + NT * u, NWT * 512 - 1);
+        const WSrc s = w_pick(item >> 9, W3_ARGS);          // wave-uniform
+        const int k = (item & 511) >> 3, ch = item & 7;
+        const bool rok = k < D;
+        item_issue(r.v[u], s.p + (size_t)(rok ? k : 0) * s.ld + s.c0, 8 * ch, D, item_fix(rok, k == D - 1, 8 * ch, D));
+    }
+}
+template <int NWT, int NT, bool SPLIT>
+__device__ __forceinline__ void w_put(__bf16* Wi, WRegs<NWT, NT>& r, int D, W3_PARAMS) {
+    constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;
+#pragma unroll
+    for (int u = 0; u < (NWT * 512 + NT - 1) / NT; ++u) {
+        const int item = tid_now() + NT * u;
+        if (item < NWT * 512) {
+            const int wi = item >> 9, k = (item & 511) >> 3, ch = item & 7;
+            const bool rok = k < D;
+            const bool fix = item_fix(rok, k == D - 1, 8 * ch, D);
+            item_mask(r.v[u], 8 * ch, D, rok, fix);
+            if (__builtin_expect(fix, 0)) {                // one thread per weight
+                const WSrc s = w_pick(wi, W3_ARGS);
+                item_refill(r.v[u], s.p + (size_t)k * s.ld + s.c0, 8 * ch, D);
+            }
+            bf8 h, l;
+            split8<SPLIT>(r.v[u], h, l);
+            const int o = wi * WST + img_off<2>(k, ch);
+            *reinterpret_cast<bf8*>(Wi + o) = h;
+            if (SPLIT) *reinterpret_cast<bf8*>(Wi + o + ST_WIMG) = l;
+        }
+    }
+}
+// the block's zero-padded vectors (and the final LayerNorm's): ST_NVEC x 64 slots over the workgroup
+template <int NT>
+__device__ __forceinline__ void vec_issue(float (&vv)[(ST_NVEC * 64 + NT - 1) / NT], const cr_block_desc& d, const StackArgs& a, int D) {
+#pragma unroll
+    for (int u = 0; u < (ST_NVEC * 64 + NT - 1) / NT; ++u) {
+        const int t = tid_now() + NT * u, c = t & 63, which = min(t >> 6, ST_NVEC - 1);
+        const float* src = which == 0 ? d.ln1_g : which == 1 ? d.ln1_b : which == 2 ? d.bqkv : which == 3 ? d.bqkv + D
+                         : which == 4 ? d.bqkv + 2 * D : which == 5 ? d.ln2_g : which == 6 ? d.ln2_b : which == 7 ? d.b1
+                         : which == 8 ? d.b2 : which == 9 ? a.lnf_g : a.lnf_b;
+        vv[u] = (src && c < D) ? src[c] : 0.0f;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void vec_put(float* vec, const float (&vv)[(ST_NVEC * 64 + NT - 1) / NT]) {
+#pragma unroll
+    for (int u = 0; u < (ST_NVEC * 64 + NT - 1) / NT; ++u) {
+        const int t = tid_now() + NT * u;
+        if (t < ST_NVEC * 64) vec[t] = vv[u];
+    }
+}
+
+// Phases of a block (B0..B3 = workgroup barriers):
+//   [Wk Wv + vectors -> LDS] B0  A: per tile  x -> K, V (HBM + LDS images), key mask    B1 [Wq W1 W2 -> LDS] B2
+//   B/C: per tile  x -> LN1 -> q_in, Q -> scores, softmax, A V + q_in -> o -> LN2 -> FFN -> y (-> final LN)   B3
+// What a phase needs from HBM (weights, the tile's x) is requested before the barrier in front of it.
+template <int NKT, bool SPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int IMG = a.T16 * 64;
+    __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Kl = Kh + (SPLIT ? IMG : 0);
+    __bf16* Vh = Kl + IMG;
+    __bf16* Vl = Vh + (SPLIT ? IMG : 0);
+    __bf16* Wi = Vl + IMG;                               // 3 weight slots x (hi [, lo])
+    constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;   // elements per weight slot
+    float* vec = reinterpret_cast<float*>(Wi + 3 * WST);  // [ST_NVEC][64]
+    float* kb = vec + ST_NVEC * 64;                      // [T16] additive key bias
+    const int wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const int D = a.blk[0].bd.D, T = a.blk[0].ad.T;
+    const int base_row = n * T;
+    SK_TS(0); SK_TS(1);
+    // tiles of this wave, heaviest first: ranks w and 2 W - 1 - w of the order "last tile first" (causal cost = tile + 1)
+    const int tile0 = a.nkt - 1 - wave, tile1 = a.nkt - 1 - (2 * NW - 1 - wave);
+    const int ntiles = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);          // tile1 >= 0 implies tile0 >= 0
+    const float c2 = a.isd_log2e;
+    auto row_of = [&](int tile) { return (u32)(base_row + min(16 * tile + (lane_now() & 15), T - 1)) * (u32)D; };   // element offset of the lane's row
+
+    WRegs<2, NT> wa;
+    float vv[NVV];
+    RRaw xa;
+    {
+        const cr_block_desc& d = a.blk[0].bd;
+        w_issue<2, NT>(wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
+        vec_issue<NT>(vv, d, a, D);
+        r_issue(xa, d.x, row_of(max(tile0, 0)), D);
+    }
+#pragma unroll 1
+    for (int b = 0; b < a.nb; ++b) {
+        const cr_block_desc& d = a.blk[b].bd;
+        const cr_attn_desc& ad = a.blk[b].ad;
+        const bool last = b == a.nb - 1;
+        {
+            w_put<2, NT, SPLIT>(Wi, wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
+            vec_put<NT>(vec, vv);
+        }
+        __syncthreads();                                  // B0
+        SK_TS(2 + 10 * b);
+        // ---- phase A: K, V of the wave's tiles (HBM + LDS images), key mask ----------------------------
+#pragma unroll 1
+        for (int i = 0; i < ntiles; ++i) {
+            const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
+            const int q0 = 16 * (i == 0 ? tile0 : tile1);
+            const bool rok = q0 + li < T;
+            const int m = base_row + min(q0 + li, T - 1);
+            const u32 mo = (u32)m * (u32)D;
+            f32x4 x[4];
+            r_finish(x, xa, rok, D);
+            if (i + 1 < ntiles) r_issue(xa, d.x, row_of(tile1), D);
+            const float xs = r_rowsum(x);
+            if (lg == 0) kb[q0 + li] = (rok && xs != 0.0f) ? 0.0f : -INFINITY;   // key mask (modules.py:222)
+            if (lg == 0 && rok) d.k_valid[m] = (xs != 0.0f) ? 1.0f : 0.0f;
+            bf8 xh[2], xl[2];
+            r_split<SPLIT>(x, xh, xl);
+            f32x4 acc[4], bias[4];
+            // K = x Wk + bk (modules.py:204): image in the k order of the score product's B operand
+            r_gemm<SPLIT>(acc, Wi, Wi + ST_WIMG, xh, xl);
+            r_vec(bias, vec + 3 * 64);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
+            r_store(d.qkv + (size_t)d.M * D, mo, acc, rok, D);
+            {
+                bf8 h[2], l[2];
+                if (!rok) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                r_split<SPLIT>(acc, h, l);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int o = img_off<2>(q0 + li, 4 * ks + lg);
+                    *reinterpret_cast<bf8*>(Kh + o) = h[ks];
+                    if (SPLIT) *reinterpret_cast<bf8*>(Kl + o) = l[ks];
+                }
+            }
+            // V = x Wv + bv (modules.py:205): image in natural column order (read transposed)
+            r_gemm<SPLIT>(acc, Wi + WST, Wi + WST + ST_WIMG, xh, xl);
+            r_vec(bias, vec + 4 * 64);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
+            r_store(d.qkv + (size_t)2 * d.M * D, mo, acc, rok, D);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf4 h, l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = rok ? acc[ct][r] : 0.0f;
+                    const __bf16 hh = (__bf16)v;
+                    h[r] = hh;
+                    l[r] = (__bf16)(v - (float)hh);
+                }
+                const int o = img_off<2>(q0 + li, 2 * ct + (lg >> 1)) + 4 * (lg & 1);
+                *reinterpret_cast<bf4*>(Vh + o) = h;
+                if (SPLIT) *reinterpret_cast<bf4*>(Vl + o) = l;
+            }
+            if (i == 0) SK_TS(3 + 10 * b);
+        }
+        SK_TS(4 + 10 * b);
+        // Wq and the feed-forward weights, and the first tile's x again, fly across the barrier
+        WRegs<3, NT> wb;
+        w_issue<3, NT>(wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
+        RRaw xb;
+        r_issue(xb, d.x, row_of(max(tile0, 0)), D);
+        __syncthreads();                                  // B1: K / V / kb complete; Wk Wv no longer read
+        w_put<3, NT, SPLIT>(Wi, wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
+        __syncthreads();                                  // B2
+        SK_TS(5 + 10 * b);
+        const int fvk = first_valid_key_lds(kb, a.T16, T);
+        const int kt_first = min(fvk >> 4, NKT - 1);      // tiles below hold no valid key: probabilities exactly 0
+        const DropCtx dc = drop_ctx(ad.drop);
+        const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
+        // ---- phase B + C per tile: LN1, Q, attention core, then LN2 + feed-forward on the rows in registers -----
+#pragma unroll 1
+        for (int i = 0; i < ntiles; ++i) {
+            const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
+            const int qt = i == 0 ? tile0 : tile1;
+            const int q0 = 16 * qt, q = q0 + li;
+            const bool rok = q < T;
+            const int m = base_row + min(q, T - 1);
+            const u32 mo = (u32)m * (u32)D;
+            const int id_n = ad.dead_ids ? ad.dead_ids[m] : 1;
+            const int mk = d.mask_ids[m];
+            f32x4 o[4];
+            bf8 qh[2], ql[2];
+            float qvq;
+            {
+                f32x4 x[4], y[4], bias[4];
+                r_finish(x, xb, rok, D);
+                r_layernorm<true>(y, x, vec, vec + 64, D);                       // modules.py:74-78
+                const float ys = r_rowsum(y);
+                qvq = (rok && ys != 0.0f) ? 1.0f : 0.0f;                         // query mask (modules.py:248-249)
+                if (lg == 0 && rok) d.q_valid[m] = qvq;
+                r_store(d.q_in, mo, y, rok, D);
+                bf8 yh[2], yl[2];
+                r_split<SPLIT>(y, yh, yl);
+                r_gemm<SPLIT>(o, Wi, Wi + ST_WIMG, yh, yl);                      // Q = q_in Wq + bq (modules.py:203)
+                r_vec(bias, vec + 2 * 64);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) o[ct] += bias[ct];
+                r_store(d.qkv, mo, o, rok, D);
+                if (!rok) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                r_split<SPLIT>(o, qh, ql);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) o[ct] = y[ct];                    // residual (modules.py:269) if the tile is dead
+            }
+            const bool is_dead = !rok || id_n == 0;
+            if (__all(is_dead ? 1 : 0)) {
+                // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
+                if (ad.row_stats && lg == 0 && rok) {
+                    float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
+                    sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 2.0f; sp[3] = 0.0f;
+                }
+                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), D);
+            } else {
+                // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block
+                f32x4 st[NKT];
+                float mx = -INFINITY;
+                auto finish = [&](int kt, f32x4 acc) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);   // key mask (modules.py:222-229)
+                    acc[0] = fmaf(acc[0], c2, b4.x); acc[1] = fmaf(acc[1], c2, b4.y);
+                    acc[2] = fmaf(acc[2], c2, b4.z); acc[3] = fmaf(acc[3], c2, b4.w);
+                    if (kt == qt) {                              // causal mask on the diagonal tile (modules.py:232-241)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = (4 * lg + r <= li) ? acc[r] : -INFINITY;
+                    }
+                    mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+                    return acc;
+                };
+                const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int kt = 0; kt < NKT; kt += 2) {
+                    const bool c0 = kt >= kt_first && kt <= qt;                         // wave-uniform
+                    const bool c1 = (kt + 1 < NKT) && kt + 1 >= kt_first && kt + 1 <= qt;
+                    f32x4 a0 = ninf, a1 = ninf;
+                    if (c0 || c1) {
+                        const int r0 = 16 * (c0 ? kt : kt + 1), r1 = 16 * (c1 ? kt + 1 : kt);
+                        bf8 k0h[2], k0l[2], k1h[2], k1l[2];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            k0h[ks] = row_frag_l(Kh, r0, ks, ln); k1h[ks] = row_frag_l(Kh, r1, ks, ln);
+                            k0l[ks] = SPLIT ? row_frag_l(Kl, r0, ks, ln) : k0h[ks]; k1l[ks] = SPLIT ? row_frag_l(Kl, r1, ks, ln) : k1h[ks];
+                        }
+                        f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            x0 = mma<SPLIT>(k0h[ks], k0l[ks], qh[ks], ql[ks], x0);
+                            x1 = mma<SPLIT>(k1h[ks], k1l[ks], qh[ks], ql[ks], x1);
+                        }
+                        BF_SGB(0x100, (SPLIT ? 8 : 4), 0);
+                        BF_SGB(0x008, (SPLIT ? 12 : 4), 0);
+                        if (c0) a0 = finish(kt, c0 ? x0 : x1);
+                        if (c1) a1 = finish(kt + 1, x1);
+                    }
+                    st[kt] = a0;
+                    if (kt + 1 < NKT) st[kt + 1] = a1;
+                }
+                mx = grp_max(mx);
+                const bool uniform = (mx == -INFINITY) && !is_dead && rok;
+                const float off = (mx == -INFINITY) ? 0.0f : mx;
+                float sum = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    if (kt >= kt_first && kt <= qt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(st[kt][r] - off);     // exp2(-inf) = 0 for masked entries
+                            st[kt][r] = p;
+                            sum += p;
+                        }
+                    } else {
+                        st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                sum = grp_sum(sum);
+                if (i == 0) SK_TS(6 + 10 * b);
+                float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+                if (is_dead) inv = 0.0f;
+                const bool any_uni = __any(uniform ? 1 : 0) != 0;
+                if (ad.row_stats && lg == 0 && rok) {            // for the backward kernels
+                    float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
+                    sp[0] = mx; sp[1] = inv; sp[2] = is_dead ? 2.0f : (uniform ? 1.0f : 0.0f); sp[3] = 0.0f;
+                }
+                // ---- softmax scale, query mask, dropout (modules.py:244-257) folded into one factor per element
+                const float wq = inv * qvq;
+                const uint32_t ridx = attn_row_idx(ad, 0, n, q);
+                const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
+                if (any_uni) {                                   // rare: a row with no valid key at all (modules.py:227-244)
+                    const float uni = uniform ? a.invT * qvq : 0.0f;
+                    const float sc = uniform ? 0.0f : wq;
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float w = 1.0f;
+                            if (dc.on) w = drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                            st[kt][r] = (st[kt][r] * sc + ((16 * kt + 4 * lg + r < T) ? uni : 0.0f)) * w;
+                        }
+                } else if (dc.on) {
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[kt][r] *= wq * drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) st[kt] *= wq;
+                }
+                // ---- O^T = V^T A^T (modules.py:262): two key tiles per k-step, V through transposed reads;
+                // accumulated on top of the residual
+                const int kt_lo = any_uni ? 0 : kt_first, kt_end = any_uni ? a.nkt : qt + 1;
+#pragma unroll
+                for (int kp = 0; kp < (NKT + 1) / 2; ++kp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    if (k1 >= kt_lo && k0 < kt_end) {            // wave-uniform; tiles outside the live range hold zeros
+                        float xx[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            xx[r] = st[k0][r];
+                            xx[4 + r] = (k1 < NKT) ? st[k1 < NKT ? k1 : k0][r] : 0.0f;
+                        }
+                        bf8 ph, pl;
+                        split8<SPLIT>(xx, ph, pl);
+                        const int ra = 16 * k0, rb = 16 * (k1 < a.nkt ? k1 : k0);   // tiles beyond T16 are not staged (their A is 0)
+                        constexpr int JB = SPLIT ? 2 : 4;
+#pragma unroll
+                        for (int j0 = 0; j0 < 4; j0 += JB) {
+                            bf8 vh[JB], vl[JB];
+#pragma unroll
+                            for (int jt = 0; jt < JB; ++jt) {
+                                vh[jt] = tr_frag_l(Vh, ra, rb, j0 + jt, ln);
+                                vl[jt] = SPLIT ? tr_frag_l(Vl, ra, rb, j0 + jt, ln) : vh[jt];
+                            }
+#pragma unroll
+                            for (int jt = 0; jt < JB; ++jt) o[j0 + jt] = mma<SPLIT>(vh[jt], vl[jt], ph, pl, o[j0 + jt]);
+                            BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                            BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                        }
+                    }
+                }
+                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), D);    // the next tile's x flies under the feed-forward
+            }
+            r_store(d.o, mo, o, rok, D);
+            if (i == 0) SK_TS(7 + 10 * b);
+            // ---- LN2 + point-wise feed-forward (modules.py:300-313), row mask (sasrec.py:83)
+            f32x4 fin[4], acc[4], bias[4];
+            r_layernorm<true>(fin, o, vec + 5 * 64, vec + 6 * 64, D);            // sasrec.py:81
+            r_store(d.f_in, mo, fin, rok, D);
+            bf8 xh[2], xl[2];
+            r_split<SPLIT>(fin, xh, xl);
+            r_gemm<SPLIT>(acc, Wi + WST, Wi + WST + ST_WIMG, xh, xl);
+            r_vec(bias, vec + 7 * 64);
+            const uint32_t e1 = ((d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaxf(acc[ct][r] + bias[ct][r], 0.0f);
+                    if (d1.on) v *= drop_factor_x(d1, e1 + d1.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:303-304
+                    acc[ct][r] = v;
+                }
+            r_store(d.hid, mo, acc, rok, D);
+            r_split<SPLIT>(acc, xh, xl);
+            r_gemm<SPLIT>(acc, Wi + 2 * WST, Wi + 2 * WST + ST_WIMG, xh, xl);
+            r_vec(bias, vec + 8 * 64);
+            const float msk = mk != 0 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[ct][r] + bias[ct][r];
+                    if (d2.on) v *= drop_factor_x(d2, e1 + d2.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:309-310
+                    acc[ct][r] = (v + fin[ct][r]) * msk;                                                  // modules.py:313, sasrec.py:83
+                }
+            r_store(d.y, mo, acc, rok, D);
+            if (i == 0) SK_TS(8 + 10 * b);
+            if (last && a.out) {                          // the stack's final LayerNorm (sasrec.py:85)
+                r_layernorm<false>(fin, acc, vec + 9 * 64, vec + 10 * 64, D);
+                r_store(a.out + a.col_out, (u32)m * (u32)a.ld_out, fin, rok, D);
+            }
+        }
+        SK_TS(10 + 10 * b);
+        if (!last) {                                      // the next block's Wk Wv, vectors and first tile (= this block's y)
+            const cr_block_desc& dn = a.blk[b + 1].bd;
+            w_issue<2, NT>(wa, D, dn.wqkv, 3 * D, D, dn.wqkv, 3 * D, 2 * D, dn.wqkv, 3 * D, 2 * D);
+            vec_issue<NT>(vv, dn, a, D);
+            r_issue(xa, dn.x, row_of(max(tile0, 0)), D);
+        }
+        __syncthreads();                                  // B3: images, weights and vectors are rewritten by the next block
+    }
+    SK_TS(63);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static size_t stack_lds_bytes(int T16, bool split) {
+    return (size_t)T16 * 64 * 2 * (split ? 4 : 2) + (size_t)3 * ST_WIMG * 2 * (split ? 2 : 1) + (size_t)ST_NVEC * 64 * 4 + (size_t)T16 * 4;
+}
+
+static const char* stack_unsupported(const cr_stack_desc* s) {
+    if (!s || !s->blocks || !s->attn) return "NULL description";
+    if (s->n_blocks < 1 || s->n_blocks > CR_STACK_MAX_BLOCKS) return "1..4 blocks";
+    const cr_block_desc& b0 = s->blocks[0];
+    const cr_attn_desc& a0 = s->attn[0];
+    if (b0.D < 8 || b0.D > 64) return "hidden size 8..64";
+    if (a0.H != 1 || a0.d != b0.D) return "one head";
+    if (a0.precision != CR_PREC_BF16X3 && a0.precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
+    if (a0.T < 1 || a0.T > 256 || b0.M != a0.B * a0.T) return "T <= 256, M = B T";
+    const int T16 = (a0.T + 15) / 16 * 16;
+    if (stack_lds_bytes(T16, a0.precision == CR_PREC_BF16X3) > 160 * 1024) return "K / V images + weights exceed the LDS";
+    for (int i = 0; i < s->n_blocks; ++i) {
+        const cr_block_desc& b = s->blocks[i];
+        const cr_attn_desc& a = s->attn[i];
+        if (b.M != b0.M || b.D != b0.D || a.B != a0.B || a.T != a0.T || a.H != 1 || a.d != b0.D || a.precision != a0.precision) return "blocks differ in shape";
+        if (a.attn_weights) return "attention weights are not produced";
+        if (a.Q != b.qkv || a.K != b.qkv + (size_t)b.M * b.D || a.V != b.qkv + (size_t)2 * b.M * b.D || a.ld != b.D) return "attn Q/K/V must be the block's qkv";
+        if (a.residual != b.q_in || a.ldr != b.D || a.out != b.o || a.ldo != b.D) return "attn residual / out must be the block's q_in / o";
+        if (a.k_valid != b.k_valid || a.q_valid != b.q_valid) return "attn masks must be the block's";
+        if (!b.x || !b.q_in || !b.qkv || !b.k_valid || !b.q_valid || !b.o || !b.f_in || !b.hid || !b.y || !b.mask_ids) return "NULL buffer";
+        if (i > 0 && b.x != s->blocks[i - 1].y) return "blocks must chain (x of block i = y of block i-1)";
+    }
+    if (s->out && (!s->lnf_gamma || !s->lnf_beta)) return "final LayerNorm parameters";
+    return nullptr;
+}
+
+extern "C" int cr_stack_fwd_supported(const cr_stack_desc* s) { return stack_unsupported(s) == nullptr; }
+
+template <int NKT, bool SPLIT>
+static int launch_stack(const StackArgs& a, int B, hipStream_t s) {
+    static cr_devmask attr_set = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES>), &attr_set);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES>), dim3(B), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
+    return cr_check_launch("cr_stack_fwd");
+}
+
+extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
+    const char* why = stack_unsupported(s);
+    CR_REQUIRE(why == nullptr, "cr_stack_fwd: unsupported (%s)", why ? why : "");
+    StackArgs a;
+    const cr_attn_desc& a0 = s->attn[0];
+    a.nb = s->n_blocks;
+    a.T16 = (a0.T + 15) / 16 * 16;
+    a.nkt = a.T16 / 16;
+    a.isd_log2e = (float)(1.4426950408889634 / sqrt((double)a0.d));
+    a.invT = 1.0f / (float)a0.T;
+    a.lnf_g = s->out ? s->lnf_gamma : nullptr; a.lnf_b = s->out ? s->lnf_beta : nullptr;
+    a.out = s->out; a.ld_out = s->ld_out; a.col_out = s->col_out;
+    a.ts = g_attn_ts_which == 7 ? g_attn_ts : nullptr;
+    for (int i = 0; i < CR_STACK_MAX_BLOCKS; ++i) {
+        const int j = i < s->n_blocks ? i : 0;
+        a.blk[i].bd = s->blocks[j];
+        a.blk[i].ad = s->attn[j];
+    }
+    const bool split = a0.precision == CR_PREC_BF16X3;
+    hipStream_t st = cr_stream(stream);
+    if (a.nkt <= 4) return split ? launch_stack<4, true>(a, a0.B, st) : launch_stack<4, false>(a, a0.B, st);
+    if (a.nkt <= 8) return split ? launch_stack<8, true>(a, a0.B, st) : launch_stack<8, false>(a, a0.B, st);
+    if (a.nkt <= 13) return split ? launch_stack<13, true>(a, a0.B, st) : launch_stack<13, false>(a, a0.B, st);
+    return split ? launch_stack<16, true>(a, a0.B, st) : launch_stack<16, false>(a, a0.B, st);
+}

@@ -202,6 +202,7 @@ class Engine:
         self.single_pass_bwd = os.environ.get("CASTREC_TWO_PASS_ATTN_BWD") != "1"
         self.fuse_tails = os.environ.get("CASTREC_NO_TAILS") != "1"
         self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
+        self.fuse_stack = os.environ.get("CASTREC_NO_STACK_KERNEL") != "1"
         self._pending_embed = {}
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
@@ -428,7 +429,7 @@ class Engine:
             return lst
         self._bwd_factories.append(factory)
 
-    def op_block(self, x, y, pfx, attn_out=None, skip_qkv=False, tail=None):
+    def op_block(self, x, y, pfx, attn_out=None, skip_qkv=False, tail=None, collect=None):
         """One transformer block (sasrec.py:65-83): y = mask * FFN(LN2(MHA(LN1(x), x))).
         Fused path only: `skip_qkv` = the LN1 + QKV phase was run as the tail of the previous block's FFN kernel;
         `tail` = ("next", next block's prefix, its output buffer) or ("lnf", param prefix, out, ld, col)."""
@@ -440,7 +441,7 @@ class Engine:
         ids = self.ids["seq"]
         wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
         if self.fused:
-            return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv, tail)
+            return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv, tail, collect)
         # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
         ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
                        1e-8, kvalid.data_ptr(), qvalid.data_ptr())
@@ -543,13 +544,16 @@ class Engine:
                            f_in.data_ptr(), hid.data_ptr(), y.data_ptr(), self.ids["seq"].data_ptr(),
                            self.rng(pfx[:-1] + ".ffn1"), self.rng(pfx[:-1] + ".ffn2"))
 
-    def _op_block_fused(self, x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv=False, tail=None):
+    def _op_block_fused(self, x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv=False, tail=None,
+                        collect=None):
         """Same block through the fused row-phase kernels (cr_block_*): 3 launches forward, 3 backward; with tails
-        (the next block's LN1 + QKV, or the stack's final LayerNorm, inside the FFN kernel) 2 forward."""
+        (the next block's LN1 + QKV, or the stack's final LayerNorm, inside the FFN kernel) 2 forward.
+        collect: a list -- the forward is not emitted here; (block desc, attention desc) is appended for op_stack's
+        one cr_stack_fwd launch.  The backward is the same in both cases."""
         M, D, H, B, T = self.M, self.D, self.H, self.B, self.T
         ids = self.ids["seq"]
         bd = self._block_desc(x, y, pfx)
-        if not skip_qkv:
+        if not skip_qkv and collect is None:
             e = self._pending_embed.pop(x.data_ptr(), None)
             if e is not None:
                 self._keep.append(e)
@@ -569,8 +573,13 @@ class Engine:
         if one_pass or (self.training and bf):
             row_stats = self.vec(pfx + "row_stats", H * B * T * 4)
             ad.row_stats = row_stats.data_ptr()
-        self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
-        if tail is None:
+        if collect is not None:
+            collect.append((bd, ad))
+        else:
+            self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
+        if collect is not None:
+            pass
+        elif tail is None:
             self._call(self.fwd, "cr_block_ln_ffn_fwd", C.byref(bd))
         elif tail[0] == "next":
             nbd = self._block_desc(y, tail[2], tail[1])
@@ -619,14 +628,27 @@ class Engine:
             return lst
         self._bwd_factories.append(factory)
 
+    def _stack_kernel_fits(self, nblocks, want_attn):
+        """Shapes cr_stack_fwd takes (castrec.h): one head, D 8..64, bf16 arithmetic, K / V images + weights within the LDS."""
+        if not (self.fused and self.fuse_stack and nblocks >= 1 and not want_attn and self.H == 1 and 8 <= self.D <= 64):
+            return False
+        if self.attn_precision == "f32" or self.T > 256:
+            return False
+        T16, split = (self.T + 15) // 16 * 16, self.attn_precision == "bf16x3"
+        lds = T16 * 64 * 2 * (4 if split else 2) + 3 * 4096 * 2 * (2 if split else 1) + 11 * 64 * 4 + T16 * 4
+        return lds <= 160 * 1024
+
     def op_stack(self, x, prefix, nblocks, out, out_ld, out_col, want_attn=False):
         """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns.
-        Fused path: block i+1's LN1 + QKV phase and the final LayerNorm run as tails of the FFN kernels."""
+        Fused path: block i+1's LN1 + QKV phase and the final LayerNorm run as tails of the FFN kernels; where the
+        whole-stack kernel fits (cr_stack_fwd) the forward of up to four blocks + the final LayerNorm is ONE launch."""
         tails = self.fused and self.fuse_tails and nblocks > 0
-        if nblocks == 0 and x.data_ptr() in self._pending_embed:      # no block to carry the gather
+        stack = self._stack_kernel_fits(nblocks, want_attn)
+        if (nblocks == 0 or stack) and x.data_ptr() in self._pending_embed:      # no block kernel to carry the gather
             self._call(self.fwd, "cr_embed_fwd", C.byref(self._pending_embed.pop(x.data_ptr())))
         ys = [self.buf("%s.%d.y" % (prefix, i), self.D) for i in range(nblocks)]
         cur = x
+        collect = [] if stack else None
         for i in range(nblocks):
             nxt = ys[i]
             aw = None
@@ -636,9 +658,22 @@ class Engine:
             tail = None
             if tails:
                 tail = ("next", "%s.%d." % (prefix, i + 1), ys[i + 1]) if i + 1 < nblocks else ("lnf", prefix + ".lnf", out, out_ld, out_col)
-            self.op_block(cur, nxt, "%s.%d." % (prefix, i), attn_out=aw, skip_qkv=tails and i > 0, tail=tail)
+            self.op_block(cur, nxt, "%s.%d." % (prefix, i), attn_out=aw, skip_qkv=tails and i > 0, tail=tail, collect=collect)
             cur = nxt
-        self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf", skip_fwd=tails)
+        if stack:
+            for i0 in range(0, nblocks, 4):
+                part = collect[i0:i0 + 4]
+                bds = (L.BlockDesc * len(part))(*[c[0] for c in part])
+                ads = (L.AttnDesc * len(part))(*[c[1] for c in part])
+                fin = i0 + 4 >= nblocks
+                sd = L.StackDesc(len(part), C.cast(bds, C.POINTER(L.BlockDesc)), C.cast(ads, C.POINTER(L.AttnDesc)),
+                                 self._pptr(prefix + ".lnf.gamma") if fin else None, self._pptr(prefix + ".lnf.beta") if fin else None,
+                                 out.data_ptr() if fin else None, out_ld, out_col)
+                if not L.lib.cr_stack_fwd_supported(C.byref(sd)):
+                    raise RuntimeError("cr_stack_fwd does not take the stack %s it was sized for" % prefix)
+                self._keep.append((bds, ads))
+                self._call(self.fwd, "cr_stack_fwd", C.byref(sd))
+        self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf", skip_fwd=tails or stack)
 
     def op_head(self, seq_emb):
         """sasrec.py:87-115 (+ unnormalised gradients) / test_logits sasrec.py:93-97."""

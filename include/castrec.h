@@ -275,6 +275,23 @@ typedef struct {
 } cr_block_tail_desc;
 int cr_block_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t, void* stream);
 
+/* ---- a whole stack of blocks (sasrec.py:65-85) forward in one launch, one workgroup per sequence -------------
+ * Equals, per block i, cr_block_ln_qkv_fwd(blocks[i]); cr_attn_fwd(attn[i]); cr_block_ln_ffn_fwd(blocks[i]) and then the
+ * final LayerNorm of kind-2 tails, up to the rounding of the bf16 split products (the projections and the feed-forward
+ * run on the bf16 matrix pipe here as well): every buffer of the descriptions is written as those calls write it, so
+ * the backward entry points are unchanged.  Requirements (cr_stack_fwd_supported): 1..CR_STACK_MAX_BLOCKS blocks of one
+ * shape, H = 1, D = d in 8..64, T <= 208 (CR_PREC_BF16X3) or 256 (CR_PREC_BF16), attn[i] wired to blocks[i]'s buffers
+ * (Q/K/V = qkv parts, residual = q_in, out = o, masks), no attention weights, blocks[i+1].x == blocks[i].y. */
+#define CR_STACK_MAX_BLOCKS 4
+typedef struct {
+    int n_blocks;
+    const cr_block_desc* blocks;               /* [n_blocks] */
+    const cr_attn_desc* attn;                  /* [n_blocks] */
+    const float* lnf_gamma; const float* lnf_beta; float* out; int ld_out, col_out;   /* optional (out != NULL): final LayerNorm */
+} cr_stack_desc;
+int cr_stack_fwd_supported(const cr_stack_desc* d);   /* 1 / 0 */
+int cr_stack_fwd(const cr_stack_desc* d, void* stream);
+
 typedef struct {
     cr_block_desc f;
     const float* dy;                           /* gradient of y [M,D] */

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Per-wave phase timeline of the whole-stack forward kernel (cr_stack.hip) inside the headline training step
+(cast_1, B = 128, T = 200, D = 50): stamps of the LAST cr_stack_fwd launch of the step (the trunk)."""
+import ctypes as C, os, sys, types
+os.environ["CASTREC_TIMELINE"] = "1"      # instrumented library: python -m castrec_amd.build --timeline
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import castrec_amd
+from castrec_amd import engine as E, lib as L, synth
+from castrec_amd.sampler import WarpSampler
+
+B, T = int(os.environ.get("B", 128)), int(os.environ.get("T", 200))
+PREC = os.environ.get("PREC", "bf16x3")
+corpus = synth.preset("ml-1m")
+sargs = types.SimpleNamespace(seed=42, bin_in_hours=48, max_bins=200, log_scale=False)
+smp = WarpSampler(sargs, corpus, corpus.usernum, corpus.itemnum, batch_size=B, maxlen=T)
+u, seq, pos, neg, ts_, rat, hrs, dys, _ = smp.next_batch()
+smp.close()
+hp = E.Hyper(maxlen=T, hidden_units=50, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=200, lr=1e-3)
+eng = E.Engine("cast_1", corpus.usernum, corpus.itemnum, hp, B, training=True, attn_precision=PREC)
+eng.set_batch(seq, pos, neg, ts_, hrs, dys)
+fn = getattr(L._lib, "cr_debug_attn_ts"); fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = None
+for _ in range(3):
+    eng.launch_step()
+torch.cuda.synchronize()
+NS = 64
+ts = torch.zeros(B * 8 * NS, dtype=torch.int64, device="cuda")
+fn(ts.data_ptr(), 7)
+eng.launch_step()
+torch.cuda.synchronize()
+fn(None, 0)
+t = ts.cpu().numpy().reshape(B, 8, NS).astype(np.float64)
+w0 = t[:, :, 0].min()
+print("kernel span %.1f us (wall clock, first wave start -> last wave end)" % ((t[:, :, 63].max() - w0) * 10.0 / 1e3))
+print("wave start ns p50 %.0f max %.0f" % tuple(np.percentile((t[:, :, 0] - w0) * 10.0, [50, 100])))
+names = {0: "weights staged (barrier)", 1: "phase A first tile", 2: "phase A all tiles", 3: "W1/W2 staged (2 barriers)",
+         4: "scores + softmax (first tile)", 5: "A V + o (first tile)", 6: "LN2 + FFN (first tile)", 8: "all tiles done"}
+for wave in (0, 3, 7):
+    print("-- wave", wave)
+    prev = t[:, wave, 1]
+    for b in range(2):
+        for k in (0, 1, 2, 3, 4, 5, 6, 8):
+            cur = t[:, wave, 2 + 10 * b + k]
+            ok = (cur > 0) & (prev > 0)
+            if ok.sum() == 0:
+                continue
+            dlt = (cur - prev)[ok]
+            print("  block %d  %-34s median %7.0f clk (%5.2f us)  p90 %7.0f" % (b, names[k], np.median(dlt), np.median(dlt) / 2.4e3, np.percentile(dlt, 90)))
+            prev = np.where(cur > 0, cur, prev)
