@@ -52,14 +52,19 @@ struct StackArgs {
 #endif
 
 // ---- layout R <-> rows of a dense [*, ld] matrix ----------------------------------------------------------
-// Whole 16-byte pieces are one load; the piece that crosses column D (D % 4 != 0) is read element by element with
-// clamped addresses and pieces beyond D read the window [D - 4, D) and are zeroed: no branches on the load side,
-// nothing outside the row is touched, and a lane uses only elements that r_store of the SAME lane wrote -- a tile
-// written earlier by this wave can be re-read without a barrier in between.
-struct RRaw { f4u v[4]; float p[3]; };
-// Thread / lane number the optimiser cannot hoist or share between uses: everything derived from it (column offsets, pad masks)
-// is then recomputed where it is used -- a few VALU ops -- instead of being kept live across the whole kernel (the
-// loop-invariant per-lane values of all helpers together spilled 160 registers).
+// Columns come in 16-byte pieces (column tile ct, lane group lg: columns 16 ct + 4 lg .. + 3).  With nfull = D / 16 and
+// rem = D % 16 (wave-uniform), tiles ct < nfull are whole for every lane: plain loads / stores, no masks, no address
+// clamps -- scalar branches decide.  Only tile ct == nfull needs lane predicates: pieces with 4 lg + 4 <= rem are
+// whole, the piece with 4 lg < rem < 4 lg + 4 (D % 4 != 0) is moved element by element, the rest do not exist (read as
+// 0).  A lane only ever reads elements that r_store of the SAME lane wrote, so a tile written earlier by this wave can
+// be re-read without a barrier in between.  Nothing outside a row is touched.
+// (The first version clamped and masked every piece of every tile per lane: 5 VALU instructions per element, and the
+//  kernel is VALU-issue bound -- about 700 of the 1100 instructions of a phase-A tile were this bookkeeping.)
+struct DCtx { int D, nfull, rem, np; };                   // np = D % 4: elements of the crossing piece
+__device__ __forceinline__ DCtx d_ctx(int D) { DCtx c; c.D = D; c.nfull = D >> 4; c.rem = D & 15; c.np = D & 3; return c; }
+// Thread / lane number the optimiser cannot hoist or share between uses: everything derived from it (column offsets,
+// pad masks) is then recomputed where it is used -- a few VALU ops -- instead of being kept live across the whole kernel
+// (the loop-invariant per-lane values of all helpers together spilled 160 registers).
 __device__ __forceinline__ int tid_now() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
@@ -67,44 +72,64 @@ __device__ __forceinline__ int tid_now() {
 }
 __device__ __forceinline__ int lane_now() { return tid_now() & 63; }
 typedef uint32_t u32;
-// base: a wave-uniform pointer; off: the row's element offset (32 bits: the host checks M * D < 2^30)
-__device__ __forceinline__ void r_issue(RRaw& w, const float* base, u32 off, int D) {
-    const int lg = lane_now() >> 4;
+struct RRaw { f4u v[4]; float p[3]; };
+
+// base: a wave-uniform pointer; rowb: the row's BYTE offset (32 bits: the host checks M * D * 4 < 2^32)
+__device__ __forceinline__ void r_issue(RRaw& w, const float* base, u32 rowb, const DCtx& dc) {
+    const int lgb = (lane_now() >> 4) * 4;
+    const char* b = reinterpret_cast<const char*>(base);
+    const u32 ob = rowb + 4u * (u32)lgb;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) w.v[ct] = *reinterpret_cast<const f4u*>(base + (off + (u32)min(16 * ct + 4 * lg, D - 4)));
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < dc.nfull) {
+            w.v[ct] = *reinterpret_cast<const f4u*>(b + (ob + 64u * ct));
+        } else {
+            w.v[ct] = (f4u){0.f, 0.f, 0.f, 0.f};
+            if (ct == dc.nfull && lgb + 4 <= dc.rem) w.v[ct] = *reinterpret_cast<const f4u*>(b + (ob + 64u * ct));
+        }
+    }
     w.p[0] = w.p[1] = w.p[2] = 0.0f;
-    if (D & 3) {                                          // wave-uniform
-        const int cp = D & ~3;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) w.p[r] = base[off + (u32)min(cp + r, D - 1)];
+    if (dc.np) {                                          // wave-uniform
+        if (lgb < dc.rem && lgb + 4 > dc.rem) {
+            const float* q = reinterpret_cast<const float*>(b + (ob + 64u * (u32)dc.nfull));
+            w.p[0] = q[0];
+            if (dc.np > 1) w.p[1] = q[1];
+            if (dc.np > 2) w.p[2] = q[2];
+        }
     }
 }
-__device__ __forceinline__ void r_finish(f32x4 (&x)[4], const RRaw& w, bool rok, int D) {
-    const int lg = lane_now() >> 4;
-    const int cp = D & ~3;
+__device__ __forceinline__ void r_finish(f32x4 (&x)[4], const RRaw& w, const DCtx& dc) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int c = 16 * ct + 4 * lg;
-        const bool part = c == cp;                        // the crossing piece (never true when D % 4 == 0: then cp == D)
-        x[ct][0] = (rok && c + 0 < D) ? (part ? w.p[0] : w.v[ct].x) : 0.0f;
-        x[ct][1] = (rok && c + 1 < D) ? (part ? w.p[1] : w.v[ct].y) : 0.0f;
-        x[ct][2] = (rok && c + 2 < D) ? (part ? w.p[2] : w.v[ct].z) : 0.0f;
-        x[ct][3] = (rok && c + 3 < D) ? w.v[ct].w : 0.0f;
+    for (int ct = 0; ct < 4; ++ct) x[ct] = (f32x4){w.v[ct].x, w.v[ct].y, w.v[ct].z, w.v[ct].w};
+    if (dc.np) {
+        const int lgb = (lane_now() >> 4) * 4;
+        const bool part = lgb < dc.rem && lgb + 4 > dc.rem;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            if (ct == dc.nfull) {                         // wave-uniform
+                x[ct][0] = part ? w.p[0] : x[ct][0];
+                x[ct][1] = part ? w.p[1] : x[ct][1];
+                x[ct][2] = part ? w.p[2] : x[ct][2];
+            }
     }
 }
-__device__ __forceinline__ void r_store(float* base, u32 off, const f32x4 (&x)[4], bool rok, int D) {
-    const int lg = lane_now() >> 4;
+__device__ __forceinline__ void r_store(float* base, u32 rowb, const f32x4 (&x)[4], bool rok, const DCtx& dc) {
+    const int lgb = (lane_now() >> 4) * 4;
+    char* b = reinterpret_cast<char*>(base);
+    const u32 ob = rowb + 4u * (u32)lgb;
+    if (rok) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int c = 16 * ct + 4 * lg;
-        if (rok && c < D) {
-            float* rowp = base + (off + (u32)c);
-            if (c + 4 <= D) {
-                *reinterpret_cast<f4u*>(rowp) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
-            } else {
-                rowp[0] = x[ct][0];
-                if (c + 1 < D) rowp[1] = x[ct][1];
-                if (c + 2 < D) rowp[2] = x[ct][2];
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct < dc.nfull) {
+                *reinterpret_cast<f4u*>(b + (ob + 64u * ct)) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
+            } else if (ct == dc.nfull) {
+                if (lgb + 4 <= dc.rem) *reinterpret_cast<f4u*>(b + (ob + 64u * ct)) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
+                if (dc.np && lgb < dc.rem && lgb + 4 > dc.rem) {
+                    float* q = reinterpret_cast<float*>(b + (ob + 64u * ct));
+                    q[0] = x[ct][0];
+                    if (dc.np > 1) q[1] = x[ct][1];
+                    if (dc.np > 2) q[2] = x[ct][2];
+                }
             }
         }
     }
@@ -124,22 +149,30 @@ __device__ __forceinline__ float r_rowsum(const f32x4 (&x)[4]) {
     for (int ct = 0; ct < 4; ++ct) s += (x[ct][0] + x[ct][1]) + (x[ct][2] + x[ct][3]);
     return grp_sum(s);
 }
-// LayerNorm of the lane's row (modules.py:74-78); gam / bet zero padded, so pad columns come out 0.
+// LayerNorm of the lane's row (modules.py:74-78).  x is 0 in the pad columns; gam / bet are zero padded, so pad columns
+// come out 0 without a mask; the centred values are masked in the one column tile that holds the boundary.
 // RECIP: y = g * (xc * (1 / sd)) + b (the block kernels' form), else g * (xc / sd) + b (cr_layernorm_fwd's)
 template <bool RECIP>
-__device__ __forceinline__ void r_layernorm(f32x4 (&y)[4], const f32x4 (&x)[4], const float* gam, const float* bet, int D) {
-    const int lg = lane_now() >> 4;
-    const float invD = 1.0f / (float)D;
+__device__ __forceinline__ void r_layernorm(f32x4 (&y)[4], const f32x4 (&x)[4], const float* gam, const float* bet, const DCtx& dc) {
+    const float invD = 1.0f / (float)dc.D;
     const float mean = r_rowsum(x) * invD;
     f32x4 xc[4];
     float v = 0.0f;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < dc.nfull) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            xc[ct][r] = (16 * ct + 4 * lg + r < D) ? x[ct][r] - mean : 0.0f;
-            v = fmaf(xc[ct][r], xc[ct][r], v);
+            for (int r = 0; r < 4; ++r) xc[ct][r] = x[ct][r] - mean;
+        } else if (ct == dc.nfull) {
+            const int lgb = (lane_now() >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xc[ct][r] = (lgb + r < dc.rem) ? x[ct][r] - mean : 0.0f;
+        } else {
+            xc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaf(xc[ct][r], xc[ct][r], v);
+    }
     const float sd = sqrtf(grp_sum(v) * invD + 1e-8f);
     const float rs = 1.0f / sd;
     f32x4 g[4], b[4];
@@ -275,7 +308,9 @@ __device__ __forceinline__ void vec_put(float* vec, const float (&vv)[(ST_NVEC *
 //   [Wk Wv + vectors -> LDS] B0  A: per tile  x -> K, V (HBM + LDS images), key mask    B1 [Wq W1 W2 -> LDS] B2
 //   B/C: per tile  x -> LN1 -> q_in, Q -> scores, softmax, A V + q_in -> o -> LN2 -> FFN -> y (-> final LN)   B3
 // What a phase needs from HBM (weights, the tile's x) is requested before the barrier in front of it.
-template <int NKT, bool SPLIT, int NW>
+// DS: the hidden size as a compile-time constant (0 = read it from the description): with it every column-tile
+// classification above is resolved by the compiler -- instantiated for the headline D = 50
+template <int NKT, bool SPLIT, int NW, int DS>
 __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
@@ -291,14 +326,15 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     float* kb = vec + ST_NVEC * 64;                      // [T16] additive key bias
     const int wave = threadIdx.x >> 6;
     const int n = blockIdx.x;
-    const int D = a.blk[0].bd.D, T = a.blk[0].ad.T;
+    const int D = DS > 0 ? DS : a.blk[0].bd.D, T = a.blk[0].ad.T;
     const int base_row = n * T;
     SK_TS(0); SK_TS(1);
     // tiles of this wave, heaviest first: ranks w and 2 W - 1 - w of the order "last tile first" (causal cost = tile + 1)
     const int tile0 = a.nkt - 1 - wave, tile1 = a.nkt - 1 - (2 * NW - 1 - wave);
     const int ntiles = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);          // tile1 >= 0 implies tile0 >= 0
     const float c2 = a.isd_log2e;
-    auto row_of = [&](int tile) { return (u32)(base_row + min(16 * tile + (lane_now() & 15), T - 1)) * (u32)D; };   // element offset of the lane's row
+    const DCtx dcx = d_ctx(D);
+    auto row_of = [&](int tile) { return (u32)(base_row + min(16 * tile + (lane_now() & 15), T - 1)) * (u32)(4 * D); };   // byte offset of the lane's row
 
     WRegs<2, NT> wa;
     float vv[NVV];
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         const cr_block_desc& d = a.blk[0].bd;
         w_issue<2, NT>(wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
         vec_issue<NT>(vv, d, a, D);
-        r_issue(xa, d.x, row_of(max(tile0, 0)), D);
+        r_issue(xa, d.x, row_of(max(tile0, 0)), dcx);
     }
 #pragma unroll 1
     for (int b = 0; b < a.nb; ++b) {
@@ -327,10 +363,10 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const int q0 = 16 * (i == 0 ? tile0 : tile1);
             const bool rok = q0 + li < T;
             const int m = base_row + min(q0 + li, T - 1);
-            const u32 mo = (u32)m * (u32)D;
+            const u32 mo = (u32)m * (u32)(4 * D);
             f32x4 x[4];
-            r_finish(x, xa, rok, D);
-            if (i + 1 < ntiles) r_issue(xa, d.x, row_of(tile1), D);
+            r_finish(x, xa, dcx);
+            if (i + 1 < ntiles) r_issue(xa, d.x, row_of(tile1), dcx);
             const float xs = r_rowsum(x);
             if (lg == 0) kb[q0 + li] = (rok && xs != 0.0f) ? 0.0f : -INFINITY;   // key mask (modules.py:222)
             if (lg == 0 && rok) d.k_valid[m] = (xs != 0.0f) ? 1.0f : 0.0f;
@@ -342,13 +378,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             r_vec(bias, vec + 3 * 64);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
-            r_store(d.qkv + (size_t)d.M * D, mo, acc, rok, D);
+            r_store(d.qkv + (size_t)d.M * D, mo, acc, rok, dcx);
             {
-                bf8 h[2], l[2];
-                if (!rok) {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                bf8 h[2], l[2];                           // (rows beyond T hold copies of row T - 1: finite, and masked as keys)
                 r_split<SPLIT>(acc, h, l);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -362,16 +394,17 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             r_vec(bias, vec + 4 * 64);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
-            r_store(d.qkv + (size_t)2 * d.M * D, mo, acc, rok, D);
+            r_store(d.qkv + (size_t)2 * d.M * D, mo, acc, rok, dcx);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf4 h, l;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = rok ? acc[ct][r] : 0.0f;
-                    const __bf16 hh = (__bf16)v;
-                    h[r] = hh;
-                    l[r] = (__bf16)(v - (float)hh);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 v = {acc[ct][r], acc[ct][r + 1]};
+                    const bf2 hh = __builtin_convertvector(v, bf2);
+                    const bf2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x2), bf2);
+                    h[r] = hh[0]; h[r + 1] = hh[1];
+                    l[r] = ll[0]; l[r + 1] = ll[1];
                 }
                 const int o = img_off<2>(q0 + li, 2 * ct + (lg >> 1)) + 4 * (lg & 1);
                 *reinterpret_cast<bf4*>(Vh + o) = h;
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         WRegs<3, NT> wb;
         w_issue<3, NT>(wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
         RRaw xb;
-        r_issue(xb, d.x, row_of(max(tile0, 0)), D);
+        r_issue(xb, d.x, row_of(max(tile0, 0)), dcx);
         __syncthreads();                                  // B1: K / V / kb complete; Wk Wv no longer read
         w_put<3, NT, SPLIT>(Wi, wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
         __syncthreads();                                  // B2
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const int q0 = 16 * qt, q = q0 + li;
             const bool rok = q < T;
             const int m = base_row + min(q, T - 1);
-            const u32 mo = (u32)m * (u32)D;
+            const u32 mo = (u32)m * (u32)(4 * D);
             const int id_n = ad.dead_ids ? ad.dead_ids[m] : 1;
             const int mk = d.mask_ids[m];
             f32x4 o[4];
@@ -409,23 +442,19 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             float qvq;
             {
                 f32x4 x[4], y[4], bias[4];
-                r_finish(x, xb, rok, D);
-                r_layernorm<true>(y, x, vec, vec + 64, D);                       // modules.py:74-78
+                r_finish(x, xb, dcx);
+                r_layernorm<true>(y, x, vec, vec + 64, dcx);                       // modules.py:74-78
                 const float ys = r_rowsum(y);
                 qvq = (rok && ys != 0.0f) ? 1.0f : 0.0f;                         // query mask (modules.py:248-249)
                 if (lg == 0 && rok) d.q_valid[m] = qvq;
-                r_store(d.q_in, mo, y, rok, D);
+                r_store(d.q_in, mo, y, rok, dcx);
                 bf8 yh[2], yl[2];
                 r_split<SPLIT>(y, yh, yl);
                 r_gemm<SPLIT>(o, Wi, Wi + ST_WIMG, yh, yl);                      // Q = q_in Wq + bq (modules.py:203)
                 r_vec(bias, vec + 2 * 64);
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) o[ct] += bias[ct];
-                r_store(d.qkv, mo, o, rok, D);
-                if (!rok) {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                r_store(d.qkv, mo, o, rok, dcx);
                 r_split<SPLIT>(o, qh, ql);
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) o[ct] = y[ct];                    // residual (modules.py:269) if the tile is dead
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                     float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
                     sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 2.0f; sp[3] = 0.0f;
                 }
-                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), D);
+                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), dcx);
             } else {
                 // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block
                 f32x4 st[NKT];
@@ -563,14 +592,14 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         }
                     }
                 }
-                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), D);    // the next tile's x flies under the feed-forward
+                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), dcx);    // the next tile's x flies under the feed-forward
             }
-            r_store(d.o, mo, o, rok, D);
+            r_store(d.o, mo, o, rok, dcx);
             if (i == 0) SK_TS(7 + 10 * b);
             // ---- LN2 + point-wise feed-forward (modules.py:300-313), row mask (sasrec.py:83)
             f32x4 fin[4], acc[4], bias[4];
-            r_layernorm<true>(fin, o, vec + 5 * 64, vec + 6 * 64, D);            // sasrec.py:81
-            r_store(d.f_in, mo, fin, rok, D);
+            r_layernorm<true>(fin, o, vec + 5 * 64, vec + 6 * 64, dcx);            // sasrec.py:81
+            r_store(d.f_in, mo, fin, rok, dcx);
             bf8 xh[2], xl[2];
             r_split<SPLIT>(fin, xh, xl);
             r_gemm<SPLIT>(acc, Wi + WST, Wi + WST + ST_WIMG, xh, xl);
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                     if (d1.on) v *= drop_factor_x(d1, e1 + d1.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:303-304
                     acc[ct][r] = v;
                 }
-            r_store(d.hid, mo, acc, rok, D);
+            r_store(d.hid, mo, acc, rok, dcx);
             r_split<SPLIT>(acc, xh, xl);
             r_gemm<SPLIT>(acc, Wi + 2 * WST, Wi + 2 * WST + ST_WIMG, xh, xl);
             r_vec(bias, vec + 8 * 64);
@@ -597,11 +626,11 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                     if (d2.on) v *= drop_factor_x(d2, e1 + d2.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:309-310
                     acc[ct][r] = (v + fin[ct][r]) * msk;                                                  // modules.py:313, sasrec.py:83
                 }
-            r_store(d.y, mo, acc, rok, D);
+            r_store(d.y, mo, acc, rok, dcx);
             if (i == 0) SK_TS(8 + 10 * b);
             if (last && a.out) {                          // the stack's final LayerNorm (sasrec.py:85)
-                r_layernorm<false>(fin, acc, vec + 9 * 64, vec + 10 * 64, D);
-                r_store(a.out + a.col_out, (u32)m * (u32)a.ld_out, fin, rok, D);
+                r_layernorm<false>(fin, acc, vec + 9 * 64, vec + 10 * 64, dcx);
+                r_store(a.out + a.col_out, (u32)m * (u32)(4 * a.ld_out), fin, rok, dcx);
             }
         }
         SK_TS(10 + 10 * b);
@@ -609,7 +638,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const cr_block_desc& dn = a.blk[b + 1].bd;
             w_issue<2, NT>(wa, D, dn.wqkv, 3 * D, D, dn.wqkv, 3 * D, 2 * D, dn.wqkv, 3 * D, 2 * D);
             vec_issue<NT>(vv, dn, a, D);
-            r_issue(xa, dn.x, row_of(max(tile0, 0)), D);
+            r_issue(xa, dn.x, row_of(max(tile0, 0)), dcx);
         }
         __syncthreads();                                  // B3: images, weights and vectors are rewritten by the next block
     }
@@ -651,13 +680,18 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
 
 extern "C" int cr_stack_fwd_supported(const cr_stack_desc* s) { return stack_unsupported(s) == nullptr; }
 
+template <int NKT, bool SPLIT, int DS>
+static int launch_stack_d(const StackArgs& a, int B, hipStream_t s) {
+    static cr_devmask attr_set = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS>), &attr_set);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS>), dim3(B), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
+    return cr_check_launch("cr_stack_fwd");
+}
 template <int NKT, bool SPLIT>
 static int launch_stack(const StackArgs& a, int B, hipStream_t s) {
-    static cr_devmask attr_set = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES>), &attr_set);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES>), dim3(B), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
-    return cr_check_launch("cr_stack_fwd");
+    if ((NKT == 4 || NKT == 13) && a.blk[0].bd.D == 50) return launch_stack_d<NKT, SPLIT, (NKT == 4 || NKT == 13) ? 50 : 0>(a, B, s);
+    return launch_stack_d<NKT, SPLIT, 0>(a, B, s);
 }
 
 extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
