@@ -44,7 +44,7 @@ struct StackArgs {
 #define SK_TS(slot)                                                                                          \
     do {                                                                                                     \
         if (a.ts && (threadIdx.x & 63) == 0)                                                                 \
-            a.ts[((size_t)blockIdx.x * ST_WAVES + (threadIdx.x >> 6)) * 64 + (slot)] =                       \
+            a.ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ST_WAVES + (threadIdx.x >> 6)) * 64 + (slot)] =                       \
                 ((slot) == 0 || (slot) == 63) ? wall_clock64() : clock64();                                  \
     } while (0)
 #else
@@ -310,7 +310,11 @@ __device__ __forceinline__ void vec_put(float* vec, const float (&vv)[(ST_NVEC *
 // What a phase needs from HBM (weights, the tile's x) is requested before the barrier in front of it.
 // DS: the hidden size as a compile-time constant (0 = read it from the description): with it every column-tile
 // classification above is resolved by the compiler -- instantiated for the headline D = 50
-template <int NKT, bool SPLIT, int NW, int DS>
+// PAIR: two workgroups per sequence (grid.y = 2), one block per launch.  The kernel is VALU-issue bound, so when the
+// batch leaves half of the CUs idle (B = 128 on 256 CUs) a sequence is given two of them: both workgroups compute
+// K / V of ALL tiles (phase A, the smaller phase; workgroup 0 also writes them to HBM), then each takes every other
+// tile of the heaviest-first order through phase B / C.  Block i + 1 needs y of both, hence one launch per block.
+template <int NKT, bool SPLIT, int NW, int DS, bool PAIR>
 __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
@@ -330,8 +334,13 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     const int base_row = n * T;
     SK_TS(0); SK_TS(1);
     // tiles of this wave, heaviest first: ranks w and 2 W - 1 - w of the order "last tile first" (causal cost = tile + 1)
-    const int tile0 = a.nkt - 1 - wave, tile1 = a.nkt - 1 - (2 * NW - 1 - wave);
-    const int ntiles = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);          // tile1 >= 0 implies tile0 >= 0
+    const int tile0 = a.nkt - 1 - (PAIR ? 2 * wave + (int)blockIdx.y : wave);
+    const int tile1 = PAIR ? -1 : a.nkt - 1 - (2 * NW - 1 - wave);
+    const int nB = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);              // phase B / C tiles (tile1 >= 0 implies tile0 >= 0)
+    const int nA = PAIR ? (a.nkt - wave + NW - 1) / NW : nB;                 // phase A tiles: PAIR: wave, wave + NW, ...
+    auto tile_a = [&](int i) { return PAIR ? wave + NW * i : (i == 0 ? tile0 : tile1); };
+    auto tile_b = [&](int i) { return i == 0 ? tile0 : tile1; };
+    const bool wr_kv = !PAIR || blockIdx.y == 0;                             // this workgroup writes K / V / key flags to HBM
     const float c2 = a.isd_log2e;
     const DCtx dcx = d_ctx(D);
     auto row_of = [&](int tile) { return (u32)(base_row + min(16 * tile + (lane_now() & 15), T - 1)) * (u32)(4 * D); };   // byte offset of the lane's row
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         const cr_block_desc& d = a.blk[0].bd;
         w_issue<2, NT>(wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
         vec_issue<NT>(vv, d, a, D);
-        r_issue(xa, d.x, row_of(max(tile0, 0)), dcx);
+        r_issue(xa, d.x, row_of(max(tile_a(0), 0)), dcx);
     }
 #pragma unroll 1
     for (int b = 0; b < a.nb; ++b) {
@@ -356,20 +365,23 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         }
         __syncthreads();                                  // B0
         SK_TS(2 + 10 * b);
+        // Wq and the feed-forward weights are requested now and land under phase A
+        WRegs<3, NT> wb;
+        w_issue<3, NT>(wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
         // ---- phase A: K, V of the wave's tiles (HBM + LDS images), key mask ----------------------------
 #pragma unroll 1
-        for (int i = 0; i < ntiles; ++i) {
+        for (int i = 0; i < nA; ++i) {
             const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
-            const int q0 = 16 * (i == 0 ? tile0 : tile1);
+            const int q0 = 16 * tile_a(i);
             const bool rok = q0 + li < T;
             const int m = base_row + min(q0 + li, T - 1);
             const u32 mo = (u32)m * (u32)(4 * D);
             f32x4 x[4];
             r_finish(x, xa, dcx);
-            if (i + 1 < ntiles) r_issue(xa, d.x, row_of(tile1), dcx);
+            if (i + 1 < nA) r_issue(xa, d.x, row_of(tile_a(i + 1)), dcx);
             const float xs = r_rowsum(x);
             if (lg == 0) kb[q0 + li] = (rok && xs != 0.0f) ? 0.0f : -INFINITY;   // key mask (modules.py:222)
-            if (lg == 0 && rok) d.k_valid[m] = (xs != 0.0f) ? 1.0f : 0.0f;
+            if (lg == 0 && rok && wr_kv) d.k_valid[m] = (xs != 0.0f) ? 1.0f : 0.0f;
             bf8 xh[2], xl[2];
             r_split<SPLIT>(x, xh, xl);
             f32x4 acc[4], bias[4];
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             r_vec(bias, vec + 3 * 64);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
-            r_store(d.qkv + (size_t)d.M * D, mo, acc, rok, dcx);
+            r_store(d.qkv + (size_t)d.M * D, mo, acc, rok && wr_kv, dcx);
             {
                 bf8 h[2], l[2];                           // (rows beyond T hold copies of row T - 1: finite, and masked as keys)
                 r_split<SPLIT>(acc, h, l);
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             r_vec(bias, vec + 4 * 64);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
-            r_store(d.qkv + (size_t)2 * d.M * D, mo, acc, rok, dcx);
+            r_store(d.qkv + (size_t)2 * d.M * D, mo, acc, rok && wr_kv, dcx);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf4 h, l;
@@ -413,11 +425,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             if (i == 0) SK_TS(3 + 10 * b);
         }
         SK_TS(4 + 10 * b);
-        // Wq and the feed-forward weights, and the first tile's x again, fly across the barrier
-        WRegs<3, NT> wb;
-        w_issue<3, NT>(wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
+        // the first B / C tile's x flies across the barrier
         RRaw xb;
-        r_issue(xb, d.x, row_of(max(tile0, 0)), dcx);
+        r_issue(xb, d.x, row_of(max(tile_b(0), 0)), dcx);
         __syncthreads();                                  // B1: K / V / kb complete; Wk Wv no longer read
         w_put<3, NT, SPLIT>(Wi, wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
         __syncthreads();                                  // B2
@@ -428,9 +438,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
         // ---- phase B + C per tile: LN1, Q, attention core, then LN2 + feed-forward on the rows in registers -----
 #pragma unroll 1
-        for (int i = 0; i < ntiles; ++i) {
+        for (int i = 0; i < nB; ++i) {
             const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
-            const int qt = i == 0 ? tile0 : tile1;
+            const int qt = tile_b(i);
             const int q0 = 16 * qt, q = q0 + li;
             const bool rok = q < T;
             const int m = base_row + min(q, T - 1);
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                     float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
                     sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 2.0f; sp[3] = 0.0f;
                 }
-                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), dcx);
+                if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);
             } else {
                 // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block
                 f32x4 st[NKT];
@@ -575,7 +585,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         }
                         bf8 ph, pl;
                         split8<SPLIT>(xx, ph, pl);
-                        const int ra = 16 * k0, rb = 16 * (k1 < a.nkt ? k1 : k0);   // tiles beyond T16 are not staged (their A is 0)
+                        // tiles beyond T16 are not staged (their A is 0); DS instantiations run with nkt == NKT: constant offsets
+                        const int ra = 16 * k0, rb = 16 * ((DS > 0 ? k1 < NKT : k1 < a.nkt) ? k1 : k0);
                         constexpr int JB = SPLIT ? 2 : 4;
 #pragma unroll
                         for (int j0 = 0; j0 < 4; j0 += JB) {
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         }
                     }
                 }
-                if (i + 1 < ntiles) r_issue(xb, d.x, row_of(tile1), dcx);    // the next tile's x flies under the feed-forward
+                if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);    // the next tile's x flies under the feed-forward
             }
             r_store(d.o, mo, o, rok, dcx);
             if (i == 0) SK_TS(7 + 10 * b);
@@ -638,7 +649,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const cr_block_desc& dn = a.blk[b + 1].bd;
             w_issue<2, NT>(wa, D, dn.wqkv, 3 * D, D, dn.wqkv, 3 * D, 2 * D, dn.wqkv, 3 * D, 2 * D);
             vec_issue<NT>(vv, dn, a, D);
-            r_issue(xa, dn.x, row_of(max(tile0, 0)), dcx);
+            r_issue(xa, dn.x, row_of(max(tile_a(0), 0)), dcx);
         }
         __syncthreads();                                  // B3: images, weights and vectors are rewritten by the next block
     }
@@ -661,6 +672,7 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
     if (a0.H != 1 || a0.d != b0.D) return "one head";
     if (a0.precision != CR_PREC_BF16X3 && a0.precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
     if (a0.T < 1 || a0.T > 256 || b0.M != a0.B * a0.T) return "T <= 256, M = B T";
+    if ((size_t)b0.M * (size_t)(s->out && s->ld_out > b0.D ? s->ld_out : b0.D) * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
     const int T16 = (a0.T + 15) / 16 * 16;
     if (stack_lds_bytes(T16, a0.precision == CR_PREC_BF16X3) > 160 * 1024) return "K / V images + weights exceed the LDS";
     for (int i = 0; i < s->n_blocks; ++i) {
@@ -680,42 +692,57 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
 
 extern "C" int cr_stack_fwd_supported(const cr_stack_desc* s) { return stack_unsupported(s) == nullptr; }
 
-template <int NKT, bool SPLIT, int DS>
+template <int NKT, bool SPLIT, int DS, bool PAIR>
 static int launch_stack_d(const StackArgs& a, int B, hipStream_t s) {
     static cr_devmask attr_set = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS>), &attr_set);
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR>), &attr_set);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS>), dim3(B), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
+    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR>), dim3(B, PAIR ? 2 : 1), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
     return cr_check_launch("cr_stack_fwd");
 }
 template <int NKT, bool SPLIT>
-static int launch_stack(const StackArgs& a, int B, hipStream_t s) {
-    if ((NKT == 4 || NKT == 13) && a.blk[0].bd.D == 50) return launch_stack_d<NKT, SPLIT, (NKT == 4 || NKT == 13) ? 50 : 0>(a, B, s);
-    return launch_stack_d<NKT, SPLIT, 0>(a, B, s);
+static int launch_stack(const StackArgs& a, int B, bool pair, hipStream_t s) {
+    constexpr int DS = (NKT == 4 || NKT == 13) ? 50 : 0;                 // the headline hidden size as a constant
+    if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false>(a, B, s);
+    return pair ? launch_stack_d<NKT, SPLIT, 0, true>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false>(a, B, s);
 }
+static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, hipStream_t st) {
+    if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, st) : launch_stack<4, false>(a, B, pair, st);
+    if (a.nkt <= 8) return split ? launch_stack<8, true>(a, B, pair, st) : launch_stack<8, false>(a, B, pair, st);
+    if (a.nkt <= 13) return split ? launch_stack<13, true>(a, B, pair, st) : launch_stack<13, false>(a, B, pair, st);
+    return split ? launch_stack<16, true>(a, B, pair, st) : launch_stack<16, false>(a, B, pair, st);
+}
+
+// batches up to this size run two workgroups per sequence, one launch per block (256 CUs, one workgroup each)
+static const int g_stack_pair_max_b = getenv("CASTREC_STACK_PAIR_MAX_B") ? atoi(getenv("CASTREC_STACK_PAIR_MAX_B")) : 160;
 
 extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
     const char* why = stack_unsupported(s);
     CR_REQUIRE(why == nullptr, "cr_stack_fwd: unsupported (%s)", why ? why : "");
     StackArgs a;
     const cr_attn_desc& a0 = s->attn[0];
-    a.nb = s->n_blocks;
     a.T16 = (a0.T + 15) / 16 * 16;
     a.nkt = a.T16 / 16;
     a.isd_log2e = (float)(1.4426950408889634 / sqrt((double)a0.d));
     a.invT = 1.0f / (float)a0.T;
-    a.lnf_g = s->out ? s->lnf_gamma : nullptr; a.lnf_b = s->out ? s->lnf_beta : nullptr;
-    a.out = s->out; a.ld_out = s->ld_out; a.col_out = s->col_out;
     a.ts = g_attn_ts_which == 7 ? g_attn_ts : nullptr;
-    for (int i = 0; i < CR_STACK_MAX_BLOCKS; ++i) {
-        const int j = i < s->n_blocks ? i : 0;
-        a.blk[i].bd = s->blocks[j];
-        a.blk[i].ad = s->attn[j];
-    }
+    a.ld_out = s->ld_out; a.col_out = s->col_out;
     const bool split = a0.precision == CR_PREC_BF16X3;
+    const bool pair = a0.B <= g_stack_pair_max_b && a.nkt >= 2;
     hipStream_t st = cr_stream(stream);
-    if (a.nkt <= 4) return split ? launch_stack<4, true>(a, a0.B, st) : launch_stack<4, false>(a, a0.B, st);
-    if (a.nkt <= 8) return split ? launch_stack<8, true>(a, a0.B, st) : launch_stack<8, false>(a, a0.B, st);
-    if (a.nkt <= 13) return split ? launch_stack<13, true>(a, a0.B, st) : launch_stack<13, false>(a, a0.B, st);
-    return split ? launch_stack<16, true>(a, a0.B, st) : launch_stack<16, false>(a, a0.B, st);
+    const int per = pair ? 1 : s->n_blocks;               // blocks per launch
+    for (int i0 = 0; i0 < s->n_blocks; i0 += per) {
+        const bool fin = i0 + per >= s->n_blocks && s->out != nullptr;
+        a.nb = per;
+        a.lnf_g = fin ? s->lnf_gamma : nullptr; a.lnf_b = fin ? s->lnf_beta : nullptr;
+        a.out = fin ? s->out : nullptr;
+        for (int i = 0; i < CR_STACK_MAX_BLOCKS; ++i) {
+            const int j = i < per ? i0 + i : i0;
+            a.blk[i].bd = s->blocks[j];
+            a.blk[i].ad = s->attn[j];
+        }
+        int rc = launch_stack_any(a, a0.B, split, pair, st);
+        if (rc) return rc;
+    }
+    return CR_OK;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-wave phase timeline of the whole-stack forward kernel (cr_stack.hip) inside the headline training step
-(cast_1, B = 128, T = 200, D = 50): stamps of the LAST cr_stack_fwd launch of the step (the trunk)."""
+(cast_1, B = 128, T = 200, D = 50): stamps of the LAST cr_stack_fwd launch of the step (the trunk; in pair mode --
+two workgroups per sequence, one launch per block -- its last block)."""
 import ctypes as C, os, sys, types
 os.environ["CASTREC_TIMELINE"] = "1"      # instrumented library: python -m castrec_amd.build --timeline
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,12 +25,14 @@ for _ in range(3):
     eng.launch_step()
 torch.cuda.synchronize()
 NS = 64
-ts = torch.zeros(B * 8 * NS, dtype=torch.int64, device="cuda")
+ts = torch.zeros(2 * B * 8 * NS, dtype=torch.int64, device="cuda")
 fn(ts.data_ptr(), 7)
 eng.launch_step()
 torch.cuda.synchronize()
 fn(None, 0)
-t = ts.cpu().numpy().reshape(B, 8, NS).astype(np.float64)
+t = ts.cpu().numpy().reshape(2 * B, 8, NS).astype(np.float64)
+t = t[t[:, 0, 63] > 0]                              # workgroups that ran (pair mode: 2 B, else B)
+print("workgroups", len(t))
 w0 = t[:, :, 0].min()
 print("kernel span %.1f us (wall clock, first wave start -> last wave end)" % ((t[:, :, 63].max() - w0) * 10.0 / 1e3))
 print("wave start ns p50 %.0f max %.0f" % tuple(np.percentile((t[:, :, 0] - w0) * 10.0, [50, 100])))
