@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcastrec.so")
 LIB_TL = os.path.join(PKG, "libcastrec_tl.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
-           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
+           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -40,7 +40,7 @@ def build(force=False, verbose=False, timeline=False):
     lib = LIB_TL if timeline else LIB
     flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else [])
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
-    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"),
+    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"),
                os.path.join(ROOT, "include", "castrec.h")]
     objs, jobs = [], []
     for s in SOURCES:

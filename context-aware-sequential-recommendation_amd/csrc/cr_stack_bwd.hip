@@ -1,0 +1,598 @@
+// Backward of a block's row phases (the work of cr_block_ln_ffn_bwd and cr_block_ln_qkv_bwd) in register layout R
+// (cr_rlayout.hpp), one workgroup per sequence, bf16 MFMA on split (or plain) operands.
+//
+// Why.  The fp32 kernels of cr_block.hip run 27-35 us per launch at the headline shape and, like every kernel of this
+// step, are bound by instruction issue, not by the matrix pipe (13-20 % busy) or HBM (1.4 TB/s): a 64-row tile goes
+// global -> registers -> LDS -> (ds_read_b32 + v_mfma_f32_16x16x4: 9 instructions per 4 k) -> LDS -> registers -> global
+// with per-element bookkeeping in between and seven workgroup barriers per tile.  Here a wave owns a 16-row tile and
+// the whole chain  dy -> g2 -> g2 W2^T -> ReLU gate -> g1 W1^T + dy -> LayerNorm backward -> d_o  (and the LN1 + Q/K/V
+// one) runs through its registers: g @ W^T is out^T = W g^T, A = rows of the [in][out] weight image (one ds_read_b128
+// per 8 k, the image kept in the k order of the B operand), B = the lane's own registers, D = layout R again.
+//
+// Weight gradients dW = a^T g need the ROW index as k, i.e. operands transposed across lanes: each wave writes its
+// tile of a (with a column of ones planted at column D: row D of dW is then the bias gradient) and of g as bf16 images
+// into LDS, and after a barrier every wave owns two 16 x 16 tiles of dW over ALL rows of the round
+// (v_mfma_f32_16x16x16_bf16, both operands through ds_read_b64_tr_b16).  A sequence is processed in two rounds of up
+// to 7 tiles (one tile per wave and round) so the images of a round fit the LDS next to the weights; the
+// accumulators persist across rounds and sequences, one gradient slab per workgroup, fixed summation order
+// (bitwise reproducible), no atomics.
+//
+// Same inputs, outputs and slab layout as the cr_block_* entry points (castrec.h); results differ from them by the
+// rounding of the split products (~1e-5 relative).  Shapes: D < 64 (the ones column), T <= 224 (two rounds of 7 tiles).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cr_rlayout.hpp"
+
+#define SB_WAVES 8
+#define SB_NT (64 * SB_WAVES)
+#define SB_TPR 7                  // tiles per round (16 rows each)
+#define SB_IMG (SB_TPR * 16 * 64) // bf16 elements of one activation / gradient image
+
+struct SbArgs {
+    cr_block_bwd_desc bd;
+    cr_embed_bwd_desc sc;         // qkv: optional scatter of dx into the embedding tables (see cr_block_ln_qkv_bwd_scatter)
+    int B, T, nkt, scatter;
+    unsigned long long* ts;
+};
+
+#ifdef CR_TIMELINE
+#define SB_TS(slot)                                                                                          \
+    do {                                                                                                     \
+        if (a.ts && (threadIdx.x & 63) == 0)                                                                 \
+            a.ts[((size_t)blockIdx.x * SB_WAVES + (threadIdx.x >> 6)) * 64 + (slot)] =                       \
+                ((slot) == 0 || (slot) == 63) ? wall_clock64() : clock64();                                  \
+    } while (0)
+#else
+#define SB_TS(slot) do { } while (0)
+#endif
+
+// ---- weight [D][D] -> [64][64] image whose columns are in the k order of layout R's B operand -------------
+// position 32 ks + 8 lg + 4 h + r  <->  column 32 ks + 16 h + 4 lg + r: row_frag_l then delivers A[i = row][k] for
+// out^T = W g^T with one 16-byte read per k-step.  An item (row, columns 8 ch .. 8 ch + 7) lands as two 8-byte pieces.
+template <int NWT, int NT, bool SPLIT>
+__device__ __forceinline__ void w_put_perm(__bf16* Wi, WRegs<NWT, NT>& r, int D, W3_PARAMS) {
+    constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;
+#pragma unroll
+    for (int u = 0; u < (NWT * 512 + NT - 1) / NT; ++u) {
+        const int item = tid_now() + NT * u;
+        if (item < NWT * 512) {
+            const int wi = item >> 9, k = (item & 511) >> 3, ch = item & 7;
+            const bool rok = k < D;
+            const bool fix = item_fix(rok, k == D - 1, 8 * ch, D);
+            item_mask(r.v[u], 8 * ch, D, rok, fix);
+            if (__builtin_expect(fix, 0)) {                // one thread per weight
+                const WSrc s = w_pick(wi, W3_ARGS);
+                item_refill(r.v[u], s.p + (size_t)k * s.ld + s.c0, 8 * ch, D);
+            }
+            bf8 h, l;
+            split8<SPLIT>(r.v[u], h, l);
+            const int ks = ch >> 2, c4 = ch & 3, hh = c4 >> 1, lga = 2 * (c4 & 1);
+            const int oa = wi * WST + img_off<2>(k, 4 * ks + lga) + 4 * hh;
+            const int ob = wi * WST + img_off<2>(k, 4 * ks + lga + 1) + 4 * hh;
+            *reinterpret_cast<bf4*>(Wi + oa) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
+            *reinterpret_cast<bf4*>(Wi + ob) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
+            if (SPLIT) {
+                *reinterpret_cast<bf4*>(Wi + oa + ST_WIMG) = __builtin_shufflevector(l, l, 0, 1, 2, 3);
+                *reinterpret_cast<bf4*>(Wi + ob + ST_WIMG) = __builtin_shufflevector(l, l, 4, 5, 6, 7);
+            }
+        }
+    }
+}
+
+// acc (layout R) (+)= g W^T for the permuted [in][out] image W (hi, lo): out^T[in][row] = sum_out W[in][out] g^T[out][row]
+template <bool SPLIT, bool ACC>
+__device__ __forceinline__ void r_gemm_t(f32x4 (&acc)[4], const __bf16* Wh, const __bf16* Wl, const bf8 (&gh)[2], const bf8 (&gl)[2]) {
+    const int lane = lane_now();
+    if (!ACC) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf8 wh[4], wl[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            wh[ct] = row_frag_l(Wh, 16 * ct, ks, lane);
+            wl[ct] = SPLIT ? row_frag_l(Wl, 16 * ct, ks, lane) : wh[ct];
+        }
+        if (SPLIT) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], gh[ks], acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], gl[ks], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], gh[ks], acc[ct], 0, 0, 0);
+    }
+}
+
+// the wave's tile (layout R) -> rows [row0, row0 + 16) of an image in natural column order (read transposed)
+template <bool SPLIT>
+__device__ __forceinline__ void img_put(__bf16* Ih, __bf16* Il, int row0, const f32x4 (&x)[4]) {
+    const int lane = lane_now(), li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        bf4 h, l;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2 v = {x[ct][r], x[ct][r + 1]};
+            const bf2 hh = __builtin_convertvector(v, bf2);
+            h[r] = hh[0]; h[r + 1] = hh[1];
+            if (SPLIT) {
+                const bf2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x2), bf2);
+                l[r] = ll[0]; l[r + 1] = ll[1];
+            }
+        }
+        const int o = img_off<2>(row0 + li, 2 * ct + (lg >> 1)) + 4 * (lg & 1);
+        *reinterpret_cast<bf4*>(Ih + o) = h;
+        if (SPLIT) *reinterpret_cast<bf4*>(Il + o) = l;
+    }
+}
+
+// four rows (k = 4 lg + 0..3 of the tile at row0) of image column 16 jt + li: the K = 16 MFMA's A or B operand
+__device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane) {
+    const int lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<2>(row0 + 4 * lg + q, 2 * jt + (p >> 1)) + 4 * (p & 1)));
+}
+// acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1)
+template <bool SPLIT>
+__device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
+                                            int ntr, int it, int jt0) {
+    const int lane = lane_now();
+#pragma unroll 1
+    for (int t = 0; t < ntr; ++t) {
+        const bf4 ah = tr4(Ah, 16 * t, it, lane);
+        const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;
+        bf4 gh[2], gl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gh[j] = tr4(Gh, 16 * t, jt0 + j, lane);
+            gl[j] = SPLIT ? tr4(Gl, 16 * t, jt0 + j, lane) : gh[j];
+        }
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, gh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gl[j], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gh[j], acc[j], 0, 0, 0);
+    }
+}
+// accumulators D[in = 16 it + 4 lg + r][out = 16 (jt0 + j) + li] -> slab (row pitch ldw); row D is the bias gradient
+__device__ __forceinline__ void wgrad_store(float* dst, int ldw, float* bias_dst, const f32x4 (&acc)[2], int D, int it, int jt0) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = 16 * (jt0 + j) + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * it + 4 * lg + r;
+            if (col < D) {
+                if (k < D) dst[(size_t)k * ldw + col] = acc[j][r];
+                else if (k == D) bias_dst[col] = acc[j][r];
+            }
+        }
+    }
+}
+// plant 1.0 at column D (D < 64) of the lane's row: the bias-gradient row of a^T g
+__device__ __forceinline__ void plant_one(f32x4 (&x)[4], int D) {
+    const int lgb = (lane_now() >> 4) * 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * ct + lgb + r == D) x[ct][r] = 1.0f;
+}
+
+// LayerNorm backward of the lane's row (x pad columns 0, dy pad columns 0, gam zero padded):
+// dx = rstd * (dy g - mean(dy g) - xhat mean(dy g xhat)); ag += dy xhat, ab += dy
+__device__ __forceinline__ void r_ln_bwd(f32x4 (&dx)[4], const f32x4 (&x)[4], const f32x4 (&dy)[4], const float* gam,
+                                         f32x4 (&ag)[4], f32x4 (&ab)[4], const DCtx& dc) {
+    const float invD = 1.0f / (float)dc.D;
+    const float mean = r_rowsum(x) * invD;
+    f32x4 xc[4];
+    float v = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < dc.nfull) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xc[ct][r] = x[ct][r] - mean;
+        } else if (ct == dc.nfull) {
+            const int lgb = (lane_now() >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xc[ct][r] = (lgb + r < dc.rem) ? x[ct][r] - mean : 0.0f;
+        } else {
+            xc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaf(xc[ct][r], xc[ct][r], v);
+    }
+    const float rstd = 1.0f / sqrtf(grp_sum(v) * invD + 1e-8f);
+    f32x4 g[4];
+    r_vec(g, gam);
+    float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xc[ct][r] *= rstd;                                       // xhat (0 in the pad columns)
+            const float dg = dy[ct][r] * g[ct][r];
+            c1 += dg;
+            c2 = fmaf(dg, xc[ct][r], c2);
+            ag[ct][r] = fmaf(dy[ct][r], xc[ct][r], ag[ct][r]);
+            ab[ct][r] += dy[ct][r];
+            dx[ct][r] = dg;
+        }
+    c1 = grp_sum(c1) * invD;
+    c2 = grp_sum(c2) * invD;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < dc.nfull) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dx[ct][r] = rstd * (dx[ct][r] - c1 - xc[ct][r] * c2);
+        } else if (ct == dc.nfull) {
+            const int lgb = (lane_now() >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dx[ct][r] = (lgb + r < dc.rem) ? rstd * (dx[ct][r] - c1 - xc[ct][r] * c2) : 0.0f;
+        } else {
+            dx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+// per-lane LayerNorm-gradient partials (the lane's row, 16 columns) -> sums over the wave's 16 rows -> per-wave LDS
+// slots -> fixed-order sum over the waves -> slab
+__device__ __forceinline__ void ln_grads_store(float* part /* [2][SB_WAVES][64] */, f32x4 (&ag)[4], f32x4 (&ab)[4], float* dg, float* db, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = cr_row16_sum(ag[ct][r]), sb = cr_row16_sum(ab[ct][r]);
+            if (li == 0) {
+                part[wave * 64 + 16 * ct + 4 * lg + r] = sg;
+                part[(SB_WAVES + wave) * 64 + 16 * ct + 4 * lg + r] = sb;
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += SB_NT) {
+        float g = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SB_WAVES; ++w) { g += part[w * 64 + c]; b += part[(SB_WAVES + w) * 64 + c]; }
+        dg[c] = g;
+        db[c] = b;
+    }
+}
+
+// =====================================================================================================
+// LN2 + feed-forward backward:  dy -> d_o, slabs of dW2 db2 dW1 db1 dgamma2 dbeta2, optional attention delta
+// =====================================================================================================
+template <bool SPLIT, int DS>
+__global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
+    const cr_block_bwd_desc& bd = a.bd;
+    const cr_block_desc& d = bd.f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;
+    constexpr int IST = SPLIT ? 2 * SB_IMG : SB_IMG;      // elements of one image slot (hi [, lo])
+    __bf16* Wi = reinterpret_cast<__bf16*>(smem_raw);     // slot 0: W1 (permuted), slot 1: W2
+    __bf16* Im = Wi + 2 * WST;                            // image slots: 0 hid, 1 g2, 2 f_in, 3 g1
+    float* gam = reinterpret_cast<float*>(Im + 4 * IST);  // [64] gamma2, zero padded
+    float* part = gam + 64;                               // [2][SB_WAVES][64]
+    const int D = DS > 0 ? DS : d.D, T = a.T;
+    const DCtx dcx = d_ctx(D);
+    const int wave = threadIdx.x >> 6;
+    SB_TS(0); SB_TS(1);
+    {
+        WRegs<2, SB_NT> w;
+        w_issue<2, SB_NT>(w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        const int t = threadIdx.x;
+        const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
+        w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        if (t < 64) gam[t] = gv;
+    }
+    const DropCtx d2 = drop_ctx(d.drop_ffn2);
+    const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
+    f32x4 aw1[2], aw2[2], ag[4], ab[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
+    const int it = wave >> 1, jt0 = 2 * (wave & 1);       // this wave's tiles of the weight gradients
+    __syncthreads();
+    SB_TS(2);
+#pragma unroll 1
+    for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
+#pragma unroll 1
+        for (int rd = 0; rd < 2; ++rd) {
+            const int tile = rd * SB_TPR + wave;
+            const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);       // tiles of this round (wave-uniform, may be <= 0)
+            if (wave < ntr) {
+                const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
+                const int q = 16 * tile + li;
+                const bool rok = q < T;
+                const int m = n * T + min(q, T - 1);
+                const u32 mo = (u32)m * (u32)(4 * D);
+                RRaw rdy, rhid, rfin, ro, rq;
+                r_issue(rdy, bd.dy, mo, dcx);
+                r_issue(rhid, d.hid, mo, dcx);
+                r_issue(rfin, d.f_in, mo, dcx);
+                r_issue(ro, d.o, mo, dcx);
+                if (bd.attn_delta) r_issue(rq, d.q_in, mo, dcx);
+                const float msk = (rok && d.mask_ids[m] != 0) ? 1.0f : 0.0f;    // rows beyond T contribute nothing
+                f32x4 dy[4], g2[4], hid[4];
+                r_finish(dy, rdy, dcx);
+                // g2 = dy * mask * keep2 / (1 - rate) (sasrec.py:83, modules.py:309-310)
+                const uint32_t e2 = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + d2.key;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dy[ct][r] *= msk;
+                        float v = dy[ct][r];
+                        if (d2.on) v *= drop_factor_x(d2, e2 + (uint32_t)(16 * ct + r) * CR_PHI);
+                        g2[ct][r] = v;
+                    }
+                r_finish(hid, rhid, dcx);
+                img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, g2);
+                {
+                    f32x4 h1[4];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) h1[ct] = hid[ct];
+                    plant_one(h1, D);
+                    img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, h1);
+                }
+                // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (modules.py:300-304)
+                bf8 gh[2], gl[2];
+                f32x4 g1[4];
+                r_split<SPLIT>(g2, gh, gl);
+                r_gemm_t<SPLIT, false>(g1, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g1[ct][r] = (hid[ct][r] > 0.0f) ? g1[ct][r] * scale1 : 0.0f;
+                img_put<SPLIT>(Im + 3 * IST, Im + 3 * IST + SB_IMG, 16 * wave, g1);
+                {
+                    f32x4 fin[4];
+                    r_finish(fin, rfin, dcx);
+                    plant_one(fin, D);
+                    img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, fin);
+                }
+                // df = g1 W1^T + dy * mask (residual of modules.py:313)
+                f32x4 df[4];
+                r_split<SPLIT>(g1, gh, gl);
+                r_gemm_t<SPLIT, false>(df, Wi, Wi + ST_WIMG, gh, gl);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) df[ct] += dy[ct];
+                // LN2 backward: x = o, dy = df -> d_o
+                f32x4 o[4], dout[4];
+                r_finish(o, ro, dcx);
+                r_ln_bwd(dout, o, df, gam, ag, ab, dcx);
+                r_store(bd.d_o, mo, dout, rok, dcx);
+                if (bd.attn_delta) {
+                    // delta[m] = sum_c d_o[m][c] * (o[m][c] - q_in[m][c]) (the attention core's output is o - q_in, modules.py:262-269)
+                    f32x4 qin[4];
+                    r_finish(qin, rq, dcx);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc);
+                    acc = grp_sum(acc);
+                    if (lg == 0 && rok) bd.attn_delta[m] = acc;
+                }
+            }
+            __syncthreads();
+            if (ntr > 0) {
+                wgrad_accum<SPLIT>(aw2, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
+                wgrad_accum<SPLIT>(aw1, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+            }
+            __syncthreads();
+        }
+    }
+    SB_TS(10);
+    const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+    wgrad_store(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, it, jt0);
+    wgrad_store(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, it, jt0);
+    ln_grads_store(part, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
+    SB_TS(63);
+}
+
+// =====================================================================================================
+// LN1 + Q/K/V projections backward:  (dQ|dK|dV, d_o) -> dx (= or +=), slabs of dWqkv dbqkv dgamma1 dbeta1
+// =====================================================================================================
+template <bool SPLIT, int DS>
+__global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
+    const cr_block_bwd_desc& bd = a.bd;
+    const cr_block_desc& d = bd.f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;
+    constexpr int IST = SPLIT ? 2 * SB_IMG : SB_IMG;
+    __bf16* Wi = reinterpret_cast<__bf16*>(smem_raw);     // Wq, Wk, Wv (permuted)
+    __bf16* Im = Wi + 3 * WST;                            // image slots: first {q_in, dQ}, then {x, dK, dV}
+    float* gam = reinterpret_cast<float*>(Im + 3 * IST);  // [64] gamma1
+    float* part = gam + 64;
+    const int D = DS > 0 ? DS : d.D, T = a.T;
+    const DCtx dcx = d_ctx(D);
+    const int wave = threadIdx.x >> 6;
+    const size_t MD = (size_t)d.M * D;
+    {
+        WRegs<3, SB_NT> w;
+        w_issue<3, SB_NT>(w, D, d.wqkv, 3 * D, 0, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D);
+        const int t = threadIdx.x;
+        const float gv = (t < D) ? d.ln1_g[t] : 0.0f;
+        w_put_perm<3, SB_NT, SPLIT>(Wi, w, D, d.wqkv, 3 * D, 0, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D);
+        if (t < 64) gam[t] = gv;
+    }
+    f32x4 awq[2], awk[2], awv[2], ag[4], ab[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awk[j] = awq[j]; awv[j] = awq[j]; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
+    const int it = wave >> 1, jt0 = 2 * (wave & 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
+#pragma unroll 1
+        for (int rd = 0; rd < 2; ++rd) {
+            const int tile = rd * SB_TPR + wave;
+            const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
+            const bool active = wave < ntr;
+            f32x4 x[4], dK[4], dV[4];                     // kept for the second image phase
+            if (active) {
+                const int ln = lane_now(), li = ln & 15;
+                const int q = 16 * tile + li;
+                const bool rok = q < T;
+                const int m = n * T + min(q, T - 1);
+                const u32 mo = (u32)m * (u32)(4 * D);
+                RRaw rdq, rdk, rdv, rqin, rx, rdo, rdx;
+                r_issue(rdq, bd.dqkv, mo, dcx, rok);                 // rows beyond T: zero gradients
+                r_issue(rqin, d.q_in, mo, dcx);
+                r_issue(rdo, bd.d_o, mo, dcx, rok);
+                r_issue(rdk, bd.dqkv + MD, mo, dcx, rok);
+                r_issue(rdv, bd.dqkv + 2 * MD, mo, dcx, rok);
+                r_issue(rx, d.x, mo, dcx);
+                if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
+                f32x4 dQ[4], dqin[4], dxp[4];
+                bf8 gh[2], gl[2];
+                r_finish(dQ, rdq, dcx);
+                img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, dQ);
+                {
+                    f32x4 qin[4];
+                    r_finish(qin, rqin, dcx);
+                    plant_one(qin, D);
+                    img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, qin);
+                }
+                // dq_in = dQ Wq^T + d_o (residual branch, modules.py:269)
+                r_split<SPLIT>(dQ, gh, gl);
+                r_gemm_t<SPLIT, false>(dqin, Wi, Wi + ST_WIMG, gh, gl);
+                {
+                    f32x4 dob[4];
+                    r_finish(dob, rdo, dcx);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) dqin[ct] += dob[ct];
+                }
+                // dx_part = dK Wk^T + dV Wv^T
+                r_finish(dK, rdk, dcx);
+                r_split<SPLIT>(dK, gh, gl);
+                r_gemm_t<SPLIT, false>(dxp, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
+                r_finish(dV, rdv, dcx);
+                r_split<SPLIT>(dV, gh, gl);
+                r_gemm_t<SPLIT, true>(dxp, Wi + 2 * WST, Wi + 2 * WST + ST_WIMG, gh, gl);
+                // dx = dx_part + LN1 backward(dq_in; x)
+                r_finish(x, rx, dcx);
+                f32x4 dxl[4];
+                r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) dxl[ct] += dxp[ct];
+                if (bd.dx_accumulate) {
+                    f32x4 old[4];
+                    r_finish(old, rdx, dcx);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) dxl[ct] += old[ct];
+                }
+                r_store(bd.dx, mo, dxl, rok, dcx);
+            }
+            __syncthreads();
+            if (ntr > 0) wgrad_accum<SPLIT>(awq, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
+            __syncthreads();
+            if (active) {
+                plant_one(x, D);
+                img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, x);
+                img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, dK);
+                img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, dV);
+            }
+            __syncthreads();
+            if (ntr > 0) {
+                wgrad_accum<SPLIT>(awk, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
+                wgrad_accum<SPLIT>(awv, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
+            }
+            __syncthreads();
+        }
+    }
+    const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+    wgrad_store(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0);
+    wgrad_store(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0);
+    wgrad_store(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0);
+    ln_grads_store(part, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static const char* sb_unsupported(const cr_block_bwd_desc* bd, int B, int T, int precision) {
+    if (!bd) return "NULL description";
+    const cr_block_desc& d = bd->f;
+    if (d.D < 8 || d.D >= 64) return "hidden size 8..63 (a spare column carries the bias gradients)";
+    if (precision != CR_PREC_BF16X3 && precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
+    if (B < 1 || T < 1 || d.M != B * T) return "M = B T";
+    if ((T + 15) / 16 > 2 * SB_TPR) return "T <= 224 (two rounds of 7 row tiles)";
+    if ((size_t)d.M * d.D * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
+    if (bd->n_slabs < 1) return "n_slabs";
+    return nullptr;
+}
+extern "C" int cr_stack_bwd_supported(const cr_block_bwd_desc* bd, int B, int T, int precision) {
+    return sb_unsupported(bd, B, T, precision) == nullptr;
+}
+
+static size_t sb_lds(int nw, int nimg, bool split) {
+    return (size_t)nw * ST_WIMG * 2 * (split ? 2 : 1) + (size_t)nimg * SB_IMG * 2 * (split ? 2 : 1) + 64 * 4 + 2 * SB_WAVES * 64 * 4;
+}
+
+template <bool SPLIT, int DS>
+static int launch_ffn_bwd(const SbArgs& a, hipStream_t s) {
+    static cr_devmask attr = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_ffn_bwd<SPLIT, DS>), &attr);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stack_ffn_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(2, 4, SPLIT), s, a);
+    return cr_check_launch("cr_stack_ffn_bwd");
+}
+template <bool SPLIT, int DS>
+static int launch_qkv_bwd(const SbArgs& a, hipStream_t s) {
+    static cr_devmask attr = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_qkv_bwd<SPLIT, DS>), &attr);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stack_qkv_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(3, 3, SPLIT), s, a);
+    return cr_check_launch("cr_stack_qkv_bwd");
+}
+
+static int sb_args(SbArgs* a, const cr_block_bwd_desc* bd, int B, int T, int precision, const char* who) {
+    const char* why = sb_unsupported(bd, B, T, precision);
+    CR_REQUIRE(why == nullptr, "%s: unsupported (%s)", who, why ? why : "");
+    memset(static_cast<void*>(a), 0, sizeof(*a));
+    a->bd = *bd;
+    a->B = B; a->T = T; a->nkt = (T + 15) / 16;
+    a->ts = nullptr;
+    return CR_OK;
+}
+
+extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+    SbArgs a;
+    int rc = sb_args(&a, bd, B, T, precision, "cr_stack_ffn_bwd");
+    if (rc) return rc;
+    const cr_block_desc* d = &bd->f;
+    CR_REQUIRE(bd->dy && bd->d_o && d->hid && d->f_in && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_stack_ffn_bwd: NULL pointer");
+    CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b, "cr_stack_ffn_bwd: NULL gradient pointer");
+    CR_REQUIRE(bd->attn_delta == nullptr || d->q_in != nullptr, "cr_stack_ffn_bwd: attn_delta needs q_in");
+    a.ts = g_attn_ts_which == 8 ? g_attn_ts : nullptr;
+    const bool split = precision == CR_PREC_BF16X3;
+    hipStream_t s = cr_stream(stream);
+    if (d->D == 50) return split ? launch_ffn_bwd<true, 50>(a, s) : launch_ffn_bwd<false, 50>(a, s);
+    return split ? launch_ffn_bwd<true, 0>(a, s) : launch_ffn_bwd<false, 0>(a, s);
+}
+
+extern "C" int cr_stack_qkv_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+    SbArgs a;
+    int rc = sb_args(&a, bd, B, T, precision, "cr_stack_qkv_bwd");
+    if (rc) return rc;
+    const cr_block_desc* d = &bd->f;
+    CR_REQUIRE(bd->dqkv && bd->d_o && bd->dx && d->q_in && d->x && d->wqkv && d->ln1_g, "cr_stack_qkv_bwd: NULL pointer");
+    CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b, "cr_stack_qkv_bwd: NULL gradient pointer");
+    CR_REQUIRE(bd->dq_part == nullptr, "cr_stack_qkv_bwd: dq_part (single-pass fp32 attention backward) is not taken");
+    const bool split = precision == CR_PREC_BF16X3;
+    hipStream_t s = cr_stream(stream);
+    if (d->D == 50) return split ? launch_qkv_bwd<true, 50>(a, s) : launch_qkv_bwd<false, 50>(a, s);
+    return split ? launch_qkv_bwd<true, 0>(a, s) : launch_qkv_bwd<false, 0>(a, s);
+}

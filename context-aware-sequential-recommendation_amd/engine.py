@@ -203,6 +203,7 @@ class Engine:
         self.fuse_tails = os.environ.get("CASTREC_NO_TAILS") != "1"
         self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
         self.fuse_stack = os.environ.get("CASTREC_NO_STACK_KERNEL") != "1"
+        self.fuse_stack_bwd = os.environ.get("CASTREC_NO_STACK_BWD") != "1"
         self._pending_embed = {}
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
@@ -617,12 +618,20 @@ class Engine:
                 delta = self.vec("attn_delta", M)
                 bbd.attn_delta = delta.data_ptr()
                 abd.delta = delta.data_ptr()
-            self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
+            # bf16 arithmetic: the row phases run on the register-layout kernels (cr_stack_bwd.hip) where they take the shape
+            prec = ATTN_PRECISIONS[self.attn_precision]
+            rows_bf = bool(self.fuse_stack_bwd and bf and not one_pass and L.lib.cr_stack_bwd_supported(C.byref(bbd), B, T, prec))
+            if rows_bf:
+                self._call(lst, "cr_stack_ffn_bwd", C.byref(bbd), B, T, prec)
+            else:
+                self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             recipe = self._scatter_recipe.get(x.data_ptr())
             if recipe is not None and not bbd.dx_accumulate:
                 self._scatter_claimed.add(x.data_ptr())
                 self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()))
+            elif rows_bf:
+                self._call(lst, "cr_stack_qkv_bwd", C.byref(bbd), B, T, prec)
             else:
                 self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst

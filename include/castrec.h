@@ -308,6 +308,14 @@ typedef struct {
 int cr_block_ln_ffn_bwd(const cr_block_bwd_desc* d, void* stream);
 int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
 
+/* The same two backward steps on the bf16 matrix pipe, one workgroup per sequence, rows in registers (cr_stack_bwd.hip):
+ * same description, inputs, outputs and slab layout as cr_block_ln_ffn_bwd / cr_block_ln_qkv_bwd (dq_part must be NULL);
+ * results equal theirs up to the rounding of the split products.  B, T: the sequences behind the M = B * T rows;
+ * precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Shapes: 8 <= D < 64, T <= 224 (cr_stack_bwd_supported). */
+int cr_stack_bwd_supported(const cr_block_bwd_desc* d, int B, int T, int precision);   /* 1 / 0 */
+int cr_stack_ffn_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
+int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
+
 /* cr_block_ln_qkv_bwd of a stack's FIRST block whose input x was composed by an embedding gather: instead of
  * storing dx the kernel applies that gather's backward to its rows (cr_embed_bwd, large-table mode): `sc` is the
  * descriptor that call would have taken (sc->f.out is ignored; no small-table slabs; d_addend dense [M, D]);

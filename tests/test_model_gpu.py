@@ -288,6 +288,43 @@ def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, m
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * gmax, k
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("env,T,D,B", [("CASTREC_NO_STACK_BWD", 40, 50, 6), ("CASTREC_NO_STACK_BWD", 200, 50, 3), ("CASTREC_NO_STACK_BWD", 33, 24, 5),
+                                       ("CASTREC_NO_STACK_KERNEL", 40, 50, 6), ("CASTREC_NO_STACK_KERNEL", 200, 50, 3), ("CASTREC_NO_STACK_KERNEL", 33, 24, 5)])
+def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, env, T, D, B):
+    """The whole-stack forward (cr_stack.hip) and the register-layout row-phase backward (cr_stack_bwd.hip) against the
+    kernels they replace (cr_block_* + cr_attn_fwd): same parameters, same batch, dropout on, n_slabs below AND above the
+    batch size.  Same mathematics; the projections / feed-forward / weight gradients run on split bf16 products here and on
+    fp32 MFMA there, so the two differ by the rounding of those products: 1e-4 of the tensor scale for the split form
+    (measured 2e-5); plain bf16 rounds every operand to 8 bits, at different places on the two paths: 3e-2 on the
+    activations, 1e-1 on the gradients (ReLU gates of near-zero units flip; measured 4.5e-2)."""
+    rs = np.random.RandomState(5)
+    itemnum, max_bins = 45, 9
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=max_bins, seed=13)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
+    monkeypatch.setenv(env, "1")
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
+    monkeypatch.delenv(env)
+    names = lambda e: [n for n, _, _ in e.fwd + e.bwd]
+    new = "cr_stack_fwd" if env == "CASTREC_NO_STACK_KERNEL" else "cr_stack_ffn_bwd"
+    assert new in names(a) and new not in names(b)
+    a.P.add_(0.05 * torch.randn(a.P.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
+    b.P.copy_(a.P)
+    batch = make_batch(rs, B, T, itemnum, max_bins)
+    for eng in (a, b):
+        eng.set_batch(*batch)
+        eng.launch_step(apply=False)
+    torch.cuda.synchronize()
+    tol = 1e-4 if prec == "bf16x3" else 3e-2
+    assert float((a.seq_emb - b.seq_emb).abs().max()) <= tol * float(b.seq_emb.abs().max())
+    sa, sb = a.state.cpu().numpy(), b.state.cpu().numpy()
+    assert sa[2] == sb[2] and sa[0] == pytest.approx(sb[0], rel=tol)
+    ga, gb = a.grads(), b.grads()
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1) * gmax, k
+
+
 def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None):
     tol = TOL[prec]
     rs = np.random.RandomState(D + T)
