@@ -141,24 +141,26 @@ template <bool SPLIT>
 __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
                                             int ntr, int it, int jt0) {
     const int lane = lane_now();
-#pragma unroll 1
-    for (int t = 0; t < ntr; ++t) {
-        const bf4 ah = tr4(Ah, 16 * t, it, lane);
-        const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;
-        bf4 gh[2], gl[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            gh[j] = tr4(Gh, 16 * t, jt0 + j, lane);
-            gl[j] = SPLIT ? tr4(Gl, 16 * t, jt0 + j, lane) : gh[j];
+    for (int t = 0; t < SB_TPR; ++t) {                   // unrolled, wave-uniform guard: several tiles' reads in flight
+        if (t < ntr) {
+            const bf4 ah = tr4(Ah, 16 * t, it, lane);
+            const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;
+            bf4 gh[2], gl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                gh[j] = tr4(Gh, 16 * t, jt0 + j, lane);
+                gl[j] = SPLIT ? tr4(Gl, 16 * t, jt0 + j, lane) : gh[j];
+            }
+            if (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, gh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gl[j], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gh[j], acc[j], 0, 0, 0);
         }
-        if (SPLIT) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, gh[j], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gl[j], acc[j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gh[j], acc[j], 0, 0, 0);
     }
 }
 // accumulators D[in = 16 it + 4 lg + r][out = 16 (jt0 + j) + li] -> slab (row pitch ldw); row D is the bias gradient
@@ -285,14 +287,6 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     const DCtx dcx = d_ctx(D);
     const int wave = threadIdx.x >> 6;
     SB_TS(0); SB_TS(1);
-    {
-        WRegs<2, SB_NT> w;
-        w_issue<2, SB_NT>(w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
-        const int t = threadIdx.x;
-        const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
-        w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
-        if (t < 64) gam[t] = gv;
-    }
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
     f32x4 aw1[2], aw2[2], ag[4], ab[4];
@@ -301,26 +295,52 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);       // this wave's tiles of the weight gradients
+    // work items of this workgroup: (sequence n, round rd), n = blockIdx.x, + gridDim.x, ...; the inputs of the NEXT
+    // item's tile are requested before the weight-gradient phase of the current one (and the first before the weights
+    // are staged): a tile's five row blocks come from HBM, 2-3 us that nothing else would cover
+    RRaw rdy, rhid, rfin, ro, rq;
+    auto tile_rows = [&](int n, int rd, int& m, bool& rok) {
+        const int q = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
+        rok = q < T;
+        m = n * T + min(q, T - 1);
+    };
+    auto issue = [&](int n, int rd) {
+        if (n < a.B && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+            int m; bool rok;
+            tile_rows(n, rd, m, rok);
+            const u32 mo = (u32)m * (u32)(4 * D);
+            r_issue(rdy, bd.dy, mo, dcx);
+            r_issue(rhid, d.hid, mo, dcx);
+            r_issue(rfin, d.f_in, mo, dcx);
+            r_issue(ro, d.o, mo, dcx);
+            if (bd.attn_delta) r_issue(rq, d.q_in, mo, dcx);
+        }
+    };
+    // (memory returns in order: the weights are requested first, or their staging would wait for the tile as well)
+    const int R = a.nkt > SB_TPR ? 2 : 1, nitems = R * a.B;
+    {
+        WRegs<2, SB_NT> w;
+        w_issue<2, SB_NT>(w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        const int t = threadIdx.x;
+        const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
+        if ((int)blockIdx.x < nitems) issue((int)blockIdx.x / R, (int)blockIdx.x % R);
+        w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        if (t < 64) gam[t] = gv;
+    }
     __syncthreads();
     SB_TS(2);
+    // work items (sequence n, round rd) are dealt round-robin to the workgroups: with n_slabs >= R * B every workgroup
+    // runs ONE round (B = 128 sequences of 13 tiles on 256 CUs)
 #pragma unroll 1
-    for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
-#pragma unroll 1
-        for (int rd = 0; rd < 2; ++rd) {
-            const int tile = rd * SB_TPR + wave;
-            const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);       // tiles of this round (wave-uniform, may be <= 0)
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        {
+            const int n = item / R, rd = item % R;
+            const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);       // tiles of this round (wave-uniform)
             if (wave < ntr) {
-                const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
-                const int q = 16 * tile + li;
-                const bool rok = q < T;
-                const int m = n * T + min(q, T - 1);
+                const int lg = lane_now() >> 4;
+                int m; bool rok;
+                tile_rows(n, rd, m, rok);
                 const u32 mo = (u32)m * (u32)(4 * D);
-                RRaw rdy, rhid, rfin, ro, rq;
-                r_issue(rdy, bd.dy, mo, dcx);
-                r_issue(rhid, d.hid, mo, dcx);
-                r_issue(rfin, d.f_in, mo, dcx);
-                r_issue(ro, d.o, mo, dcx);
-                if (bd.attn_delta) r_issue(rq, d.q_in, mo, dcx);
                 const float msk = (rok && d.mask_ids[m] != 0) ? 1.0f : 0.0f;    // rows beyond T contribute nothing
                 f32x4 dy[4], g2[4], hid[4];
                 r_finish(dy, rdy, dcx);
@@ -384,18 +404,22 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
                     if (lg == 0 && rok) bd.attn_delta[m] = acc;
                 }
             }
+            if (item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
+            SB_TS(3);
             __syncthreads();
-            if (ntr > 0) {
-                wgrad_accum<SPLIT>(aw2, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
-                wgrad_accum<SPLIT>(aw1, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
-            }
+            SB_TS(4);
+            wgrad_accum<SPLIT>(aw2, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
+            wgrad_accum<SPLIT>(aw1, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+            SB_TS(5);
             __syncthreads();
+            SB_TS(6);
         }
     }
     SB_TS(10);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     wgrad_store(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, it, jt0);
     wgrad_store(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, it, jt0);
+    SB_TS(11);
     ln_grads_store(part, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
     SB_TS(63);
 }
@@ -418,11 +442,34 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
     const DCtx dcx = d_ctx(D);
     const int wave = threadIdx.x >> 6;
     const size_t MD = (size_t)d.M * D;
+    // the next work item's first inputs (dQ, q_in, d_o, dK) are requested ahead, as in the feed-forward kernel; dV, x
+    // (and the old dx) follow at the head of the item, under its first product.  (Not in the generic-D build: its
+    // column-tile predicates are live values too, and the look-ahead registers on top of them spilled 270.)
+    constexpr bool PF = DS > 0;
+    RRaw rdq, rqin, rdo, rdk;
+    auto tile_rows = [&](int n, int rd, int& m, bool& rok) {
+        const int q = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
+        rok = q < T;
+        m = n * T + min(q, T - 1);
+    };
+    auto issue = [&](int n, int rd) {
+        if (n < a.B && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+            int m; bool rok;
+            tile_rows(n, rd, m, rok);
+            const u32 mo = (u32)m * (u32)(4 * D);
+            r_issue(rdq, bd.dqkv, mo, dcx, rok);                     // rows beyond T: zero gradients
+            r_issue(rqin, d.q_in, mo, dcx);
+            r_issue(rdo, bd.d_o, mo, dcx, rok);
+            r_issue(rdk, bd.dqkv + MD, mo, dcx, rok);
+        }
+    };
+    const int R = a.nkt > SB_TPR ? 2 : 1, nitems = R * a.B;
     {
         WRegs<3, SB_NT> w;
         w_issue<3, SB_NT>(w, D, d.wqkv, 3 * D, 0, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D);
         const int t = threadIdx.x;
         const float gv = (t < D) ? d.ln1_g[t] : 0.0f;
+        if (PF && (int)blockIdx.x < nitems) issue((int)blockIdx.x / R, (int)blockIdx.x % R);
         w_put_perm<3, SB_NT, SPLIT>(Wi, w, D, d.wqkv, 3 * D, 0, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D);
         if (t < 64) gam[t] = gv;
     }
@@ -434,24 +481,18 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
     __syncthreads();
 #pragma unroll 1
-    for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
-#pragma unroll 1
-        for (int rd = 0; rd < 2; ++rd) {
-            const int tile = rd * SB_TPR + wave;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        {
+            const int n = item / R, rd = item % R;
             const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
             const bool active = wave < ntr;
             f32x4 x[4], dK[4], dV[4];                     // kept for the second image phase
+            if (!PF) issue(n, rd);
             if (active) {
-                const int ln = lane_now(), li = ln & 15;
-                const int q = 16 * tile + li;
-                const bool rok = q < T;
-                const int m = n * T + min(q, T - 1);
+                int m; bool rok;
+                tile_rows(n, rd, m, rok);
                 const u32 mo = (u32)m * (u32)(4 * D);
-                RRaw rdq, rdk, rdv, rqin, rx, rdo, rdx;
-                r_issue(rdq, bd.dqkv, mo, dcx, rok);                 // rows beyond T: zero gradients
-                r_issue(rqin, d.q_in, mo, dcx);
-                r_issue(rdo, bd.d_o, mo, dcx, rok);
-                r_issue(rdk, bd.dqkv + MD, mo, dcx, rok);
+                RRaw rdv, rx, rdx;
                 r_issue(rdv, bd.dqkv + 2 * MD, mo, dcx, rok);
                 r_issue(rx, d.x, mo, dcx);
                 if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
@@ -495,8 +536,9 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
                 }
                 r_store(bd.dx, mo, dxl, rok, dcx);
             }
+            if (PF && item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
             __syncthreads();
-            if (ntr > 0) wgrad_accum<SPLIT>(awq, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
+            wgrad_accum<SPLIT>(awq, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
             __syncthreads();
             if (active) {
                 plant_one(x, D);
@@ -505,10 +547,8 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
                 img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, dV);
             }
             __syncthreads();
-            if (ntr > 0) {
-                wgrad_accum<SPLIT>(awk, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
-                wgrad_accum<SPLIT>(awv, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
-            }
+            wgrad_accum<SPLIT>(awk, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
+            wgrad_accum<SPLIT>(awv, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
             __syncthreads();
         }
     }

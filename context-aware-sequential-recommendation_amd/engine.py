@@ -218,6 +218,13 @@ class Engine:
         lay = self.layout
         if not n_slabs:
             n_slabs = auto_slabs(batch_size * hp.maxlen)
+            # the register-layout backward kernels (cr_stack_bwd.hip) deal (sequence, round) items to the slab workgroups:
+            # with a slab per item every workgroup runs one round (B = 128 sequences of 13 tiles: 256 workgroups, 256 CUs)
+            if (self.fused and self.attn_precision != "f32" and self.H == 1 and 8 <= self.D < 64 and self.T <= 224
+                    and os.environ.get("CASTREC_NO_STACK_BWD") != "1"):
+                items = batch_size * (2 if self.T > 112 else 1)
+                if n_slabs < items <= 512:
+                    n_slabs = items
         self.n_slabs = n_slabs
         f32 = dict(dtype=torch.float32, device=self.dev)
         if share is not None:

@@ -26,7 +26,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 NS = 64
 ts = torch.zeros(2 * B * 8 * NS, dtype=torch.int64, device="cuda")
-fn(ts.data_ptr(), 7)
+WHICH = int(os.environ.get("WHICH", "7"))      # 7: cr_stack_fwd, 8: cr_stack_ffn_bwd
+fn(ts.data_ptr(), WHICH)
 eng.launch_step()
 torch.cuda.synchronize()
 fn(None, 0)
@@ -36,6 +37,20 @@ print("workgroups", len(t))
 w0 = t[:, :, 0].min()
 print("kernel span %.1f us (wall clock, first wave start -> last wave end)" % ((t[:, :, 63].max() - w0) * 10.0 / 1e3))
 print("wave start ns p50 %.0f max %.0f" % tuple(np.percentile((t[:, :, 0] - w0) * 10.0, [50, 100])))
+if WHICH == 8:
+    nm = {2: "weights staged (barrier)", 3: "round 0 tile", 4: "barrier", 5: "round 0 weight gradients", 6: "barrier", 7: "round 1 tile", 8: "barrier",
+          9: "round 1 weight gradients", 10: "barrier", 11: "slab stores", 63: "LayerNorm gradient fold + store"}
+    for wave in (0, 3, 6, 7):
+        print("-- wave", wave)
+        prev = t[:, wave, 1]
+        for k in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            cur = t[:, wave, k]
+            ok = (cur > 0) & (prev > 0)
+            if ok.sum():
+                dlt = (cur - prev)[ok]
+                print("  %-34s median %7.0f clk (%5.2f us)  p90 %7.0f" % (nm[k], np.median(dlt), np.median(dlt) / 2.4e3, np.percentile(dlt, 90)))
+            prev = np.where(cur > 0, cur, prev)
+    sys.exit(0)
 names = {0: "weights staged (barrier)", 1: "phase A first tile", 2: "phase A all tiles", 3: "W1/W2 staged (2 barriers)",
          4: "scores + softmax (first tile)", 5: "A V + o (first tile)", 6: "LN2 + FFN (first tile)", 8: "all tiles done"}
 for wave in (0, 3, 7):
