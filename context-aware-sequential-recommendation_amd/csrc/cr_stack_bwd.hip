@@ -438,6 +438,8 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
     __bf16* Im = Wi + 3 * WST;                            // image slots: first {q_in, dQ}, then {x, dK, dV}
     float* gam = reinterpret_cast<float*>(Im + 3 * IST);  // [64] gamma1
     float* part = gam + 64;
+    // scatter: fp32 scratch [7 waves][16][64]: split build: image slot 2 (free until the second image phase); else appended
+    float* scat = SPLIT ? reinterpret_cast<float*>(Im + 2 * IST) : part + 2 * SB_WAVES * 64;
     const int D = DS > 0 ? DS : d.D, T = a.T;
     const DCtx dcx = d_ctx(D);
     const int wave = threadIdx.x >> 6;
@@ -534,7 +536,49 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) dxl[ct] += old[ct];
                 }
-                r_store(bd.dx, mo, dxl, rok, dcx);
+                if (!a.scatter) {
+                    r_store(bd.dx, mo, dxl, rok, dcx);
+                } else {
+                    // x was composed by an embedding gather (cr_embed_fwd): its backward applied to the tile right here instead
+                    // of storing dx (see cr_block_ln_qkv_bwd_scatter).  g = dx * mask with the gather's dropout regenerated;
+                    // d_addend straight from the registers; for the table rows the tile goes through a wave-private fp32
+                    // scratch (the image slot the second phase fills later) so that one row = one contiguous float-atomic burst.
+                    const cr_embed_desc& e = a.sc.f;
+                    const DropCtx dce = drop_ctx(e.drop);
+                    const int ln = lane_now(), li = ln & 15, lg = ln >> 4;
+                    const int mk = e.mask_ids ? e.mask_ids[m] : 1;
+                    const float kf = (rok && mk != 0) ? 1.0f : 0.0f;
+                    const uint32_t eb = ((e.drop.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + dce.key;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = dxl[ct][r] * kf;
+                            if (dce.on) v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
+                            dxl[ct][r] = v;
+                        }
+                    if (a.sc.d_addend) r_store(a.sc.d_addend, mo, dxl, rok, dcx);
+                    if (a.sc.table_grad || a.sc.pos_grad) {
+                        float* scr = scat + wave * (16 * 64);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)     // 16-byte piece (4 ct + lg) of row li, XOR-ed with li: conflict-free both ways
+                            *reinterpret_cast<float4*>(scr + li * 64 + 4 * ((4 * ct + lg) ^ li)) = make_float4(dxl[ct][0], dxl[ct][1], dxl[ct][2], dxl[ct][3]);
+                        const int my_id = e.ids[m];                                  // lanes 0..15: the id of row li
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int nr = min(16, T - 16 * (rd * SB_TPR + wave));
+                        const int col = ln;
+#pragma unroll 4
+                        for (int r = 0; r < nr; ++r) {
+                            const int id = __shfl(my_id, r, 64);
+                            const float g = scr[r * 64 + 4 * ((col >> 2) ^ r) + (col & 3)];
+                            if (col < D) {
+                                if (a.sc.table_grad && !(e.zero_pad && id == 0)) atomicAdd(a.sc.table_grad + (size_t)id * D + col, g * e.scale);
+                                if (a.sc.pos_grad) atomicAdd(a.sc.pos_grad + (size_t)((n * T + 16 * (rd * SB_TPR + wave) + r) % e.T) * D + col, g);
+                            }
+                        }
+                    }
+                }
             }
             if (PF && item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
             __syncthreads();
@@ -594,7 +638,7 @@ static int launch_qkv_bwd(const SbArgs& a, hipStream_t s) {
     static cr_devmask attr = 0;
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_qkv_bwd<SPLIT, DS>), &attr);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_qkv_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(3, 3, SPLIT), s, a);
+    hipLaunchKernelGGL((k_stack_qkv_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(3, 3, SPLIT) + ((a.scatter && !SPLIT) ? (size_t)SB_TPR * 16 * 64 * 4 : 0), s, a);
     return cr_check_launch("cr_stack_qkv_bwd");
 }
 
@@ -623,16 +667,36 @@ extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int p
     return split ? launch_ffn_bwd<true, 0>(a, s) : launch_ffn_bwd<false, 0>(a, s);
 }
 
-extern "C" int cr_stack_qkv_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+static int stack_qkv_bwd_any(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream, const char* who) {
     SbArgs a;
-    int rc = sb_args(&a, bd, B, T, precision, "cr_stack_qkv_bwd");
+    int rc = sb_args(&a, bd, B, T, precision, who);
     if (rc) return rc;
     const cr_block_desc* d = &bd->f;
-    CR_REQUIRE(bd->dqkv && bd->d_o && bd->dx && d->q_in && d->x && d->wqkv && d->ln1_g, "cr_stack_qkv_bwd: NULL pointer");
-    CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b, "cr_stack_qkv_bwd: NULL gradient pointer");
-    CR_REQUIRE(bd->dq_part == nullptr, "cr_stack_qkv_bwd: dq_part (single-pass fp32 attention backward) is not taken");
+    CR_REQUIRE(bd->dqkv && bd->d_o && d->q_in && d->x && d->wqkv && d->ln1_g, "%s: NULL pointer", who);
+    CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b, "%s: NULL gradient pointer", who);
+    CR_REQUIRE(bd->dq_part == nullptr, "%s: dq_part (single-pass fp32 attention backward) is not taken", who);
+    if (sc) {
+        const cr_embed_desc* e = &sc->f;
+        CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
+                   "%s: the embedding recipe must describe the block's dense input x", who);
+        CR_REQUIRE(sc->n_slabs == 0, "%s: small-table mode is not fused", who);
+        CR_REQUIRE(!bd->dx_accumulate, "%s: dx_accumulate is not supported (this kernel must be the only producer of dx)", who);
+        CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "%s: nothing to scatter into", who);
+        CR_REQUIRE(sc->d_addend == nullptr || e->ld_add == d->D, "%s: d_addend must be dense [M, D]", who);
+        a.sc = *sc;
+        a.scatter = 1;
+    } else {
+        CR_REQUIRE(bd->dx, "%s: dx is NULL", who);
+    }
     const bool split = precision == CR_PREC_BF16X3;
     hipStream_t s = cr_stream(stream);
     if (d->D == 50) return split ? launch_qkv_bwd<true, 50>(a, s) : launch_qkv_bwd<false, 50>(a, s);
     return split ? launch_qkv_bwd<true, 0>(a, s) : launch_qkv_bwd<false, 0>(a, s);
+}
+extern "C" int cr_stack_qkv_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+    return stack_qkv_bwd_any(bd, nullptr, B, T, precision, stream, "cr_stack_qkv_bwd");
+}
+extern "C" int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream) {
+    CR_REQUIRE(sc != nullptr, "cr_stack_qkv_bwd_scatter: NULL embedding recipe");
+    return stack_qkv_bwd_any(bd, sc, B, T, precision, stream, "cr_stack_qkv_bwd_scatter");
 }

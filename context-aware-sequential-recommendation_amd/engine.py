@@ -636,7 +636,10 @@ class Engine:
             recipe = self._scatter_recipe.get(x.data_ptr())
             if recipe is not None and not bbd.dx_accumulate:
                 self._scatter_claimed.add(x.data_ptr())
-                self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()))
+                if rows_bf:
+                    self._call(lst, "cr_stack_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()), B, T, prec)
+                else:
+                    self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()))
             elif rows_bf:
                 self._call(lst, "cr_stack_qkv_bwd", C.byref(bbd), B, T, prec)
             else:

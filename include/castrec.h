@@ -315,6 +315,8 @@ int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
 int cr_stack_bwd_supported(const cr_block_bwd_desc* d, int B, int T, int precision);   /* 1 / 0 */
 int cr_stack_ffn_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
 int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
+/* ... with the embedding gather's backward applied instead of storing dx: arguments as cr_block_ln_qkv_bwd_scatter */
+int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);
 
 /* cr_block_ln_qkv_bwd of a stack's FIRST block whose input x was composed by an embedding gather: instead of
  * storing dx the kernel applies that gather's backward to its rows (cr_embed_bwd, large-table mode): `sc` is the
