@@ -112,8 +112,14 @@ def algo_work(name, fnargs, eng):
         return 2.0 * M * D * 2 * D + (2.0 * M * D * 3 * D if fnargs[1]._obj.kind == 1 else 0.0), None, "mfma"
     if name == "cr_block_ln_ffn_bwd":
         return 2.0 * M * D * 4 * D, None, "mfma"
-    if name in ("cr_block_ln_qkv_bwd", "cr_block_ln_qkv_bwd_scatter"):
+    if name in ("cr_block_ln_qkv_bwd", "cr_block_ln_qkv_bwd_scatter", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter"):
         return 2.0 * M * D * 6 * D, None, "mfma"
+    if name == "cr_stack_ffn_bwd":
+        return 2.0 * M * D * 4 * D, None, "mfma"
+    if name == "cr_stack_fwd":
+        # per block: Q K V projections + causal attention (QK^T + PV, causal half) + the two feed-forward layers
+        nb = fnargs[0]._obj.n_blocks
+        return nb * (2.0 * M * D * 3 * D + 2.0 * D * T * (T + 1) * B + 2.0 * M * D * 2 * D), None, "mfma"
     return None, None, "hbm"
 
 
@@ -166,7 +172,8 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_qkv_fwd": ["k_block_ln_qkv_fwd"], "cr_block_ln_qkv_fwd_gather": ["k_block_ln_qkv_fwd"],
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
-              "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"]}
+              "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
+              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"]}
 
 
 def pmc_lookup(abi_name, precision):
@@ -458,6 +465,13 @@ def main():
                 attn[n_] = dict(us_per_launch=round(a["us"] / a["launches"], 2), launches_per_step=a["launches"], achieved_TFLOPs=round(tf, 2),
                                 frac_of_f32_mfma_peak=round(tf / 157.3, 4), frac_of_bf16_mfma_peak=round(tf / PEAK_BF16_TF, 5),
                                 mfma_busy_frac=mb, traffic=tr)
+        # every entry point of the step: time per step, launches, and the algorithmic rate against its bound
+        kernels = {}
+        for n_, a in sorted(by_name.items(), key=lambda kv: -kv[1]["us"]):
+            pk, un = PEAK[a["bound"]]
+            rate = (a["flops"] / 1e12 if a["bound"] == "mfma" else a["bytes"] / 1e9) / (a["us"] * 1e-6) if a["us"] > 0 else 0.0
+            kernels[n_] = dict(us_per_step=round(a["us"], 1), launches=a["launches"], bound=a["bound"],
+                               achieved=round(rate, 2) if (a["flops"] or a["bytes"]) else None, unit=un)
         attn["executed_flop_frac"] = executed_tile_fraction(host_batches, T)
         attn["arithmetic"] = {"f32": "v_mfma_f32_16x16x4_f32", "bf16x3": "v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), fp32 accumulate",
                               "bf16": "v_mfma_f32_16x16x32_bf16, fp32 accumulate"}[prec]
@@ -479,7 +493,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 split MFMA in attention)", "bf16": "bf16 (attention) / f32"}[prec],
-            "data": "synthetic", "config": cfg, "roofline": roofline, "attention": attn,
+            "data": "synthetic", "config": cfg, "roofline": roofline, "attention": attn, "kernels": kernels,
         }
     del eng
     torch.cuda.empty_cache()

@@ -22,6 +22,7 @@
 // the separate kernels, so the backward kernels regenerate the same masks.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "cr_attn_common.hpp"
 #include "cr_bf16.hpp"
@@ -36,6 +37,8 @@ struct StackArgs {
     float isd_log2e, invT;
     const float* lnf_g; const float* lnf_b; float* out; int ld_out, col_out;
     unsigned long long* ts;       // debug: per-wave phase stamps [B][8 waves][64] (tools/stack_ts.py); NULL in production
+    int gather;                   // blk[0].bd.x is composed here from the embedding recipe `e` (and written: the backward reads it)
+    cr_embed_desc e;
     StackBlk blk[CR_STACK_MAX_BLOCKS];
 };
 
@@ -106,8 +109,11 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     const int tile0 = a.nkt - 1 - (PAIR ? 2 * wave + (int)blockIdx.y : wave);
     const int tile1 = PAIR ? -1 : a.nkt - 1 - (2 * NW - 1 - wave);
     const int nB = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);              // phase B / C tiles (tile1 >= 0 implies tile0 >= 0)
-    const int nA = PAIR ? (a.nkt - wave + NW - 1) / NW : nB;                 // phase A tiles: PAIR: wave, wave + NW, ...
-    auto tile_a = [&](int i) { return PAIR ? wave + NW * i : (i == 0 ? tile0 : tile1); };
+    // phase A tiles: the wave's own B / C tile first, then (PAIR) the tile of the same rank pair that the OTHER workgroup
+    // takes through B / C -- so a wave only ever re-reads rows of x / y that it wrote itself
+    const int tileP = PAIR ? a.nkt - 1 - (2 * wave + 1 - (int)blockIdx.y) : tile1;
+    const int nA = (tile0 >= 0 ? 1 : 0) + (tileP >= 0 ? 1 : 0);
+    auto tile_a = [&](int i) { return (i == 0 && tile0 >= 0) ? tile0 : tileP; };
     auto tile_b = [&](int i) { return i == 0 ? tile0 : tile1; };
     const bool wr_kv = !PAIR || blockIdx.y == 0;                             // this workgroup writes K / V / key flags to HBM
     const float c2 = a.isd_log2e;
@@ -116,12 +122,28 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
 
     WRegs<2, NT> wa;
     float vv[NVV];
-    RRaw xa;
+    RRaw xa, xp, xd;                                      // x rows (or, composing x: table rows), positional rows, addend rows
+    // composing x (a.gather): ids of the wave's phase-A rows, loaded once; issue_x requests what a tile's x is made of
+    int gid0 = 0, gid1 = 0;
+    if (a.gather) {
+        gid0 = a.e.ids[base_row + min(16 * max(tile_a(0), 0) + (lane_now() & 15), T - 1)];
+        gid1 = a.e.ids[base_row + min(16 * max(tile_a(1), 0) + (lane_now() & 15), T - 1)];
+    }
+    auto issue_x = [&](const float* xsrc, int tile, int gid, bool gather) {
+        if (!gather) {
+            r_issue(xa, xsrc, row_of(tile), dcx);
+        } else {
+            const int t = min(16 * tile + (lane_now() & 15), T - 1);
+            r_issue(xa, a.e.table, (u32)gid * (u32)(4 * D), dcx);                               // row 0 exists; zeroed below when zero_pad
+            if (a.e.pos_table) r_issue(xp, a.e.pos_table, (u32)((base_row + t) % a.e.T) * (u32)(4 * D), dcx);
+            if (a.e.addend) r_issue(xd, a.e.addend, (u32)(base_row + t) * (u32)(4 * a.e.ld_add), dcx);
+        }
+    };
     {
         const cr_block_desc& d = a.blk[0].bd;
         w_issue<2, NT>(wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
         vec_issue<NT>(vv, d, a, D);
-        r_issue(xa, d.x, row_of(max(tile_a(0), 0)), dcx);
+        issue_x(d.x, max(tile_a(0), 0), gid0, a.gather != 0);
     }
 #pragma unroll 1
     for (int b = 0; b < a.nb; ++b) {
@@ -147,7 +169,31 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const u32 mo = (u32)m * (u32)(4 * D);
             f32x4 x[4];
             r_finish(x, xa, dcx);
-            if (i + 1 < nA) r_issue(xa, d.x, row_of(tile_a(i + 1)), dcx);
+            if (a.gather && b == 0) {
+                // x[m] = mask * dropout(table'[id[m]] * scale + pos[m % T] + addend[m])  (cr_embed_fwd: sasrec.py:27-62 / cast_1.py:86-91)
+                const cr_embed_desc& e = a.e;
+                const int gid = i == 0 ? gid0 : gid1;
+                const bool padrow = e.zero_pad && gid == 0;
+                const bool dead = e.mask_ids && e.mask_ids[m] == 0;
+                f32x4 pv[4], av[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) { pv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; av[ct] = pv[ct]; }
+                if (e.pos_table) r_finish(pv, xp, dcx);
+                if (e.addend) r_finish(av, xd, dcx);
+                const DropCtx dce = drop_ctx(e.drop);
+                const uint32_t eb = ((e.drop.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + dce.key;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = (padrow ? 0.0f : x[ct][r]) * e.scale + pv[ct][r] + av[ct][r];
+                        if (dce.on) v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
+                        x[ct][r] = dead ? 0.0f : v;
+                    }
+                // the wave writes x for the tile it takes through phase B / C (it re-reads those rows there)
+                r_store(e.out, mo, x, rok && (!PAIR || tile_a(i) == tile0), dcx);
+            }
+            if (i + 1 < nA) issue_x(d.x, tile_a(i + 1), gid1, a.gather && b == 0);
             const float xs = r_rowsum(x);
             if (lg == 0) kb[q0 + li] = (rok && xs != 0.0f) ? 0.0f : -INFINITY;   // key mask (modules.py:222)
             if (lg == 0 && rok && wr_kv) d.k_valid[m] = (xs != 0.0f) ? 1.0f : 0.0f;
@@ -418,7 +464,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const cr_block_desc& dn = a.blk[b + 1].bd;
             w_issue<2, NT>(wa, D, dn.wqkv, 3 * D, D, dn.wqkv, 3 * D, 2 * D, dn.wqkv, 3 * D, 2 * D);
             vec_issue<NT>(vv, dn, a, D);
-            r_issue(xa, dn.x, row_of(max(tile_a(0), 0)), dcx);
+            issue_x(dn.x, max(tile_a(0), 0), 0, false);
         }
         __syncthreads();                                  // B3: images, weights and vectors are rewritten by the next block
     }
@@ -456,6 +502,13 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
         if (i > 0 && b.x != s->blocks[i - 1].y) return "blocks must chain (x of block i = y of block i-1)";
     }
     if (s->out && (!s->lnf_gamma || !s->lnf_beta)) return "final LayerNorm parameters";
+    if (s->embed) {
+        const cr_embed_desc& e = *s->embed;
+        if (!e.ids || !e.table || e.M != b0.M || e.D != b0.D || e.T < 1 || e.V < 1) return "embedding recipe: shape";
+        if (e.out != b0.x || e.ld_out != b0.D || e.col_off != 0) return "embedding recipe must describe blocks[0].x (dense)";
+        if ((size_t)e.V * e.D * 4 >= ((size_t)1 << 32)) return "embedding table of 4 GiB or more (32-bit row offsets)";
+        if (e.addend && (size_t)e.M * e.ld_add * 4 >= ((size_t)1 << 32)) return "addend of 4 GiB or more";
+    }
     return nullptr;
 }
 
@@ -500,9 +553,12 @@ extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
     const bool pair = a0.B <= g_stack_pair_max_b && a.nkt >= 2;
     hipStream_t st = cr_stream(stream);
     const int per = pair ? 1 : s->n_blocks;               // blocks per launch
+    memset(&a.e, 0, sizeof(a.e));
     for (int i0 = 0; i0 < s->n_blocks; i0 += per) {
         const bool fin = i0 + per >= s->n_blocks && s->out != nullptr;
         a.nb = per;
+        a.gather = (i0 == 0 && s->embed) ? 1 : 0;
+        if (a.gather) a.e = *s->embed;
         a.lnf_g = fin ? s->lnf_gamma : nullptr; a.lnf_b = fin ? s->lnf_beta : nullptr;
         a.out = fin ? s->out : nullptr;
         for (int i = 0; i < CR_STACK_MAX_BLOCKS; ++i) {

@@ -663,7 +663,10 @@ class Engine:
         whole-stack kernel fits (cr_stack_fwd) the forward of up to four blocks + the final LayerNorm is ONE launch."""
         tails = self.fused and self.fuse_tails and nblocks > 0
         stack = self._stack_kernel_fits(nblocks, want_attn)
-        if (nblocks == 0 or stack) and x.data_ptr() in self._pending_embed:      # no block kernel to carry the gather
+        emb = None
+        if stack and x.data_ptr() in self._pending_embed:                # the stack kernel composes its input itself
+            emb = self._pending_embed.pop(x.data_ptr())
+        if nblocks == 0 and x.data_ptr() in self._pending_embed:         # no block kernel to carry the gather
             self._call(self.fwd, "cr_embed_fwd", C.byref(self._pending_embed.pop(x.data_ptr())))
         ys = [self.buf("%s.%d.y" % (prefix, i), self.D) for i in range(nblocks)]
         cur = x
@@ -687,7 +690,9 @@ class Engine:
                 fin = i0 + 4 >= nblocks
                 sd = L.StackDesc(len(part), C.cast(bds, C.POINTER(L.BlockDesc)), C.cast(ads, C.POINTER(L.AttnDesc)),
                                  self._pptr(prefix + ".lnf.gamma") if fin else None, self._pptr(prefix + ".lnf.beta") if fin else None,
-                                 out.data_ptr() if fin else None, out_ld, out_col)
+                                 out.data_ptr() if fin else None, out_ld, out_col,
+                                 C.pointer(emb) if (emb is not None and i0 == 0) else None)
+                self._keep.append(emb)
                 if not L.lib.cr_stack_fwd_supported(C.byref(sd)):
                     raise RuntimeError("cr_stack_fwd does not take the stack %s it was sized for" % prefix)
                 self._keep.append((bds, ads))

@@ -105,7 +105,7 @@ class BlockTailDesc(C.Structure):
 
 class StackDesc(C.Structure):
     _fields_ = [("n_blocks", c_i), ("blocks", C.POINTER(BlockDesc)), ("attn", C.POINTER(AttnDesc)), ("lnf_gamma", c_p),
-                ("lnf_beta", c_p), ("out", c_p), ("ld_out", c_i), ("col_out", c_i)]
+                ("lnf_beta", c_p), ("out", c_p), ("ld_out", c_i), ("col_out", c_i), ("embed", C.POINTER(EmbedDesc))]
 
 
 class HeadDesc(C.Structure):

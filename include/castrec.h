@@ -288,6 +288,8 @@ typedef struct {
     const cr_block_desc* blocks;               /* [n_blocks] */
     const cr_attn_desc* attn;                  /* [n_blocks] */
     const float* lnf_gamma; const float* lnf_beta; float* out; int ld_out, col_out;   /* optional (out != NULL): final LayerNorm */
+    const cr_embed_desc* embed;                /* optional: the cr_embed_fwd call that composes blocks[0].x (embed->out == blocks[0].x,
+                                                  dense); x is then composed -- and written -- by this launch instead */
 } cr_stack_desc;
 int cr_stack_fwd_supported(const cr_stack_desc* d);   /* 1 / 0 */
 int cr_stack_fwd(const cr_stack_desc* d, void* stream);
