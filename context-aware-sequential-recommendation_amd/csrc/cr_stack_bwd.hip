@@ -34,6 +34,8 @@ struct SbArgs {
     cr_block_bwd_desc bd;
     cr_embed_bwd_desc sc;         // qkv: optional scatter of dx into the embedding tables (see cr_block_ln_qkv_bwd_scatter)
     int B, T, nkt, scatter;
+    int has_ln;                   // ffn: bd.dy is not read; it is the backward of the stack's final LayerNorm (`ln`) applied to ln.dy
+    cr_ln_bwd_desc ln;
     unsigned long long* ts;
 };
 
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     __bf16* Im = Wi + 2 * WST;                            // image slots: 0 hid, 1 g2, 2 f_in, 3 g1
     float* gam = reinterpret_cast<float*>(Im + 4 * IST);  // [64] gamma2, zero padded
     float* part = gam + 64;                               // [2][SB_WAVES][64]
+    float* gamF = part + 2 * SB_WAVES * 64;               // [64] gamma of the stack's final LayerNorm (has_ln)
     const int D = DS > 0 ? DS : d.D, T = a.T;
     const DCtx dcx = d_ctx(D);
     const int wave = threadIdx.x >> 6;
@@ -298,7 +301,11 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     // work items of this workgroup: (sequence n, round rd), n = blockIdx.x, + gridDim.x, ...; the inputs of the NEXT
     // item's tile are requested before the weight-gradient phase of the current one (and the first before the weights
     // are staged): a tile's five row blocks come from HBM, 2-3 us that nothing else would cover
-    RRaw rdy, rhid, rfin, ro, rq;
+    constexpr bool PF = DS > 0;                          // look-ahead loads only in the D-specialised build (register budget)
+    RRaw rdy, rhid, rfin, ro, rq, ry;
+    f32x4 agF[4], abF[4];                                 // final-LayerNorm gradient partials (has_ln)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { agF[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; abF[ct] = agF[ct]; }
     auto tile_rows = [&](int n, int rd, int& m, bool& rok) {
         const int q = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
         rok = q < T;
@@ -309,7 +316,12 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
             int m; bool rok;
             tile_rows(n, rd, m, rok);
             const u32 mo = (u32)m * (u32)(4 * D);
-            r_issue(rdy, bd.dy, mo, dcx);
+            if (a.has_ln) {                                          // rows beyond T: zero gradient (they must not reach the LayerNorm sums)
+                r_issue(rdy, a.ln.dy, (u32)m * (u32)(4 * a.ln.lddy), dcx, rok);
+                r_issue(ry, d.y, mo, dcx);
+            } else {
+                r_issue(rdy, bd.dy, mo, dcx);
+            }
             r_issue(rhid, d.hid, mo, dcx);
             r_issue(rfin, d.f_in, mo, dcx);
             r_issue(ro, d.o, mo, dcx);
@@ -323,9 +335,10 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
         w_issue<2, SB_NT>(w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
         const int t = threadIdx.x;
         const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
-        if ((int)blockIdx.x < nitems) issue((int)blockIdx.x / R, (int)blockIdx.x % R);
+        const float gf = (a.has_ln && t < D) ? a.ln.gamma[t] : 0.0f;
+        if (PF && (int)blockIdx.x < nitems) issue((int)blockIdx.x / R, (int)blockIdx.x % R);
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
-        if (t < 64) gam[t] = gv;
+        if (t < 64) { gam[t] = gv; gamF[t] = gf; }
     }
     __syncthreads();
     SB_TS(2);
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
         {
             const int n = item / R, rd = item % R;
             const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);       // tiles of this round (wave-uniform)
+            if (!PF) issue(n, rd);
             if (wave < ntr) {
                 const int lg = lane_now() >> 4;
                 int m; bool rok;
@@ -344,6 +358,14 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
                 const float msk = (rok && d.mask_ids[m] != 0) ? 1.0f : 0.0f;    // rows beyond T contribute nothing
                 f32x4 dy[4], g2[4], hid[4];
                 r_finish(dy, rdy, dcx);
+                if (a.has_ln) {
+                    // dy = backward of the stack's final LayerNorm (sasrec.py:85) on the gradient rows, x = this block's y
+                    f32x4 yv[4], dyo[4];
+                    r_finish(yv, ry, dcx);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) dyo[ct] = dy[ct];
+                    r_ln_bwd(dy, yv, dyo, gamF, agF, abF, dcx);
+                }
                 // g2 = dy * mask * keep2 / (1 - rate) (sasrec.py:83, modules.py:309-310)
                 const uint32_t e2 = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + d2.key;
 #pragma unroll
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
                     if (lg == 0 && rok) bd.attn_delta[m] = acc;
                 }
             }
-            if (item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
+            if (PF && item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
             SB_TS(3);
             __syncthreads();
             SB_TS(4);
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     wgrad_store(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, it, jt0);
     SB_TS(11);
     ln_grads_store(part, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
+    if (a.has_ln) ln_grads_store(part, agF, abF, a.ln.dgamma + so, a.ln.dbeta + so, D);
     SB_TS(63);
 }
 
@@ -630,7 +653,7 @@ static int launch_ffn_bwd(const SbArgs& a, hipStream_t s) {
     static cr_devmask attr = 0;
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_ffn_bwd<SPLIT, DS>), &attr);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_ffn_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(2, 4, SPLIT), s, a);
+    hipLaunchKernelGGL((k_stack_ffn_bwd<SPLIT, DS>), dim3(a.bd.n_slabs), dim3(SB_NT), sb_lds(2, 4, SPLIT) + 64 * 4, s, a);
     return cr_check_launch("cr_stack_ffn_bwd");
 }
 template <bool SPLIT, int DS>
@@ -652,19 +675,36 @@ static int sb_args(SbArgs* a, const cr_block_bwd_desc* bd, int B, int T, int pre
     return CR_OK;
 }
 
-extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+static int stack_ffn_bwd_any(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream, const char* who) {
     SbArgs a;
-    int rc = sb_args(&a, bd, B, T, precision, "cr_stack_ffn_bwd");
+    int rc = sb_args(&a, bd, B, T, precision, who);
     if (rc) return rc;
     const cr_block_desc* d = &bd->f;
-    CR_REQUIRE(bd->dy && bd->d_o && d->hid && d->f_in && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_stack_ffn_bwd: NULL pointer");
-    CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b, "cr_stack_ffn_bwd: NULL gradient pointer");
-    CR_REQUIRE(bd->attn_delta == nullptr || d->q_in != nullptr, "cr_stack_ffn_bwd: attn_delta needs q_in");
+    CR_REQUIRE(bd->d_o && d->hid && d->f_in && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "%s: NULL pointer", who);
+    CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b, "%s: NULL gradient pointer", who);
+    CR_REQUIRE(bd->attn_delta == nullptr || d->q_in != nullptr, "%s: attn_delta needs q_in", who);
+    if (n) {
+        CR_REQUIRE(n->x == d->y && n->ldx == d->D && n->M == d->M && n->D == d->D, "%s: the LayerNorm's input must be this block's y", who);
+        CR_REQUIRE(n->gamma && n->dy && n->dgamma && n->dbeta && n->accumulate == 0, "%s: LayerNorm backward arguments", who);
+        CR_REQUIRE(n->slab_stride == bd->slab_stride && n->n_slabs == bd->n_slabs, "%s: the LayerNorm's slabs must be the block's", who);
+        CR_REQUIRE((size_t)n->M * n->lddy * 4 < ((size_t)1 << 32), "%s: dy of 4 GiB or more", who);
+        a.ln = *n;
+        a.has_ln = 1;
+    } else {
+        CR_REQUIRE(bd->dy, "%s: dy is NULL", who);
+    }
     a.ts = g_attn_ts_which == 8 ? g_attn_ts : nullptr;
     const bool split = precision == CR_PREC_BF16X3;
     hipStream_t s = cr_stream(stream);
     if (d->D == 50) return split ? launch_ffn_bwd<true, 50>(a, s) : launch_ffn_bwd<false, 50>(a, s);
     return split ? launch_ffn_bwd<true, 0>(a, s) : launch_ffn_bwd<false, 0>(a, s);
+}
+extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
+    return stack_ffn_bwd_any(bd, nullptr, B, T, precision, stream, "cr_stack_ffn_bwd");
+}
+extern "C" int cr_stack_ffn_bwd_ln(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream) {
+    CR_REQUIRE(n != nullptr, "cr_stack_ffn_bwd_ln: NULL LayerNorm description");
+    return stack_ffn_bwd_any(bd, n, B, T, precision, stream, "cr_stack_ffn_bwd_ln");
 }
 
 static int stack_qkv_bwd_any(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream, const char* who) {

@@ -207,6 +207,7 @@ class Engine:
         self._pending_embed = {}
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
+        self._lnf_intent = {}                         # y buffer of a stack's last block -> (LN output pointer, param prefix, out, ld, col)
         self.fuse_head_ln = os.environ.get("CASTREC_NO_HEAD_LN") != "1"
         self._check_ids = os.environ.get("CASTREC_NO_ID_CHECK") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
@@ -372,7 +373,7 @@ class Engine:
         self._ln_recipe[yptr] = (x, pname)            # op_head may take this backward over (cr_head_fwd_bwd_ln)
 
         def factory():
-            if yptr in self._ln_claimed:
+            if yptr in self._ln_claimed or self._lnf_fused(x):
                 return []
             dy = self._grad_of(y)
             dx = self._grad_of(x)
@@ -383,6 +384,12 @@ class Engine:
             self._call(lst, "cr_layernorm_bwd", C.byref(bd))
             return lst
         self._bwd_factories.append(factory)
+
+    def _lnf_fused(self, x):
+        """True when the final LayerNorm whose input is buffer x has its backward applied inside the last block's FFN
+        backward (cr_stack_ffn_bwd_ln) -- decided the same way by the LayerNorm's factory and by the block's."""
+        it = self._lnf_intent.get(x.data_ptr())
+        return it is not None and it[0] not in self._ln_claimed
 
     def op_dropout_inplace(self, c, ncols, site):
         """tf.layers.dropout on the first `ncols` columns of concat buffer c (cast_2.py:90-92, cast_4.py:115-124)."""
@@ -628,9 +635,17 @@ class Engine:
             # bf16 arithmetic: the row phases run on the register-layout kernels (cr_stack_bwd.hip) where they take the shape
             prec = ATTN_PRECISIONS[self.attn_precision]
             rows_bf = bool(self.fuse_stack_bwd and bf and not one_pass and L.lib.cr_stack_bwd_supported(C.byref(bbd), B, T, prec))
-            if rows_bf:
+            if rows_bf and self._lnf_fused(y):
+                _, pname, lo, lo_ld, lo_col = self._lnf_intent[y.data_ptr()]
+                dlo = self._grad_of(lo)
+                nd = L.LnBwdDesc(y.data_ptr(), D, self._pptr(pname + ".gamma"), dlo.data_ptr() + 4 * lo_col, lo_ld, None, D, 0,
+                                 self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+                assert id(dy) not in self._grad_written, "the final LayerNorm must be the only consumer of the stack's output"
+                self._call(lst, "cr_stack_ffn_bwd_ln", C.byref(bbd), C.byref(nd), B, T, prec)
+            elif rows_bf:
                 self._call(lst, "cr_stack_ffn_bwd", C.byref(bbd), B, T, prec)
             else:
+                assert not self._lnf_fused(y), "final LayerNorm backward was left to a kernel that does not take it"
                 self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             recipe = self._scatter_recipe.get(x.data_ptr())
@@ -697,6 +712,10 @@ class Engine:
                     raise RuntimeError("cr_stack_fwd does not take the stack %s it was sized for" % prefix)
                 self._keep.append((bds, ads))
                 self._call(self.fwd, "cr_stack_fwd", C.byref(sd))
+        if (stack and self.training and self.fuse_stack_bwd and self.D < 64 and self.T <= 224
+                and os.environ.get("CASTREC_NO_LNF_FUSION") != "1"):
+            # the register-layout FFN backward of the last block can apply this LayerNorm's backward on its way in
+            self._lnf_intent[cur.data_ptr()] = (out.data_ptr() + 4 * out_col, prefix + ".lnf", out, out_ld, out_col)
         self.op_layernorm(cur, out, out_ld, out_col, prefix + ".lnf", skip_fwd=tails or stack)
 
     def op_head(self, seq_emb):

@@ -316,6 +316,10 @@ int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
  * precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Shapes: 8 <= D < 64, T <= 224 (cr_stack_bwd_supported). */
 int cr_stack_bwd_supported(const cr_block_bwd_desc* d, int B, int T, int precision);   /* 1 / 0 */
 int cr_stack_ffn_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
+/* ... of a stack's LAST block, with the backward of the stack's final LayerNorm (sasrec.py:85) applied to the gradient rows
+ * on the way in: `n` is the cr_layernorm_bwd call that would have produced d->dy (n->x == d->f.y; d->dy and n->dx are not
+ * touched; n->accumulate == 0; same slabs as d) */
+int cr_stack_ffn_bwd_ln(const cr_block_bwd_desc* d, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream);
 int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
 /* ... with the embedding gather's backward applied instead of storing dx: arguments as cr_block_ln_qkv_bwd_scatter */
 int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);

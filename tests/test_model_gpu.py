@@ -245,7 +245,8 @@ def test_awkward_hidden_sizes_and_row_counts(E, model, D, H, T, L, B, prec):
     _other_shapes(E, model, D, H, T, L, B, prec=prec)
 
 
-@pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD", "CASTREC_NO_EMBED_FUSION", "CASTREC_NO_HEAD_LN"])
+@pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD", "CASTREC_NO_EMBED_FUSION", "CASTREC_NO_HEAD_LN",
+                                 "CASTREC_NO_STACK_KERNEL", "CASTREC_NO_STACK_BWD", "CASTREC_NO_LNF_FUSION"])
 def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     """The plain FFN forward entry (no tail), the two-pass attention backward at one head and the stand-alone
     embedding gather in front of a stack: the engine's default path no longer uses them, the C ABI still offers them."""
