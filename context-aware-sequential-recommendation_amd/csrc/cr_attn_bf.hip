@@ -567,16 +567,26 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // FAST: images at a compile-time stride, operand reads = (per-lane base + pair offset) + immediate (see bf_bwd_k_pass)
+    constexpr bool FAST = PAIRED && !MULTI && NKS == 2;
+    constexpr int FSTR = 256 * 64;
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* Kl = Kh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
-    __bf16* Vh = Kl + g.ch_rows * (32 * NKS);
-    __bf16* Vl = Vh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
-    float* kb = reinterpret_cast<float*>(Vl + g.ch_rows * (32 * NKS));   // [ch_rows]
+    __bf16* Kl = Kh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
+    __bf16* Vh = Kl + (FAST ? FSTR : g.ch_rows * (32 * NKS));
+    __bf16* Vl = Vh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
+    float* kb = reinterpret_cast<float*>(Vl + (FAST ? FSTR : g.ch_rows * (32 * NKS)));   // [ch_rows] (FAST: + 16, the absent tile of an odd count)
     const int nw = blockDim.x >> 6;
     const int head = blockIdx.x / d.B, n = blockIdx.x % d.B;
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    int ftr[4];
+    {
+        const int q_ = li >> 2, p_ = li & 3;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
+    }
     BT_TS(0); BT_TS(1);
     const DropCtx dc = drop_ctx(d.drop);
     TileSched sch = sched_init(nw, wave);
@@ -623,6 +633,11 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     int kt_first = 0;
     if (!multi) {
         stage(0);
+        if (FAST && (g.nkt & 1)) {                       // the absent second tile of the last pair: finite (zero) rows, masked keys
+            const int t = threadIdx.x, im = t >> 7, o16 = t & 127;
+            *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Kh + im * FSTR) + (size_t)g.ch_rows * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < 16) kb[g.ch_rows + t] = -INFINITY;
+        }
         BT_TS(2);
         __syncthreads();
         BT_TS(3);
@@ -685,14 +700,30 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
             const int lo = max(kt_first, kt_c0), hi = min(qt, kt_c0 + g.ch_rows / 16 - 1);
             for (int kp = lo >> 1; 2 * kp <= hi; ++kp) {                 // pairs of key tiles (global indices 2kp, 2kp+1)
                 const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                const int l0 = k0 - kt_c0, l1 = (k1 <= hi ? k1 : k0) - kt_c0;   // chunk-local tiles (l1 clamped: zeros below)
+                // chunk-local tiles (l1 clamped: zeros below; FAST: always k0 + 1 -- real or zeroed rows, coefficients 0)
+                const int l0 = k0 - kt_c0, l1 = FAST ? k1 : (k1 <= hi ? k1 : k0) - kt_c0;
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                const int po = 4096 * kp;
+                auto rfF = [&](int base, int ks, int second, int lo_) {
+                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + 2048 * second + 2 * FSTR * lo_);
+                };
+                auto trF = [&](int base, int jt, int lo_) {
+                    const unsigned char* pa = smem_raw + (base + po + ftr[jt]) + 2 * FSTR * lo_;
+                    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
+                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
                 {
                     bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        a0h[ks] = row_frag<NKS>(Kh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Kh, 16 * l1, ks);
-                        a0l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l1, ks) : a1h[ks];
+                        if (FAST) {
+                            a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                            a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                        } else {
+                            a0h[ks] = row_frag<NKS>(Kh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Kh, 16 * l1, ks);
+                            a0l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Kl, 16 * l1, ks) : a1h[ks];
+                        }
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -706,8 +737,13 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 v0h[NKS], v0l[NKS], v1h[NKS], v1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        v0h[ks] = row_frag<NKS>(Vh, 16 * l0, ks); v1h[ks] = row_frag<NKS>(Vh, 16 * l1, ks);
-                        v0l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l0, ks) : v0h[ks]; v1l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l1, ks) : v1h[ks];
+                        if (FAST) {
+                            v0h[ks] = rfF(4 * FSTR, ks, 0, 0); v1h[ks] = rfF(4 * FSTR, ks, 1, 0);
+                            v0l[ks] = SPLIT ? rfF(4 * FSTR, ks, 0, 1) : v0h[ks]; v1l[ks] = SPLIT ? rfF(4 * FSTR, ks, 1, 1) : v1h[ks];
+                        } else {
+                            v0h[ks] = row_frag<NKS>(Vh, 16 * l0, ks); v1h[ks] = row_frag<NKS>(Vh, 16 * l1, ks);
+                            v0l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l0, ks) : v0h[ks]; v1l[ks] = SPLIT ? row_frag<NKS>(Vl, 16 * l1, ks) : v1h[ks];
+                        }
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -721,8 +757,13 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                 bf8 bh[JB], bl[JB];
 #pragma unroll
                 for (int jt = 0; jt < JB; ++jt) {
-                    bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, jt);
-                    bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, jt) : bh[jt];
+                    if (FAST) {
+                        bh[jt] = trF(0, jt, 0);
+                        bl[jt] = SPLIT ? trF(0, jt, 1) : bh[jt];
+                    } else {
+                        bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, jt);
+                        bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, jt) : bh[jt];
+                    }
                 }
                 float x[8];
                 auto finish = [&](int kt, int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
@@ -749,8 +790,13 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = JB; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, j0 + jt);
-                        bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, j0 + jt) : bh[jt];
+                        if (FAST) {
+                            bh[jt] = trF(0, j0 + jt, 0);
+                            bl[jt] = SPLIT ? trF(0, j0 + jt, 1) : bh[jt];
+                        } else {
+                            bh[jt] = tr_frag<NKS>(Kh, 16 * l0, 16 * l1, j0 + jt);
+                            bl[jt] = SPLIT ? tr_frag<NKS>(Kl, 16 * l0, 16 * l1, j0 + jt) : bh[jt];
+                        }
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(ah, al, bh[jt], bl[jt], dq[j0 + jt]);
@@ -782,14 +828,20 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     constexpr int JB = SPLIT ? 2 : NDT;                  // column tiles per batch of transposed reads (register budget)
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // FAST (the fused launch at head dims 33..64): the four images sit at a compile-time stride of 256 rows, so that inside the
+    // pair loop an operand read is (per-lane base + pair offset) + immediate: 12 address adds per iteration instead of one per
+    // read (the run-time image pointers and tile indices made every one of the 60 reads of an iteration compute its own
+    // address: 99 of the 313 vector instructions of the loop)
+    constexpr bool FAST = PAIRED && !MULTI && NKS == 2;
+    constexpr int FSTR = 256 * 64;                        // elements between images (FAST)
     __bf16* Qh = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* Ql = Qh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
-    __bf16* Oh = Ql + g.ch_rows * (32 * NKS);
-    __bf16* Ol = Oh + (SPLIT ? g.ch_rows * (32 * NKS) : 0);
+    __bf16* Ql = Qh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
+    __bf16* Oh = Ql + (FAST ? FSTR : g.ch_rows * (32 * NKS));
+    __bf16* Ol = Oh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
     // per-row statistics of the staged query chunk, stored so that the inner loop is branch-free:
     //   A[q][key] = valid * exp2(s c - smx) * sinv + (key < T ? suni : 0); normal row: suni = 0; uniform row: sinv = 0,
     //   suni = 1/T; dead row: both 0 (smx = 1e30 wherever sinv = 0: the exponential is exactly 0, never inf * 0)
-    float* smx = reinterpret_cast<float*>(Ol + g.ch_rows * (32 * NKS));          // [ch_rows] each
+    float* smx = reinterpret_cast<float*>(Ol + (FAST ? FSTR : g.ch_rows * (32 * NKS)));          // [ch_rows] each
     float* sinv = smx + g.ch_rows;
     float* sdel = sinv + g.ch_rows;
     float* suni = sdel + g.ch_rows;
@@ -800,6 +852,15 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    // FAST: per-lane byte offsets of the operand reads at tile 0 of an image (see img_off: the swizzle term (row & 6) does not
+    // depend on the tile, so a tile adds 2048 bytes)
+    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    int ftr[4];
+    {
+        const int q = li >> 2, p = li & 3;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q, 2 * jt + (p >> 1)) + 4 * (p & 1));
+    }
     BT_TS(8);
     const DropCtx dc = drop_ctx(d.drop);
     TileSched sch = sched_init(nw, wave);
@@ -854,6 +915,12 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     int fvk = 0;
     if (!multi) {
         stage(0);
+        if (FAST && (g.nkt & 1)) {
+            // an odd tile count: the last pair's second tile does not exist; its rows are read all the same (with zero
+            // coefficients) and must hold finite values: zero them (16 rows x 128 bytes x 4 images, 16 bytes per thread)
+            const int t = threadIdx.x, im = t >> 7, o16 = t & 127;
+            *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Qh + im * FSTR) + (size_t)g.ch_rows * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         BT_TS(9);
         __syncthreads();
         stage_flags();
@@ -911,12 +978,28 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 const bool w0 = wanted(l0), w1 = two && wanted(l1);
                 if (!w0 && !w1) continue;
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                // FAST: byte addresses of this pair's tiles: (lane base + 4096 * qp); second tile + 2048, lo image + 32768
+                const int po = 4096 * qp;
+                auto rfF = [&](int base, int ks, int second, int lo) {
+                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + 2048 * second + 2 * FSTR * lo);
+                };
+                auto trF = [&](int base, int jt, int lo) {
+                    const unsigned char* pa = smem_raw + (base + po + ftr[jt]) + 2 * FSTR * lo;
+                    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
+                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
                 {
                     bf8 a0h[NKS], a0l[NKS], a1h[NKS], a1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        a0h[ks] = row_frag<NKS>(Qh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Qh, 16 * l1, ks);
-                        a0l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l1, ks) : a1h[ks];
+                        if (FAST) {
+                            a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                            a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                        } else {
+                            a0h[ks] = row_frag<NKS>(Qh, 16 * l0, ks); a1h[ks] = row_frag<NKS>(Qh, 16 * l1, ks);
+                            a0l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l0, ks) : a0h[ks]; a1l[ks] = SPLIT ? row_frag<NKS>(Ql, 16 * l1, ks) : a1h[ks];
+                        }
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -930,8 +1013,13 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                     bf8 o0h[NKS], o0l[NKS], o1h[NKS], o1l[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        o0h[ks] = row_frag<NKS>(Oh, 16 * l0, ks); o1h[ks] = row_frag<NKS>(Oh, 16 * l1, ks);
-                        o0l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l0, ks) : o0h[ks]; o1l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l1, ks) : o1h[ks];
+                        if (FAST) {
+                            o0h[ks] = rfF(4 * FSTR, ks, 0, 0); o1h[ks] = rfF(4 * FSTR, ks, 1, 0);
+                            o0l[ks] = SPLIT ? rfF(4 * FSTR, ks, 0, 1) : o0h[ks]; o1l[ks] = SPLIT ? rfF(4 * FSTR, ks, 1, 1) : o1h[ks];
+                        } else {
+                            o0h[ks] = row_frag<NKS>(Oh, 16 * l0, ks); o1h[ks] = row_frag<NKS>(Oh, 16 * l1, ks);
+                            o0l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l0, ks) : o0h[ks]; o1l[ks] = SPLIT ? row_frag<NKS>(Ol, 16 * l1, ks) : o1h[ks];
+                        }
                     }
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -945,8 +1033,13 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 bf8 oth[JB], otl[JB];
 #pragma unroll
                 for (int jt = 0; jt < JB; ++jt) {
-                    oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, jt);
-                    otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, jt) : oth[jt];
+                    if (FAST) {
+                        oth[jt] = trF(4 * FSTR, jt, 0);
+                        otl[jt] = SPLIT ? trF(4 * FSTR, jt, 1) : oth[jt];
+                    } else {
+                        oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, jt);
+                        otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, jt) : oth[jt];
+                    }
                 }
                 float xa[8], xd[8];
                 auto finish = [&](int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
@@ -982,8 +1075,13 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = JB; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, j0 + jt);
-                        otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        if (FAST) {
+                            oth[jt] = trF(4 * FSTR, j0 + jt, 0);
+                            otl[jt] = SPLIT ? trF(4 * FSTR, j0 + jt, 1) : oth[jt];
+                        } else {
+                            oth[jt] = tr_frag<NKS>(Oh, 16 * l0, 16 * l1, j0 + jt);
+                            otl[jt] = SPLIT ? tr_frag<NKS>(Ol, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        }
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(ah, al, oth[jt], otl[jt], dv[j0 + jt]);
@@ -994,8 +1092,13 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 for (int j0 = 0; j0 < NDT; j0 += JB) {
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        oth[jt] = tr_frag<NKS>(Qh, 16 * l0, 16 * l1, j0 + jt);
-                        otl[jt] = SPLIT ? tr_frag<NKS>(Ql, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        if (FAST) {
+                            oth[jt] = trF(0, j0 + jt, 0);
+                            otl[jt] = SPLIT ? trF(0, j0 + jt, 1) : oth[jt];
+                        } else {
+                            oth[jt] = tr_frag<NKS>(Qh, 16 * l0, 16 * l1, j0 + jt);
+                            otl[jt] = SPLIT ? tr_frag<NKS>(Ql, 16 * l0, 16 * l1, j0 + jt) : oth[jt];
+                        }
                     }
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(dh, dl, oth[jt], otl[jt], dk[j0 + jt]);   // dK += dS^T Q
@@ -1131,7 +1234,9 @@ static int launch_bf_bwd(const cr_attn_bwd_desc* bd, const BfGeom& g, hipStream_
         if (rc) return rc;
         BfGeom gf = g;
         if (g_attn_ts_which == 5) gf.ts = g_attn_ts;
-        hipLaunchKernelGGL((k_bf_bwd_fused<NKS, SPLIT>), dim3(d->B * d->H, 2), dim3(512), img + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4, s, *bd, gf);
+        // (the key-owner workgroups at NKS == 2 keep their four images at a fixed stride of 256 rows)
+        const size_t img_k = NKS == 2 ? (size_t)4 * 256 * 64 * 2 : img;
+        hipLaunchKernelGGL((k_bf_bwd_fused<NKS, SPLIT>), dim3(d->B * d->H, 2), dim3(512), (img_k > img ? img_k : img) + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4 + 64, s, *bd, gf);
         return cr_check_launch("cr_attn_bwd(bf16, fused)");
     }
     BfGeom gq = g, gk = g;
