@@ -91,7 +91,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int IMG = a.T16 * 64;
+    // (DS instantiations run with nkt == NKT: the image size is then a constant and the hi / lo / K / V / weight images are
+    //  immediates apart: an operand read is one per-lane base + immediate instead of an address sum per read)
+    const int IMG = DS > 0 ? 16 * NKT * 64 : a.T16 * 64;
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Kl = Kh + (SPLIT ? IMG : 0);
     __bf16* Vh = Kl + IMG;
