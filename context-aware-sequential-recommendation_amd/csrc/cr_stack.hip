@@ -86,7 +86,9 @@ __device__ __forceinline__ void vec_put(float* vec, const float (&vv)[(ST_NVEC *
 // batch leaves half of the CUs idle (B = 128 on 256 CUs) a sequence is given two of them: both workgroups compute
 // K / V of ALL tiles (phase A, the smaller phase; workgroup 0 also writes them to HBM), then each takes every other
 // tile of the heaviest-first order through phase B / C.  Block i + 1 needs y of both, hence one launch per block.
-template <int NKT, bool SPLIT, int NW, int DS, bool PAIR>
+// HD: heads (1, or 2 with head dim 32: head h is then exactly k-step h of the score product and column tiles 2h, 2h + 1 of
+// the output -- config C3: D = 64, two heads)
+template <int NKT, bool SPLIT, int NW, int DS, bool PAIR, int HD>
 __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
@@ -287,13 +289,16 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                 for (int ct = 0; ct < 4; ++ct) o[ct] = y[ct];                    // residual (modules.py:269) if the tile is dead
             }
             const bool is_dead = !rok || id_n == 0;
+#pragma unroll
+            for (int h = 0; h < HD; ++h) {
+            const int ks_lo = HD == 2 ? h : 0, ks_hi = HD == 2 ? h + 1 : 2;          // k-steps of this head's columns
+            const size_t srow = ((size_t)h * gridDim.x + n) * T + q;                // its row statistics
             if (__all(is_dead ? 1 : 0)) {
                 // the whole tile is padding: A = 0 -> out = residual (known dead downstream, sasrec.py:83)
                 if (ad.row_stats && lg == 0 && rok) {
-                    float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
+                    float* sp = ad.row_stats + srow * 4;
                     sp[0] = 0.0f; sp[1] = 0.0f; sp[2] = 2.0f; sp[3] = 0.0f;
                 }
-                if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);
             } else {
                 // ---- scores St[key][query] (modules.py:216-241), kept for the whole row block
                 f32x4 st[NKT];
@@ -319,18 +324,18 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         const int r0 = 16 * (c0 ? kt : kt + 1), r1 = 16 * (c1 ? kt + 1 : kt);
                         bf8 k0h[2], k0l[2], k1h[2], k1l[2];
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
                             k0h[ks] = row_frag_l(Kh, r0, ks, ln); k1h[ks] = row_frag_l(Kh, r1, ks, ln);
                             k0l[ks] = SPLIT ? row_frag_l(Kl, r0, ks, ln) : k0h[ks]; k1l[ks] = SPLIT ? row_frag_l(Kl, r1, ks, ln) : k1h[ks];
                         }
                         f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
                             x0 = mma<SPLIT>(k0h[ks], k0l[ks], qh[ks], ql[ks], x0);
                             x1 = mma<SPLIT>(k1h[ks], k1l[ks], qh[ks], ql[ks], x1);
                         }
-                        BF_SGB(0x100, (SPLIT ? 8 : 4), 0);
-                        BF_SGB(0x008, (SPLIT ? 12 : 4), 0);
+                        BF_SGB(0x100, (SPLIT ? 8 : 4) / HD, 0);
+                        BF_SGB(0x008, (SPLIT ? 12 : 4) / HD, 0);
                         if (c0) a0 = finish(kt, c0 ? x0 : x1);
                         if (c1) a1 = finish(kt + 1, x1);
                     }
@@ -360,12 +365,12 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                 if (is_dead) inv = 0.0f;
                 const bool any_uni = __any(uniform ? 1 : 0) != 0;
                 if (ad.row_stats && lg == 0 && rok) {            // for the backward kernels
-                    float* sp = ad.row_stats + ((size_t)n * T + q) * 4;
+                    float* sp = ad.row_stats + srow * 4;
                     sp[0] = mx; sp[1] = inv; sp[2] = is_dead ? 2.0f : (uniform ? 1.0f : 0.0f); sp[3] = 0.0f;
                 }
                 // ---- softmax scale, query mask, dropout (modules.py:244-257) folded into one factor per element
                 const float wq = inv * qvq;
-                const uint32_t ridx = attn_row_idx(ad, 0, n, q);
+                const uint32_t ridx = attn_row_idx(ad, h, n, q);
                 const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
                 if (any_uni) {                                   // rare: a row with no valid key at all (modules.py:227-244)
                     const float uni = uniform ? a.invT * qvq : 0.0f;
@@ -404,9 +409,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         split8<SPLIT>(xx, ph, pl);
                         // tiles beyond T16 are not staged (their A is 0); DS instantiations run with nkt == NKT: constant offsets
                         const int ra = 16 * k0, rb = 16 * ((DS > 0 ? k1 < NKT : k1 < a.nkt) ? k1 : k0);
-                        constexpr int JB = SPLIT ? 2 : 4;
+                        constexpr int JB = (SPLIT || HD == 2) ? 2 : 4;
 #pragma unroll
-                        for (int j0 = 0; j0 < 4; j0 += JB) {
+                        for (int j0 = (HD == 2 ? 2 * h : 0); j0 < (HD == 2 ? 2 * h + 2 : 4); j0 += JB) {
                             bf8 vh[JB], vl[JB];
 #pragma unroll
                             for (int jt = 0; jt < JB; ++jt) {
@@ -420,8 +425,9 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                         }
                     }
                 }
-                if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);    // the next tile's x flies under the feed-forward
             }
+            }   // heads
+            if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);        // the next tile's x flies under the feed-forward
             r_store(d.o, mo, o, rok, dcx);
             if (i == 0) SK_TS(7 + 10 * b);
             // ---- LN2 + point-wise feed-forward (modules.py:300-313), row mask (sasrec.py:83)
@@ -486,7 +492,7 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
     const cr_block_desc& b0 = s->blocks[0];
     const cr_attn_desc& a0 = s->attn[0];
     if (b0.D < 8 || b0.D > 64) return "hidden size 8..64";
-    if (a0.H != 1 || a0.d != b0.D) return "one head";
+    if (!((a0.H == 1 && a0.d == b0.D) || (a0.H == 2 && a0.d == 32 && b0.D == 64))) return "one head, or two heads of 32 columns";
     if (a0.precision != CR_PREC_BF16X3 && a0.precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
     if (a0.T < 1 || a0.T > 256 || b0.M != a0.B * a0.T) return "T <= 256, M = B T";
     if ((size_t)b0.M * (size_t)(s->out && s->ld_out > b0.D ? s->ld_out : b0.D) * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
@@ -495,7 +501,7 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
     for (int i = 0; i < s->n_blocks; ++i) {
         const cr_block_desc& b = s->blocks[i];
         const cr_attn_desc& a = s->attn[i];
-        if (b.M != b0.M || b.D != b0.D || a.B != a0.B || a.T != a0.T || a.H != 1 || a.d != b0.D || a.precision != a0.precision) return "blocks differ in shape";
+        if (b.M != b0.M || b.D != b0.D || a.B != a0.B || a.T != a0.T || a.H != a0.H || a.d != a0.d || a.precision != a0.precision) return "blocks differ in shape";
         if (a.attn_weights) return "attention weights are not produced";
         if (a.Q != b.qkv || a.K != b.qkv + (size_t)b.M * b.D || a.V != b.qkv + (size_t)2 * b.M * b.D || a.ld != b.D) return "attn Q/K/V must be the block's qkv";
         if (a.residual != b.q_in || a.ldr != b.D || a.out != b.o || a.ldo != b.D) return "attn residual / out must be the block's q_in / o";
@@ -516,19 +522,20 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
 
 extern "C" int cr_stack_fwd_supported(const cr_stack_desc* s) { return stack_unsupported(s) == nullptr; }
 
-template <int NKT, bool SPLIT, int DS, bool PAIR>
+template <int NKT, bool SPLIT, int DS, bool PAIR, int HD>
 static int launch_stack_d(const StackArgs& a, int B, hipStream_t s) {
     static cr_devmask attr_set = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR>), &attr_set);
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD>), &attr_set);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR>), dim3(B, PAIR ? 2 : 1), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
+    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD>), dim3(B, PAIR ? 2 : 1), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
     return cr_check_launch("cr_stack_fwd");
 }
 template <int NKT, bool SPLIT>
 static int launch_stack(const StackArgs& a, int B, bool pair, hipStream_t s) {
     constexpr int DS = (NKT == 4 || NKT == 13) ? 50 : 0;                 // the headline hidden size as a constant
-    if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false>(a, B, s);
-    return pair ? launch_stack_d<NKT, SPLIT, 0, true>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false>(a, B, s);
+    if (a.blk[0].ad.H == 2) return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
+    if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false, 1>(a, B, s);
+    return pair ? launch_stack_d<NKT, SPLIT, 0, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 1>(a, B, s);
 }
 static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, hipStream_t st) {
     if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, st) : launch_stack<4, false>(a, B, pair, st);

@@ -18,7 +18,8 @@
 // (bitwise reproducible), no atomics.
 //
 // Same inputs, outputs and slab layout as the cr_block_* entry points (castrec.h); results differ from them by the
-// rounding of the split products (~1e-5 relative).  Shapes: D < 64 (the ones column), T <= 224 (two rounds of 7 tiles).
+// rounding of the split products (~1e-5 relative).  Shapes: D <= 64 (D < 64: bias gradients from the ones column; D = 64:
+// from an all-ones product), T <= 224 (two rounds of 7 tiles).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -138,11 +139,14 @@ __device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane
     const int lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + img_off<2>(row0 + 4 * lg + q, 2 * jt + (p >> 1)) + 4 * (p & 1)));
 }
-// acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1)
-template <bool SPLIT>
-__device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
+// acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1).
+// BIAS (D == 64: no spare column for the ones trick): the waves with it == 0 also form accb[j] += 1^T g, the column sums
+// of g (an all-ones A operand: every row of the result is the bias gradient).
+template <bool SPLIT, bool BIAS>
+__device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
                                             int ntr, int it, int jt0) {
     const int lane = lane_now();
+    const bf4 ones = (bf4){(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
     for (int t = 0; t < SB_TPR; ++t) {                   // unrolled, wave-uniform guard: several tiles' reads in flight
         if (t < ntr) {
@@ -162,11 +166,20 @@ __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], const __bf16* Ah, c
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gh[j], acc[j], 0, 0, 0);
+            if (BIAS && it == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, gl[j], accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, gh[j], accb[j], 0, 0, 0);
+                }
+            }
         }
     }
 }
 // accumulators D[in = 16 it + 4 lg + r][out = 16 (jt0 + j) + li] -> slab (row pitch ldw); row D is the bias gradient
-__device__ __forceinline__ void wgrad_store(float* dst, int ldw, float* bias_dst, const f32x4 (&acc)[2], int D, int it, int jt0) {
+// (D < 64), or it comes from accb (BIAS)
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_store(float* dst, int ldw, float* bias_dst, const f32x4 (&acc)[2], const f32x4 (&accb)[2], int D, int it, int jt0) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -179,6 +192,7 @@ __device__ __forceinline__ void wgrad_store(float* dst, int ldw, float* bias_dst
                 else if (k == D) bias_dst[col] = acc[j][r];
             }
         }
+        if (BIAS && it == 0 && lg == 0 && col < D) bias_dst[col] = accb[j][0];
     }
 }
 // plant 1.0 at column D (D < 64) of the lane's row: the bias-gradient row of a^T g
@@ -292,16 +306,17 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     SB_TS(0); SB_TS(1);
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-    f32x4 aw1[2], aw2[2], ag[4], ab[4];
+    constexpr bool BIAS = DS == 64;                       // no spare column: bias gradients by an all-ones product
+    f32x4 aw1[2], aw2[2], ab1[2], ab2[2], ag[4], ab[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; }
+    for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; ab1[j] = aw1[j]; ab2[j] = aw1[j]; }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);       // this wave's tiles of the weight gradients
     // work items of this workgroup: (sequence n, round rd), n = blockIdx.x, + gridDim.x, ...; the inputs of the NEXT
     // item's tile are requested before the weight-gradient phase of the current one (and the first before the weights
     // are staged): a tile's five row blocks come from HBM, 2-3 us that nothing else would cover
-    constexpr bool PF = DS > 0;                          // look-ahead loads only in the D-specialised build (register budget)
+    constexpr bool PF = DS == 50;                        // look-ahead loads only where the register budget allows
     RRaw rdy, rhid, rfin, ro, rq, ry;
     f32x4 agF[4], abF[4];                                 // final-LayerNorm gradient partials (has_ln)
 #pragma unroll
@@ -430,8 +445,8 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
             SB_TS(3);
             __syncthreads();
             SB_TS(4);
-            wgrad_accum<SPLIT>(aw2, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
-            wgrad_accum<SPLIT>(aw1, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+            wgrad_accum<SPLIT, BIAS>(aw2, ab2, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
+            wgrad_accum<SPLIT, BIAS>(aw1, ab1, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
             SB_TS(5);
             __syncthreads();
             SB_TS(6);
@@ -439,8 +454,8 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
     }
     SB_TS(10);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    wgrad_store(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, it, jt0);
-    wgrad_store(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, it, jt0);
+    wgrad_store<BIAS>(bd.g_w1 + so, D, bd.g_b1 + so, aw1, ab1, D, it, jt0);
+    wgrad_store<BIAS>(bd.g_w2 + so, D, bd.g_b2 + so, aw2, ab2, D, it, jt0);
     SB_TS(11);
     ln_grads_store(part, ag, ab, bd.g_ln2_g + so, bd.g_ln2_b + so, D);
     if (a.has_ln) ln_grads_store(part, agF, abF, a.ln.dgamma + so, a.ln.dbeta + so, D);
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
     // the next work item's first inputs (dQ, q_in, d_o, dK) are requested ahead, as in the feed-forward kernel; dV, x
     // (and the old dx) follow at the head of the item, under its first product.  (Not in the generic-D build: its
     // column-tile predicates are live values too, and the look-ahead registers on top of them spilled 270.)
-    constexpr bool PF = DS > 0;
+    constexpr bool PF = DS == 50;
     RRaw rdq, rqin, rdo, rdk;
     auto tile_rows = [&](int n, int rd, int& m, bool& rok) {
         const int q = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
@@ -498,9 +513,10 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
         w_put_perm<3, SB_NT, SPLIT>(Wi, w, D, d.wqkv, 3 * D, 0, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D);
         if (t < 64) gam[t] = gv;
     }
-    f32x4 awq[2], awk[2], awv[2], ag[4], ab[4];
+    constexpr bool BIAS = DS == 64;
+    f32x4 awq[2], awk[2], awv[2], abq[2], abk[2], abv[2], ag[4], ab[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awk[j] = awq[j]; awv[j] = awq[j]; }
+    for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awk[j] = awq[j]; awv[j] = awq[j]; abq[j] = awq[j]; abk[j] = awq[j]; abv[j] = awq[j]; }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
             }
             if (PF && item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
             __syncthreads();
-            wgrad_accum<SPLIT>(awq, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
+            wgrad_accum<SPLIT, BIAS>(awq, abq, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
             __syncthreads();
             if (active) {
                 plant_one(x, D);
@@ -614,15 +630,15 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
                 img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, dV);
             }
             __syncthreads();
-            wgrad_accum<SPLIT>(awk, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
-            wgrad_accum<SPLIT>(awv, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
+            wgrad_accum<SPLIT, BIAS>(awk, abk, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
+            wgrad_accum<SPLIT, BIAS>(awv, abv, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
             __syncthreads();
         }
     }
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    wgrad_store(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0);
-    wgrad_store(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0);
-    wgrad_store(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0);
+    wgrad_store<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, abq, D, it, jt0);
+    wgrad_store<BIAS>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, abk, D, it, jt0);
+    wgrad_store<BIAS>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, abv, D, it, jt0);
     ln_grads_store(part, ag, ab, bd.g_ln1_g + so, bd.g_ln1_b + so, D);
 }
 
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(SB_NT) void k_stack_qkv_bwd(SbArgs a) {
 static const char* sb_unsupported(const cr_block_bwd_desc* bd, int B, int T, int precision) {
     if (!bd) return "NULL description";
     const cr_block_desc& d = bd->f;
-    if (d.D < 8 || d.D >= 64) return "hidden size 8..63 (a spare column carries the bias gradients)";
+    if (d.D < 8 || d.D > 64) return "hidden size 8..64";
     if (precision != CR_PREC_BF16X3 && precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
     if (B < 1 || T < 1 || d.M != B * T) return "M = B T";
     if ((T + 15) / 16 > 2 * SB_TPR) return "T <= 224 (two rounds of 7 row tiles)";
@@ -697,6 +713,7 @@ static int stack_ffn_bwd_any(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* 
     const bool split = precision == CR_PREC_BF16X3;
     hipStream_t s = cr_stream(stream);
     if (d->D == 50) return split ? launch_ffn_bwd<true, 50>(a, s) : launch_ffn_bwd<false, 50>(a, s);
+    if (d->D == 64) return split ? launch_ffn_bwd<true, 64>(a, s) : launch_ffn_bwd<false, 64>(a, s);
     return split ? launch_ffn_bwd<true, 0>(a, s) : launch_ffn_bwd<false, 0>(a, s);
 }
 extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
@@ -731,6 +748,7 @@ static int stack_qkv_bwd_any(const cr_block_bwd_desc* bd, const cr_embed_bwd_des
     const bool split = precision == CR_PREC_BF16X3;
     hipStream_t s = cr_stream(stream);
     if (d->D == 50) return split ? launch_qkv_bwd<true, 50>(a, s) : launch_qkv_bwd<false, 50>(a, s);
+    if (d->D == 64) return split ? launch_qkv_bwd<true, 64>(a, s) : launch_qkv_bwd<false, 64>(a, s);
     return split ? launch_qkv_bwd<true, 0>(a, s) : launch_qkv_bwd<false, 0>(a, s);
 }
 extern "C" int cr_stack_qkv_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {

@@ -221,7 +221,7 @@ class Engine:
             n_slabs = auto_slabs(batch_size * hp.maxlen)
             # the register-layout backward kernels (cr_stack_bwd.hip) deal (sequence, round) items to the slab workgroups:
             # with a slab per item every workgroup runs one round (B = 128 sequences of 13 tiles: 256 workgroups, 256 CUs)
-            if (self.fused and self.attn_precision != "f32" and self.H == 1 and 8 <= self.D < 64 and self.T <= 224
+            if (self.fused and self.attn_precision != "f32" and 8 <= self.D <= 64 and self.T <= 224
                     and os.environ.get("CASTREC_NO_STACK_BWD") != "1"):
                 items = batch_size * (2 if self.T > 112 else 1)
                 if n_slabs < items <= 512:
@@ -663,8 +663,10 @@ class Engine:
         self._bwd_factories.append(factory)
 
     def _stack_kernel_fits(self, nblocks, want_attn):
-        """Shapes cr_stack_fwd takes (castrec.h): one head, D 8..64, bf16 arithmetic, K / V images + weights within the LDS."""
-        if not (self.fused and self.fuse_stack and nblocks >= 1 and not want_attn and self.H == 1 and 8 <= self.D <= 64):
+        """Shapes cr_stack_fwd takes (castrec.h): one head (or two of 32 columns), D 8..64, bf16 arithmetic, K / V images +
+        weights within the LDS."""
+        heads_ok = self.H == 1 or (self.H == 2 and self.D == 64)          # two heads: head dim 32 = one k-step of the score product
+        if not (self.fused and self.fuse_stack and nblocks >= 1 and not want_attn and heads_ok and 8 <= self.D <= 64):
             return False
         if self.attn_precision == "f32" or self.T > 256:
             return False
@@ -712,7 +714,7 @@ class Engine:
                     raise RuntimeError("cr_stack_fwd does not take the stack %s it was sized for" % prefix)
                 self._keep.append((bds, ads))
                 self._call(self.fwd, "cr_stack_fwd", C.byref(sd))
-        if (stack and self.training and self.fuse_stack_bwd and self.D < 64 and self.T <= 224
+        if (stack and self.training and self.fuse_stack_bwd and self.D <= 64 and self.T <= 224
                 and os.environ.get("CASTREC_NO_LNF_FUSION") != "1"):
             # the register-layout FFN backward of the last block can apply this LayerNorm's backward on its way in
             self._lnf_intent[cur.data_ptr()] = (out.data_ptr() + 4 * out_col, prefix + ".lnf", out, out_ld, out_col)

@@ -280,7 +280,8 @@ int cr_block_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t
  * final LayerNorm of kind-2 tails, up to the rounding of the bf16 split products (the projections and the feed-forward
  * run on the bf16 matrix pipe here as well): every buffer of the descriptions is written as those calls write it, so
  * the backward entry points are unchanged.  Requirements (cr_stack_fwd_supported): 1..CR_STACK_MAX_BLOCKS blocks of one
- * shape, H = 1, D = d in 8..64, T <= 208 (CR_PREC_BF16X3) or 256 (CR_PREC_BF16), attn[i] wired to blocks[i]'s buffers
+ * shape, H = 1 with D = d in 8..64 (or H = 2, d = 32, D = 64), T <= 208 (CR_PREC_BF16X3) or 256 (CR_PREC_BF16), attn[i] wired
+ * to blocks[i]'s buffers
  * (Q/K/V = qkv parts, residual = q_in, out = o, masks), no attention weights, blocks[i+1].x == blocks[i].y. */
 #define CR_STACK_MAX_BLOCKS 4
 typedef struct {
@@ -313,7 +314,7 @@ int cr_block_ln_qkv_bwd(const cr_block_bwd_desc* d, void* stream);
 /* The same two backward steps on the bf16 matrix pipe, one workgroup per sequence, rows in registers (cr_stack_bwd.hip):
  * same description, inputs, outputs and slab layout as cr_block_ln_ffn_bwd / cr_block_ln_qkv_bwd (dq_part must be NULL);
  * results equal theirs up to the rounding of the split products.  B, T: the sequences behind the M = B * T rows;
- * precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Shapes: 8 <= D < 64, T <= 224 (cr_stack_bwd_supported). */
+ * precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Shapes: 8 <= D <= 64, T <= 224 (cr_stack_bwd_supported). */
 int cr_stack_bwd_supported(const cr_block_bwd_desc* d, int B, int T, int precision);   /* 1 / 0 */
 int cr_stack_ffn_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
 /* ... of a stack's LAST block, with the backward of the stack's final LayerNorm (sasrec.py:85) applied to the gradient rows

@@ -290,9 +290,11 @@ def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, m
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("env,T,D,B", [("CASTREC_NO_STACK_BWD", 40, 50, 6), ("CASTREC_NO_STACK_BWD", 200, 50, 3), ("CASTREC_NO_STACK_BWD", 33, 24, 5),
-                                       ("CASTREC_NO_STACK_KERNEL", 40, 50, 6), ("CASTREC_NO_STACK_KERNEL", 200, 50, 3), ("CASTREC_NO_STACK_KERNEL", 33, 24, 5)])
-def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, env, T, D, B):
+@pytest.mark.parametrize("env,T,D,B,H", [("CASTREC_NO_STACK_BWD", 40, 50, 6, 1), ("CASTREC_NO_STACK_BWD", 200, 50, 3, 1), ("CASTREC_NO_STACK_BWD", 33, 24, 5, 1),
+                                         ("CASTREC_NO_STACK_KERNEL", 40, 50, 6, 1), ("CASTREC_NO_STACK_KERNEL", 200, 50, 3, 1), ("CASTREC_NO_STACK_KERNEL", 33, 24, 5, 1),
+                                         ("CASTREC_NO_STACK_BWD", 50, 64, 5, 2), ("CASTREC_NO_STACK_KERNEL", 50, 64, 5, 2),     # config C3's shape: two heads
+                                         ("CASTREC_NO_STACK_BWD", 100, 64, 3, 1), ("CASTREC_NO_STACK_KERNEL", 100, 64, 3, 1)])
+def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, env, T, D, B, H):
     """The whole-stack forward (cr_stack.hip) and the register-layout row-phase backward (cr_stack_bwd.hip) against the
     kernels they replace (cr_block_* + cr_attn_fwd): same parameters, same batch, dropout on, n_slabs below AND above the
     batch size.  Same mathematics; the projections / feed-forward / weight gradients run on split bf16 products here and on
@@ -301,7 +303,7 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     activations, 1e-1 on the gradients (ReLU gates of near-zero units flip; measured 4.5e-2)."""
     rs = np.random.RandomState(5)
     itemnum, max_bins = 45, 9
-    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=max_bins, seed=13)
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=max_bins, seed=13)
     a = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
     monkeypatch.setenv(env, "1")
     b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
