@@ -114,7 +114,7 @@ def algo_work(name, fnargs, eng):
         return 2.0 * M * D * 4 * D, None, "mfma"
     if name in ("cr_block_ln_qkv_bwd", "cr_block_ln_qkv_bwd_scatter", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter"):
         return 2.0 * M * D * 6 * D, None, "mfma"
-    if name == "cr_stack_ffn_bwd":
+    if name in ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln"):
         return 2.0 * M * D * 4 * D, None, "mfma"
     if name == "cr_stack_fwd":
         # per block: Q K V projections + causal attention (QK^T + PV, causal half) + the two feed-forward layers
@@ -173,7 +173,7 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
               "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
-              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"]}
+              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"]}
 
 
 def pmc_lookup(abi_name, precision):
