@@ -1,25 +1,22 @@
 // A whole transformer stack (sasrec.py:65-85: per block LN1 -> Q/K/V -> causal attention -> LN2 -> feed-forward,
-// then the final LayerNorm) forward in ONE launch, one workgroup per sequence.
+// then the final LayerNorm; optionally the embedding gather that composes its input) forward, one workgroup -- or a
+// pair -- per sequence: ONE launch for the stack, or one per block when a sequence gets two workgroups (PAIR).
 //
 // Why.  At the headline shape (T = 200, D = 50, B = 128) a block's row phases are 25 600 x 50 matrices: the separate
 // kernels (cr_block_ln_qkv_fwd, cr_attn_fwd, cr_block_ln_ffn_fwd) each run 15-30 us of which launch ramp, weight staging
 // and the first HBM round trip are the larger part -- ten launches per step forward.  Everything a sequence needs is
 // 200 rows: its K / V images (bf16 hi + lo, 104 KB) and one phase's weights (48 KB) fit the 160 KB LDS of a CU, and
-// all row-local work stays in the registers of the wave that owns the 16-row tile.
-//
-// Register layout R.  A wave owns 16-row tiles; lane (li = lane & 15, lg = lane >> 4) holds row li of the tile, columns
-// 16 ct + 4 lg + r (ct, r = 0..3) -- the D-operand layout of v_mfma_f32_16x16x32_bf16 for the TRANSPOSED product
-// out^T = W^T x^T:  A = W^T (out column = li, k = input column; two ds_read_b64_tr_b16 of the [in][out] weight image),
-// B = x^T (lane = row li, k-elements = its own registers: k index 8 lg + j <-> column 32 ks + 16 (j >> 2) + 4 lg + (j & 3)),
-// D[out column 16 ct + 4 lg + r][row li] -- again layout R.  So LayerNorm -> projection -> ... -> feed-forward chain
-// through registers with no transposition; the attention core takes Q the same way (B operand of S^T = K Q^T, the K
-// image stored in that k order), and its output product is formed as O^T = V^T P^T, which lands in layout R too.
+// all row-local work stays in the registers of the wave that owns the 16-row tile (layout R, cr_rlayout.hpp: the chain
+// LayerNorm -> projection -> ... -> feed-forward runs through registers with no transposition; the attention core takes
+// Q the same way -- B operand of S^T = K Q^T, the K image stored in that k order -- and its output product is formed as
+// O^T = V^T P^T, which lands in layout R too).
 //
 // Every intermediate the backward kernels read (q_in, Q K V, row statistics, o, f_in, hid, y) is written to HBM as
-// before; tiles are re-read from there (L2) across the phase barriers, by the wave that wrote them.
+// before; a wave re-reads from there (L2) only rows it wrote itself.
 // Arithmetic: bf16 MFMA on split (hi + lo, three products) or plain bf16 operands, fp32 accumulation
 // (cr_attn_desc.precision of the blocks); element-wise work in fp32.  Counter-based dropout: same element indices as
 // the separate kernels, so the backward kernels regenerate the same masks.
+// Shapes: one head with D <= 64, or two heads of 32 columns (D = 64); T <= 208 (split) / 256 (plain).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
