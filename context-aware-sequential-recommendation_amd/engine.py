@@ -204,6 +204,7 @@ class Engine:
         self.fuse_embed = os.environ.get("CASTREC_NO_EMBED_FUSION") != "1"
         self.fuse_stack = os.environ.get("CASTREC_NO_STACK_KERNEL") != "1"
         self.fuse_stack_bwd = os.environ.get("CASTREC_NO_STACK_BWD") != "1"
+        self.fuse_wide = os.environ.get("CASTREC_NO_WIDE") != "1"
         self._pending_embed = {}
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
@@ -457,18 +458,25 @@ class Engine:
         wqkv, bqkv = self._pptr(pfx + "wqkv"), self._pptr(pfx + "bqkv")
         if self.fused:
             return self._op_block_fused(x, y, pfx, attn_out, q_in, o, f_in, hid, qkv, kvalid, qvalid, skip_qkv, tail, collect)
-        # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
-        ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
-                       1e-8, kvalid.data_ptr(), qvalid.data_ptr())
-        self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln1))
-        # Q = LN1(x) Wq + bq ; K = x Wk + bk ; V = x Wv + bv   (modules.py:203-205), one batched launch
+        # hidden sizes 128 / 192 / 256 on bf16 arithmetic: the row phases as ONE launch each (cr_wide.hip)
+        prec = ATTN_PRECISIONS[self.attn_precision]
+        wbd = self._block_desc(x, y, pfx)
+        wide = bool(self.fuse_wide and prec != L.PREC_F32 and L.lib.cr_wide_supported(C.byref(wbd), prec))
         MD4 = 4 * M * D
-        gs = []
-        for part, src in enumerate((q_in, x, x)):
-            gd = O.gemm_desc(src, D, None, 3 * D, None, D, M, D, D)
-            gd.B, gd.bias, gd.C = wqkv + 4 * part * D, bqkv + 4 * part * D, qkv.data_ptr() + part * MD4
-            gs.append(gd)
-        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 3)(*gs), 3)
+        if wide:
+            self._call(self.fwd, "cr_wide_ln_qkv_fwd", C.byref(wbd), prec)
+        else:
+            # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
+            ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
+                           1e-8, kvalid.data_ptr(), qvalid.data_ptr())
+            self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln1))
+            # Q = LN1(x) Wq + bq ; K = x Wk + bk ; V = x Wv + bv   (modules.py:203-205), one batched launch
+            gs = []
+            for part, src in enumerate((q_in, x, x)):
+                gd = O.gemm_desc(src, D, None, 3 * D, None, D, M, D, D)
+                gd.B, gd.bias, gd.C = wqkv + 4 * part * D, bqkv + 4 * part * D, qkv.data_ptr() + part * MD4
+                gs.append(gd)
+            self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 3)(*gs), 3)
         # attention core (modules.py:208-269), residual = queries
         ad = O.attn_desc(qkv, None, None, D, kvalid, qvalid, q_in, D, o, D, B, T, H, d_head,
                          rng=self.rng(pfx + "attn"), batch_global=self.batch_global,
@@ -480,15 +488,18 @@ class Engine:
             ad.row_stats = self.vec(pfx + "row_stats", H * B * T * 4).data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         # LN2 + FFN (modules.py:280-318), residual = LN2 output, then * mask (sasrec.py:83)
-        ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
-                       1e-8, None, None)
-        self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln2))
-        f1 = O.gemm_desc(f_in, D, None, D, hid, D, M, D, D, relu=True, rng=self.rng(pfx[:-1] + ".ffn1"))
-        f1.B, f1.bias = self._pptr(pfx + "w1"), self._pptr(pfx + "b1")
-        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f1), 1)
-        f2 = O.gemm_desc(hid, D, None, D, y, D, M, D, D, rng=self.rng(pfx[:-1] + ".ffn2"), residual=f_in, ldr=D, mask_ids=ids)
-        f2.B, f2.bias = self._pptr(pfx + "w2"), self._pptr(pfx + "b2")
-        self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f2), 1)
+        if wide:
+            self._call(self.fwd, "cr_wide_ln_ffn_fwd", C.byref(wbd), prec)
+        else:
+            ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
+                           1e-8, None, None)
+            self._call(self.fwd, "cr_layernorm_fwd", C.byref(ln2))
+            f1 = O.gemm_desc(f_in, D, None, D, hid, D, M, D, D, relu=True, rng=self.rng(pfx[:-1] + ".ffn1"))
+            f1.B, f1.bias = self._pptr(pfx + "w1"), self._pptr(pfx + "b1")
+            self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f1), 1)
+            f2 = O.gemm_desc(hid, D, None, D, y, D, M, D, D, rng=self.rng(pfx[:-1] + ".ffn2"), residual=f_in, ldr=D, mask_ids=ids)
+            f2.B, f2.bias = self._pptr(pfx + "w2"), self._pptr(pfx + "b2")
+            self._call(self.fwd, "cr_gemm_rows", (L.GemmDesc * 1)(f2), 1)
         if not self.training:
             return
 
@@ -499,6 +510,28 @@ class Engine:
             dqkv = self.buf(pfx + "dqkv", D, rows=3 * M)          # [3, M, D]
             stats = self.vec(pfx + "stats", H * B * T * 4)
             S = self.Gs.shape[1]
+            if wide:
+                G = self._gptr
+                bbd = L.BlockBwdDesc(L.BlockDesc.from_buffer_copy(wbd), dy.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dx.data_ptr(),
+                                     self._acc(id(dx)), G(pfx + "ln1.gamma"), G(pfx + "ln1.beta"), G(pfx + "wqkv"), G(pfx + "bqkv"),
+                                     G(pfx + "ln2.gamma"), G(pfx + "ln2.beta"), G(pfx + "w1"), G(pfx + "b1"), G(pfx + "w2"), G(pfx + "b2"),
+                                     S, self.n_slabs)
+                # dy -> g2, g1, d_o (+ dgamma2 / dbeta2 slabs); then dW2 db2 dW1 db1
+                self._call(lst, "cr_wide_ln_ffn_bwd", C.byref(bbd), g2.data_ptr(), g1.data_ptr(), prec)
+                w = (L.WgradDesc * 2)(L.WgradDesc(hid.data_ptr(), D, g2.data_ptr(), D, G(pfx + "w2"), D, G(pfx + "b2"), M, D, D),
+                                      L.WgradDesc(f_in.data_ptr(), D, g1.data_ptr(), D, G(pfx + "w1"), D, G(pfx + "b1"), M, D, D))
+                self._call(lst, "cr_gemm_wgrad", w, 2, S, self.n_slabs)
+                dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + MD4, dqkv.data_ptr() + 2 * MD4
+                abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dq, dk, dv, D, stats.data_ptr())
+                self._call(lst, "cr_attn_bwd", C.byref(abd))
+                gw, gb = G(pfx + "wqkv"), G(pfx + "bqkv")
+                w2 = (L.WgradDesc * 3)(L.WgradDesc(q_in.data_ptr(), D, dq, D, gw, 3 * D, gb, M, D, D),
+                                       L.WgradDesc(x.data_ptr(), D, dk, D, gw + 4 * D, 3 * D, gb + 4 * D, M, D, D),
+                                       L.WgradDesc(x.data_ptr(), D, dv, D, gw + 8 * D, 3 * D, gb + 8 * D, M, D, D))
+                self._call(lst, "cr_gemm_wgrad", w2, 3, S, self.n_slabs)
+                # (dQ | dK | dV, d_o) -> dx (+ dgamma1 / dbeta1 slabs)
+                self._call(lst, "cr_wide_ln_qkv_bwd", C.byref(bbd), prec)
+                return lst
             # (a) gradient wrt FFN2 pre-dropout output: dy * mask * keep/(1-rate)
             e = L.EltDesc(L.ELT_GRADPREP, dy.data_ptr(), D, None, 0, g2.data_ptr(), D, M, D, self.rng(pfx[:-1] + ".ffn2"), ids.data_ptr(), 0)
             self._call(lst, "cr_eltwise", C.byref(e))

@@ -325,6 +325,19 @@ int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, vo
 /* ... with the embedding gather's backward applied instead of storing dx: arguments as cr_block_ln_qkv_bwd_scatter */
 int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);
 
+/* ---- the same four row phases for hidden sizes 128 / 192 / 256 (configs C4, C5) on the bf16 matrix pipe (cr_wide.hip):
+ * one launch each where the unfused path runs cr_layernorm_* + cr_gemm_rows (+ cr_eltwise) chains -- modules.py:53-80
+ * (normalize), 203-205 (Q/K/V dense layers), 280-318 (feedforward) and their gradients.  Same descriptions and buffers as
+ * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: the weight gradients are NOT
+ * formed here (cr_gemm_wgrad takes q_in/x/dqkv, hid/g2 and f_in/g1): the backward entries only write the dgamma / dbeta
+ * slabs, and cr_wide_ln_ffn_bwd returns the two operands g2 = dy * dropout * mask and g1 = gated(g2 W2^T), dense [M, D];
+ * attn_delta and dq_part are not taken. */
+int cr_wide_supported(const cr_block_desc* d, int precision);   /* 1 / 0 */
+int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream);
+int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream);
+int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* d, float* g2, float* g1, int precision, void* stream);
+int cr_wide_ln_qkv_bwd(const cr_block_bwd_desc* d, int precision, void* stream);
+
 /* cr_block_ln_qkv_bwd of a stack's FIRST block whose input x was composed by an embedding gather: instead of
  * storing dx the kernel applies that gather's backward to its rows (cr_embed_bwd, large-table mode): `sc` is the
  * descriptor that call would have taken (sc->f.out is ignored; no small-table slabs; d_addend dense [M, D]);
