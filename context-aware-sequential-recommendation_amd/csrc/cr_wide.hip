@@ -25,8 +25,9 @@
 #include "cr_attn_common.hpp"
 #include "cr_bf16.hpp"
 
-#define WD_NT 512                 // threads per workgroup
-#define WD_ROWS 128               // rows per workgroup pass
+// Threads per workgroup: 8 waves (128 rows) at D = 128; 4 waves (64 rows) above, where a row's operands and partial results
+// need more than the 256 registers a wave gets at two waves per SIMD (one wave per SIMD may use all 512).
+template <int NCT> struct WdCfg { static constexpr int NT = NCT <= 8 ? 512 : 256, ROWS = NT / 4, NW = NT / 64, ITEMS = 128 * NCT / NT; };
 
 // ---- layout R rows of a dense [*, D] matrix, D = 16 NCT exactly (no boundary cases at these sizes) -------------
 template <int NCT>
@@ -117,14 +118,14 @@ __device__ __forceinline__ void wr_split2(const f32x4& a, const f32x4& b, bf8& h
 // ---- weight panels ----------------------------------------------------------------------------------------
 // An item is 8 consecutive floats of a weight row (two dword-aligned 16-byte loads).  D * 8 items per panel,
 // D / 64 per thread.
-template <int NCT> struct PanelRegs { float v[NCT / 4][8]; };
+template <int NCT> struct PanelRegs { float v[WdCfg<NCT>::ITEMS][8]; };
 
 // forward panel: W[k][c0 .. c0 + 63], k < D; item = (k, chunk of 8 columns)
 template <int NCT>
 __device__ __forceinline__ void fpanel_issue(PanelRegs<NCT>& r, const float* W, int ld, int c0) {
 #pragma unroll
-    for (int u = 0; u < NCT / 4; ++u) {
-        const int item = threadIdx.x + WD_NT * u;
+    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
         const int k = item >> 3, ch = item & 7;
         const float* p = W + (size_t)k * ld + c0 + 8 * ch;
         const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
@@ -135,8 +136,8 @@ __device__ __forceinline__ void fpanel_issue(PanelRegs<NCT>& r, const float* W, 
 template <int NCT, bool SPLIT>
 __device__ __forceinline__ void fpanel_put(const PanelRegs<NCT>& r, __bf16* img) {
 #pragma unroll
-    for (int u = 0; u < NCT / 4; ++u) {
-        const int item = threadIdx.x + WD_NT * u;
+    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
         const int k = item >> 3, ch = item & 7;
         bf8 h, l;
         split8<SPLIT>(r.v[u], h, l);
@@ -149,8 +150,8 @@ __device__ __forceinline__ void fpanel_put(const PanelRegs<NCT>& r, __bf16* img)
 template <int NCT>
 __device__ __forceinline__ void bpanel_issue(PanelRegs<NCT>& r, const float* W, int ld, int j0, int c0) {
 #pragma unroll
-    for (int u = 0; u < NCT / 4; ++u) {
-        const int item = threadIdx.x + WD_NT * u;
+    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
         const int j = item / (2 * NCT), c8 = item % (2 * NCT);
         const float* p = W + (size_t)(j0 + j) * ld + c0 + 8 * c8;
         const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
@@ -161,8 +162,8 @@ __device__ __forceinline__ void bpanel_issue(PanelRegs<NCT>& r, const float* W, 
 template <int NCT, bool SPLIT>
 __device__ __forceinline__ void bpanel_put(const PanelRegs<NCT>& r, __bf16* img) {
 #pragma unroll
-    for (int u = 0; u < NCT / 4; ++u) {
-        const int item = threadIdx.x + WD_NT * u;
+    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
         const int j = item / (2 * NCT), c8 = item % (2 * NCT);
         const int ks = c8 >> 2, q = c8 & 3, h4 = 4 * (q >> 1);
         const int chA = 4 * (ks & 1) + 2 * (q & 1);
@@ -226,30 +227,35 @@ struct WideLds {
     static constexpr int HALF = 16 * NCT * 64;                        // bf16 elements of one image half
     static constexpr int BUF = (SPLIT ? 2 : 1) * HALF;                // one panel buffer
     static constexpr size_t PANEL_BYTES = 2 * (size_t)BUF * 2;        // double buffered
-    static constexpr size_t SLOT_BYTES = 8 * 2 * 16 * NCT * 4;        // [8 waves][gamma | beta][D] floats (backward kernels)
+    static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT>::NW * 2 * 16 * NCT * 4;   // [waves][gamma | beta][D] floats (backward kernels)
 };
+
+// The panel loops below are written so that nothing depends on their being unrolled: the operand of a part is ONE register
+// array, reloaded (from rows this lane stored itself) and split again at a part boundary behind a workgroup-uniform branch,
+// and every panel's result goes to memory.  D = 128 unrolls them (static schedule, 6 panels); above that the body stays a loop.
+#define WD_UNROLL _Pragma("unroll")
+#define WD_PANEL_LOOP(NPAN) _Pragma("clang loop unroll_count(NCT <= 8 ? NPAN : 1)")
 
 // =====================================================================================================
 // forward: LN1 + Q / K / V projections
 // =====================================================================================================
 template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WD_NT) void k_wide_qkv_fwd(cr_block_desc d) {
+__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
     typedef WideLds<NCT, SPLIT> LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
-    const int m = blockIdx.x * WD_ROWS + 16 * wave + li;
+    const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
     PanelRegs<NCT> pr;
     fpanel_issue<NCT>(pr, d.wqkv, 3 * D, 0);
-    f32x4 x[NCT];
-    wr_load<NCT>(x, d.x, m, rok);
     bf8 oh[NKS], ol[NKS];                                 // the current operand: q_in for Q, x for K and V
     {
+        f32x4 x[NCT];
+        wr_load<NCT>(x, d.x, m, rok);
         float mean, rs, sum;
         wr_stats<NCT>(x, mean, rs, sum);
-        f32x4 q[NCT];
         float ys = 0.0f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -261,25 +267,29 @@ __global__ __launch_bounds__(WD_NT) void k_wide_qkv_fwd(cr_block_desc d) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y = fmaf(g[ct][r], (x[4 * p + ct][r] - mean) * rs, b[ct][r]);
-                    q[4 * p + ct][r] = y;
+                    x[4 * p + ct][r] = y;
                     ys += y;
                 }
         }
         ys = grp_sum(ys);
-        wr_store<NCT>(d.q_in, m, rok, q);
+        wr_store<NCT>(d.q_in, m, rok, x);
         if (rok && (lane >> 4) == 0) {                   // modules.py:222 (keys = x), 248-249 (queries = LN1(x))
             d.k_valid[m] = (sum != 0.0f) ? 1.0f : 0.0f;
             d.q_valid[m] = (ys != 0.0f) ? 1.0f : 0.0f;
         }
-        wr_split<NCT, SPLIT>(q, oh, ol);
+        wr_split<NCT, SPLIT>(x, oh, ol);
     }
     fpanel_put<NCT, SPLIT>(pr, pb);
     __syncthreads();
-#pragma unroll
+    WD_PANEL_LOOP(NPAN)
     for (int i = 0; i < NPAN; ++i) {
         const int part = i / NP, p = i % NP;
         if (i + 1 < NPAN) fpanel_issue<NCT>(pr, d.wqkv, 3 * D, ((i + 1) / NP) * D + 64 * ((i + 1) % NP));
-        if (i == NP) wr_split<NCT, SPLIT>(x, oh, ol);     // K and V take the un-normalised rows (modules.py:204-205)
+        if (i == NP) {                                    // K and V take the un-normalised rows (modules.py:204-205)
+            f32x4 x[NCT];
+            wr_load<NCT>(x, d.x, m, rok);
+            wr_split<NCT, SPLIT>(x, oh, ol);
+        }
         f32x4 acc[4], bias[4];
         wr_vec4(bias, d.bqkv + part * D, p);
         acc_zero(acc);
@@ -296,18 +306,18 @@ __global__ __launch_bounds__(WD_NT) void k_wide_qkv_fwd(cr_block_desc d) {
 // forward: LN2 + feed-forward
 // =====================================================================================================
 template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WD_NT) void k_wide_ffn_fwd(cr_block_desc d) {
+__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     typedef WideLds<NCT, SPLIT> LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int m = blockIdx.x * WD_ROWS + 16 * wave + li;
+    const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
     const DropCtx dc1 = drop_ctx(d.drop_ffn1), dc2 = drop_ctx(d.drop_ffn2);
     PanelRegs<NCT> pr;
     fpanel_issue<NCT>(pr, d.w1, D, 0);
-    bf8 fh[NKS], fl[NKS], hh[NKS], hl[NKS];
+    bf8 oh[NKS], ol[NKS];                                 // f_in, then hid
     {
         f32x4 x[NCT];
         wr_load<NCT>(x, d.o, m, rok);
@@ -324,88 +334,128 @@ __global__ __launch_bounds__(WD_NT) void k_wide_ffn_fwd(cr_block_desc d) {
                 for (int r = 0; r < 4; ++r) x[4 * p + ct][r] = fmaf(g[ct][r], (x[4 * p + ct][r] - mean) * rs, b[ct][r]);
         }
         wr_store<NCT>(d.f_in, m, rok, x);
-        wr_split<NCT, SPLIT>(x, fh, fl);
+        wr_split<NCT, SPLIT>(x, oh, ol);
     }
     const int id = rok ? d.mask_ids[m] : 0;
     const uint32_t xrow = ((d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
     fpanel_put<NCT, SPLIT>(pr, pb);
     __syncthreads();
-#pragma unroll
+    WD_PANEL_LOOP(NPAN)
     for (int i = 0; i < NPAN; ++i) {
         const int part = i / NP, p = i % NP;
         if (i + 1 < NPAN) fpanel_issue<NCT>(pr, (i + 1) / NP ? d.w2 : d.w1, D, 64 * ((i + 1) % NP));
-        f32x4 acc[4], bias[4];
-        wr_vec4(bias, part ? d.b2 : d.b1, p);
-        acc_zero(acc);
-        if (part == 0) {
-            panel_mma<NCT, SPLIT, true>(acc, pb + (i & 1) * LD::BUF, fh, fl);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[ct][r] + bias[ct][r], 0.0f);                          // modules.py:300
-                    if (dc1.on) v *= drop_factor_x(dc1, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc1.key);
-                    acc[ct][r] = v;
-                }
-            wr_store4(d.hid, D, m, rok, p, acc);
-            wr_split2<SPLIT>(acc[0], acc[1], hh[2 * p], hl[2 * p]);
-            wr_split2<SPLIT>(acc[2], acc[3], hh[2 * p + 1], hl[2 * p + 1]);
-        } else {
-            f32x4 res[4];
-            wr_load4(res, d.f_in, D, m, rok, p);          // this lane's own stores (residual = LN2 output, modules.py:313)
-            panel_mma<NCT, SPLIT, true>(acc, pb + (i & 1) * LD::BUF, hh, hl);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[ct][r] + bias[ct][r];
-                    if (dc2.on) v *= drop_factor_x(dc2, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc2.key);
-                    v += res[ct][r];
-                    acc[ct][r] = id ? v : 0.0f;                                              // sasrec.py:83
-                }
-            wr_store4(d.y, D, m, rok, p, acc);
+        if (i == NP) {                                    // the second layer's operand: the hidden rows this lane stored
+            f32x4 h[NCT];
+            wr_load<NCT>(h, d.hid, m, rok);
+            wr_split<NCT, SPLIT>(h, oh, ol);
         }
+        f32x4 acc[4], bias[4], res[4];
+        wr_vec4(bias, part ? d.b2 : d.b1, p);
+        if (part) wr_load4(res, d.f_in, D, m, rok, p);    // own stores (residual = LN2 output, modules.py:313)
+        acc_zero(acc);
+        panel_mma<NCT, SPLIT, true>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+        DropCtx dc;                                       // (field by field: a selected struct reference went through scratch)
+        dc.on = dc1.on;
+        dc.key = part ? dc2.key : dc1.key;
+        dc.thresh = part ? dc2.thresh : dc1.thresh;
+        dc.scale = part ? dc2.scale : dc1.scale;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[ct][r] + bias[ct][r];
+                if (!part) v = fmaxf(v, 0.0f);                                               // modules.py:300
+                if (dc.on) v *= drop_factor_x(dc, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc.key);
+                if (part) v = id ? v + res[ct][r] : 0.0f;                                    // modules.py:313, sasrec.py:83
+                acc[ct][r] = v;
+            }
+        wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
         if (i + 1 < NPAN) fpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
         __syncthreads();
     }
 }
 
 // ---- column sums of the workgroup's rows into per-thread accumulators ---------------------------------------
-// a[ct][r], b[ct][r]: the lane's contributions (row li) to dgamma / dbeta at columns 16 ct + 4 lg + r.  After the call
-// thread c < D has added this pass's dgamma[c], thread D + c its dbeta[c] into `tot`.  Two barriers.
+// colsum_put: a[ct][r] = the lane's contributions (row li) at columns 16 ct + 4 lg + r; the wave's sums go to its LDS slot
+// (which = 0: dgamma half, 1: dbeta half).  colsum_fold: after both puts, thread c < D adds this pass's dgamma[c] to tg and
+// dbeta[c] to tb, waves in a fixed order.  Two barriers.
 template <int NCT>
-__device__ __forceinline__ void colsum_fold(float* slots, const f32x4 (&a)[NCT], const f32x4 (&b)[NCT], float& tot) {
+__device__ __forceinline__ void colsum_put(float* slots, const f32x4 (&a)[NCT], int which) {
     constexpr int D = 16 * NCT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    float* sg = slots + (size_t)wave * 2 * D;
+    float* sg = slots + (size_t)wave * 2 * D + which * D;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        f32x4 ga, gb;
+        f32x4 ga;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ga[r] = cr_row16_sum(a[ct][r]);
-            gb[r] = cr_row16_sum(b[ct][r]);
+        for (int r = 0; r < 4; ++r) ga[r] = cr_row16_sum(a[ct][r]);
+        if (li == 0) *reinterpret_cast<float4*>(sg + 16 * ct + 4 * lg) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+    }
+}
+template <int NCT>
+__device__ __forceinline__ void colsum_fold(const float* slots, float& tg, float& tb) {
+    constexpr int D = 16 * NCT, NW = WdCfg<NCT>::NW;
+    __syncthreads();
+    if ((int)threadIdx.x < D) {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            s0 += slots[(size_t)w * 2 * D + threadIdx.x];
+            s1 += slots[(size_t)w * 2 * D + D + threadIdx.x];
         }
-        if (li == 0) {
-            *reinterpret_cast<float4*>(sg + 16 * ct + 4 * lg) = make_float4(ga[0], ga[1], ga[2], ga[3]);
-            *reinterpret_cast<float4*>(sg + D + 16 * ct + 4 * lg) = make_float4(gb[0], gb[1], gb[2], gb[3]);
-        }
+        tg += s0;
+        tb += s1;
     }
     __syncthreads();
-    if ((int)threadIdx.x < 2 * D) {
-        float s = 0.0f;
+}
+
+// LayerNorm backward of the lane's row (modules.py:74-78): g = gradient of the output row (the dbeta contributions), x = the
+// LayerNorm's input row; returns dx in g and the dgamma contributions (g * xhat) in x.  Two passes over two arrays (a third
+// array for xhat cost the registers the D = 256 kernels do not have).
+template <int NCT>
+__device__ __forceinline__ void wr_ln_bwd(f32x4 (&g)[NCT], f32x4 (&x)[NCT], const float* gamma) {
+    constexpr int NP = NCT / 4;
+    constexpr float invD = 1.0f / (16 * NCT);
+    float mean, rs, sum;
+    wr_stats<NCT>(x, mean, rs, sum);
+    float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += slots[(size_t)w * 2 * D + threadIdx.x];
-        tot += s;
+    for (int p = 0; p < NP; ++p) {
+        f32x4 gm[4];
+        wr_vec4(gm, gamma, p);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = (x[4 * p + ct][r] - mean) * rs;
+                const float dg = g[4 * p + ct][r] * gm[ct][r];
+                c1 += dg;
+                c2 = fmaf(dg, h, c2);
+            }
     }
-    __syncthreads();
+    c1 = grp_sum(c1) * invD;
+    c2 = grp_sum(c2) * invD;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        f32x4 gm[4];
+        wr_vec4(gm, gamma, p);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = (x[4 * p + ct][r] - mean) * rs;
+                const float go = g[4 * p + ct][r];
+                g[4 * p + ct][r] = rs * (go * gm[ct][r] - c1 - h * c2);
+                x[4 * p + ct][r] = go * h;
+            }
+    }
 }
 
 // =====================================================================================================
 // backward: feed-forward + LN2
 // =====================================================================================================
 template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WD_NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
+__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
@@ -415,16 +465,17 @@ __global__ __launch_bounds__(WD_NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const DropCtx dc2 = drop_ctx(d.drop_ffn2);
     const float gate_scale = d.drop_ffn1.rate > 0.0f ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-    const int nblk = (d.M + WD_ROWS - 1) / WD_ROWS;
-    float tot = 0.0f;
+    const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
+    float tg = 0.0f, tb = 0.0f;
+#pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int m = blk * WD_ROWS + 16 * wave + li;
+        const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
         PanelRegs<NCT> pr;
         bpanel_issue<NCT>(pr, d.w2, D, 0, 0);
         const int id = rok ? d.mask_ids[m] : 0;
         const uint32_t xrow = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
-        bf8 ah[NKS], al[NKS], gh[NKS], gl[NKS];
+        bf8 oh[NKS], ol[NKS];                             // g2, then g1
         {
             // g2 = dy * dropout(ffn2) * mask: gradient of the second dense layer's output
             f32x4 g[NCT];
@@ -438,92 +489,59 @@ __global__ __launch_bounds__(WD_NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, fl
                     g[ct][r] = id ? v : 0.0f;
                 }
             wr_store<NCT>(g2out, m, rok, g);
-            wr_split<NCT, SPLIT>(g, ah, al);
+            wr_split<NCT, SPLIT>(g, oh, ol);
         }
-        f32x4 df[NCT];
         bpanel_put<NCT, SPLIT>(pr, pb);
         __syncthreads();
-#pragma unroll
+        WD_PANEL_LOOP(NPAN)
         for (int i = 0; i < NPAN; ++i) {
             const int part = i / NP, p = i % NP;
             if (i + 1 < NPAN) bpanel_issue<NCT>(pr, (i + 1) / NP ? d.w1 : d.w2, D, 64 * ((i + 1) % NP), 0);
+            if (i == NP) {
+                f32x4 g[NCT];
+                wr_load<NCT>(g, g1out, m, rok);           // own stores
+                wr_split<NCT, SPLIT>(g, oh, ol);
+            }
             f32x4 acc[4], aux[4];
             wr_load4(aux, part ? bd.dy : d.hid, D, m, rok, p);
             acc_zero(acc);
-            if (part == 0) {
-                // g1 = (g2 W2^T) gated by the stored post-dropout ReLU output (modules.py:300-303)
-                panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, ah, al);
+            panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, oh, ol);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[ct][r] = aux[ct][r] > 0.0f ? acc[ct][r] * gate_scale : 0.0f;
-                wr_store4(g1out, D, m, rok, p, acc);
-                wr_split2<SPLIT>(acc[0], acc[1], gh[2 * p], gl[2 * p]);
-                wr_split2<SPLIT>(acc[2], acc[3], gh[2 * p + 1], gl[2 * p + 1]);
-            } else {
-                // df_in = (g1 W1^T + dy) * mask   (residual branch of modules.py:313)
-                panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, gh, gl);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) df[4 * p + ct][r] = id ? acc[ct][r] + aux[ct][r] : 0.0f;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    // part 0: g1 = (g2 W2^T) gated by the stored post-dropout ReLU output (modules.py:300-303)
+                    // part 1: df_in = (g1 W1^T + dy) * mask (residual branch of modules.py:313), parked in d_o
+                    const float v0 = aux[ct][r] > 0.0f ? acc[ct][r] * gate_scale : 0.0f;
+                    const float v1 = id ? acc[ct][r] + aux[ct][r] : 0.0f;
+                    acc[ct][r] = part ? v1 : v0;
+                }
+            wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);
             if (i + 1 < NPAN) bpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
             __syncthreads();
         }
-        // LN2 backward (modules.py:74-78): d_o = rstd * (df * gamma - mean(df * gamma) - xhat * mean(df * gamma * xhat))
         {
-            f32x4 xh[NCT];
+            f32x4 df[NCT], xh[NCT];
+            wr_load<NCT>(df, bd.d_o, m, rok);             // own stores
             wr_load<NCT>(xh, d.o, m, rok);
-            float mean, rs, sum;
-            wr_stats<NCT>(xh, mean, rs, sum);
-            float c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                f32x4 g[4];
-                wr_vec4(g, d.ln2_g, p);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float h = (xh[4 * p + ct][r] - mean) * rs;
-                        const float dg = df[4 * p + ct][r] * g[ct][r];
-                        xh[4 * p + ct][r] = h;
-                        c1 += dg;
-                        c2 = fmaf(dg, h, c2);
-                    }
-            }
-            constexpr float invD = 1.0f / D;
-            c1 = grp_sum(c1) * invD;
-            c2 = grp_sum(c2) * invD;
-            float delta = 0.0f;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                f32x4 g[4], dxo[4];
-                wr_vec4(g, d.ln2_g, p);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dxo[ct][r] = rs * (df[4 * p + ct][r] * g[ct][r] - c1 - xh[4 * p + ct][r] * c2);
-                wr_store4(bd.d_o, D, m, rok, p, dxo);
-            }
-            (void)delta;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xh[ct][r] *= df[ct][r];                 // dgamma contributions; dbeta's are df
-            colsum_fold<NCT>(slots, xh, df, tot);
+            colsum_put<NCT>(slots, df, 1);
+            wr_ln_bwd<NCT>(df, xh, d.ln2_g);
+            wr_store<NCT>(bd.d_o, m, rok, df);
+            colsum_put<NCT>(slots, xh, 0);
+            colsum_fold<NCT>(slots, tg, tb);
         }
     }
-    if ((int)threadIdx.x < D) bd.g_ln2_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tot;
-    else if ((int)threadIdx.x < 2 * D) bd.g_ln2_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x - D] = tot;
+    if ((int)threadIdx.x < D) {
+        bd.g_ln2_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tg;
+        bd.g_ln2_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tb;
+    }
 }
 
 // =====================================================================================================
 // backward: Q / K / V projections + LN1
 // =====================================================================================================
 template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WD_NT) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
+__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
@@ -532,126 +550,63 @@ __global__ __launch_bounds__(WD_NT) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
     float* slots = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
     const size_t MD = (size_t)d.M * D;
-    const int nblk = (d.M + WD_ROWS - 1) / WD_ROWS;
-    float tot = 0.0f;
+    const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
+    float tg = 0.0f, tb = 0.0f;
+#pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int m = blk * WD_ROWS + 16 * wave + li;
+        const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
         PanelRegs<NCT> pr;
         bpanel_issue<NCT>(pr, d.wqkv, 3 * D, 0, 0);
-        bf8 ah[NKS], al[NKS];
+        bf8 oh[NKS], ol[NKS];                             // dQ, dK, dV rows in turn
         {
             f32x4 g[NCT];
-            wr_load<NCT>(g, bd.dqkv, m, rok);                              // dQ rows
-            wr_split<NCT, SPLIT>(g, ah, al);
+            wr_load<NCT>(g, bd.dqkv, m, rok);
+            wr_split<NCT, SPLIT>(g, oh, ol);
         }
-        f32x4 dq[NCT];                                                    // dq_in = dQ Wq^T + d_o (residual, modules.py:269)
         bpanel_put<NCT, SPLIT>(pr, pb);
         __syncthreads();
-        // panel order: Wq rows p = 0..NP-1; then for every p: Wk rows p, Wv rows p (both into the same accumulators)
-#pragma unroll
+        // parts: Wq rows (dq_in = dQ Wq^T + d_o, parked in d_o), then LN1 backward -> dx; Wk rows (dx += dK Wk^T); Wv rows
+        WD_PANEL_LOOP(NPAN)
         for (int i = 0; i < NPAN; ++i) {
-            if (i + 1 < NPAN) {
-                const int n = i + 1;
-                const int part = n < NP ? 0 : 1 + ((n - NP) & 1), p = n < NP ? n : (n - NP) >> 1;
-                bpanel_issue<NCT>(pr, d.wqkv, 3 * D, 64 * p, part * D);
-            }
-            const __bf16* img = pb + (i & 1) * LD::BUF;
-            if (i < NP) {
-                f32x4 acc[4], res[4];
-                wr_load4(res, bd.d_o, D, m, rok, i);
-                acc_zero(acc);
-                panel_mma<NCT, SPLIT, false>(acc, img, ah, al);
+            const int part = i / NP, p = i % NP;
+            if (i == NP) {                                // (before the next panel's loads: their registers are free here)
+                // LN1 backward of dq_in with respect to x starts dx (this lane re-reads its own stores in the panels below)
+                f32x4 dq[NCT], xh[NCT];
+                wr_load<NCT>(dq, bd.d_o, m, rok);         // own stores
+                wr_load<NCT>(xh, d.x, m, rok);
+                colsum_put<NCT>(slots, dq, 1);
+                wr_ln_bwd<NCT>(dq, xh, d.ln1_g);
+                colsum_put<NCT>(slots, xh, 0);
+                if (bd.dx_accumulate) {
+                    wr_load<NCT>(xh, bd.dx, m, rok);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) dq[4 * i + ct] = acc[ct] + res[ct];
-                if (i == NP - 1) {
-                    // LN1 backward of dq_in with respect to x; the result starts dx (this lane re-reads its own stores below)
-                    f32x4 xh[NCT];
-                    wr_load<NCT>(xh, d.x, m, rok);
-                    float mean, rs, sum;
-                    wr_stats<NCT>(xh, mean, rs, sum);
-                    float c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        f32x4 g[4];
-                        wr_vec4(g, d.ln1_g, p);
-#pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float h = (xh[4 * p + ct][r] - mean) * rs;
-                                const float dg = dq[4 * p + ct][r] * g[ct][r];
-                                xh[4 * p + ct][r] = h;
-                                c1 += dg;
-                                c2 = fmaf(dg, h, c2);
-                            }
-                    }
-                    constexpr float invD = 1.0f / D;
-                    c1 = grp_sum(c1) * invD;
-                    c2 = grp_sum(c2) * invD;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        f32x4 g[4], dxo[4], old[4];
-                        wr_vec4(g, d.ln1_g, p);
-                        if (bd.dx_accumulate) wr_load4(old, bd.dx, D, m, rok, p);
-#pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                dxo[ct][r] = rs * (dq[4 * p + ct][r] * g[ct][r] - c1 - xh[4 * p + ct][r] * c2);
-                                if (bd.dx_accumulate) dxo[ct][r] += old[ct][r];
-                            }
-                        wr_store4(bd.dx, D, m, rok, p, dxo);
-                    }
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xh[ct][r] *= dq[ct][r];
-                    // (the fold's barriers are workgroup-uniform: every wave passes here exactly once per row block)
-                    colsum_fold<NCT>(slots, xh, dq, tot);
-                    f32x4 g[NCT];
-                    wr_load<NCT>(g, bd.dqkv + MD, m, rok);                 // dK rows: the operand of the next panel
-                    wr_split<NCT, SPLIT>(g, ah, al);
+                    for (int ct = 0; ct < NCT; ++ct) dq[ct] += xh[ct];
                 }
-            } else {
-                const int j = i - NP, p = j >> 1;
-                static_assert(NPAN == 3 * NP, "panel order");
-                if ((j & 1) == 0) {
-                    f32x4 acc[4];
-                    acc_zero(acc);
-                    panel_mma<NCT, SPLIT, false>(acc, img, ah, al);        // dK Wk^T
-                    f32x4 g[NCT];
-                    wr_load<NCT>(g, bd.dqkv + 2 * MD, m, rok);             // dV rows
-                    bf8 vh[NKS], vl[NKS];
-                    wr_split<NCT, SPLIT>(g, vh, vl);
-                    // keep the partial sums in dq's registers of this panel (dq is dead after the LayerNorm backward)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) dq[4 * p + ct] = acc[ct];
-                    // the operand swap: next panel is Wv rows p with dV, the one after Wk rows p + 1 with dK again
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) { ah[ks] = vh[ks]; al[ks] = vl[ks]; }
-                } else {
-                    f32x4 acc[4], old[4];
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc[ct] = dq[4 * p + ct];
-                    panel_mma<NCT, SPLIT, false>(acc, img, ah, al);        // + dV Wv^T
-                    wr_load4(old, bd.dx, D, m, rok, p);                    // the LayerNorm part (own stores)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
-                    wr_store4(bd.dx, D, m, rok, p, acc);
-                    if (i + 1 < NPAN) {
-                        f32x4 g[NCT];
-                        wr_load<NCT>(g, bd.dqkv + MD, m, rok);             // dK rows again
-                        wr_split<NCT, SPLIT>(g, ah, al);
-                    }
-                }
+                wr_store<NCT>(bd.dx, m, rok, dq);
+                colsum_fold<NCT>(slots, tg, tb);          // (workgroup-uniform: once per row block)
             }
+            if (i + 1 < NPAN) bpanel_issue<NCT>(pr, d.wqkv, 3 * D, 64 * ((i + 1) % NP), ((i + 1) / NP) * D);
+            if (i == NP || i == 2 * NP) {
+                f32x4 g[NCT];
+                wr_load<NCT>(g, bd.dqkv + (size_t)part * MD, m, rok);      // dK / dV rows
+                wr_split<NCT, SPLIT>(g, oh, ol);
+            }
+            f32x4 acc[4], old[4];
+            wr_load4(old, part ? bd.dx : bd.d_o, D, m, rok, p);           // residual (modules.py:269) / the sum so far
+            acc_zero(acc);
+            panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
+            wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);
             if (i + 1 < NPAN) bpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
             __syncthreads();
         }
     }
-    if ((int)threadIdx.x < D) bd.g_ln1_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tot;
-    else if ((int)threadIdx.x < 2 * D) bd.g_ln1_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x - D] = tot;
+    if ((int)threadIdx.x < D) {
+        bd.g_ln1_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tg;
+        bd.g_ln1_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tb;
+    }
 }
 
 // =====================================================================================================
@@ -666,11 +621,13 @@ static const char* wide_why(const cr_block_desc* d, int precision) {
 }
 extern "C" int cr_wide_supported(const cr_block_desc* d, int precision) { return d && wide_why(d, precision) == nullptr; }
 
-template <typename K, typename... A>
-static int wide_launch(K kern, cr_devmask* done, int grid, size_t lds, hipStream_t s, const char* who, A... args) {
+// grid < 0: one workgroup per row block (forward); else the slab count
+template <int NCT, typename K, typename... A>
+static int wide_launch(K kern, cr_devmask* done, int M, int grid, size_t lds, hipStream_t s, const char* who, A... args) {
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(kern), done);
     if (rc != CR_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WD_NT), lds, s, args...);
+    if (grid < 0) grid = cr_ceil_div(M, WdCfg<NCT>::ROWS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WdCfg<NCT>::NT), lds, s, args...);
     return cr_check_launch(who);
 }
 
@@ -680,14 +637,14 @@ static int wide_launch(K kern, cr_devmask* done, int grid, size_t lds, hipStream
         const bool sp = precision == CR_PREC_BF16X3;                                                                      \
         switch (d->D / 16) {                                                                                              \
             case 8:                                                                                                       \
-                return sp ? wide_launch(KERN<8, true>, &done[0], GRID, WideLds<8, true>::PANEL_BYTES + (SLOTS ? WideLds<8, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)      \
-                          : wide_launch(KERN<8, false>, &done[1], GRID, WideLds<8, false>::PANEL_BYTES + (SLOTS ? WideLds<8, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__);  \
+                return sp ? wide_launch<8>(KERN<8, true>, &done[0], d->M, GRID, WideLds<8, true>::PANEL_BYTES + (SLOTS ? WideLds<8, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)      \
+                          : wide_launch<8>(KERN<8, false>, &done[1], d->M, GRID, WideLds<8, false>::PANEL_BYTES + (SLOTS ? WideLds<8, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__);  \
             case 12:                                                                                                      \
-                return sp ? wide_launch(KERN<12, true>, &done[2], GRID, WideLds<12, true>::PANEL_BYTES + (SLOTS ? WideLds<12, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
-                          : wide_launch(KERN<12, false>, &done[3], GRID, WideLds<12, false>::PANEL_BYTES + (SLOTS ? WideLds<12, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
+                return sp ? wide_launch<12>(KERN<12, true>, &done[2], d->M, GRID, WideLds<12, true>::PANEL_BYTES + (SLOTS ? WideLds<12, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
+                          : wide_launch<12>(KERN<12, false>, &done[3], d->M, GRID, WideLds<12, false>::PANEL_BYTES + (SLOTS ? WideLds<12, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
             default:                                                                                                      \
-                return sp ? wide_launch(KERN<16, true>, &done[4], GRID, WideLds<16, true>::PANEL_BYTES + (SLOTS ? WideLds<16, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
-                          : wide_launch(KERN<16, false>, &done[5], GRID, WideLds<16, false>::PANEL_BYTES + (SLOTS ? WideLds<16, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
+                return sp ? wide_launch<16>(KERN<16, true>, &done[4], d->M, GRID, WideLds<16, true>::PANEL_BYTES + (SLOTS ? WideLds<16, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
+                          : wide_launch<16>(KERN<16, false>, &done[5], d->M, GRID, WideLds<16, false>::PANEL_BYTES + (SLOTS ? WideLds<16, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
         }                                                                                                                 \
     } while (0)
 
@@ -698,7 +655,7 @@ extern "C" int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* s
     CR_REQUIRE(d->x && d->q_in && d->qkv && d->k_valid && d->q_valid && d->wqkv && d->bqkv && d->ln1_g && d->ln1_b,
                "cr_wide_ln_qkv_fwd: NULL pointer");
     hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_qkv_fwd, cr_ceil_div(d->M, WD_ROWS), false, "cr_wide_ln_qkv_fwd", *d);
+    WIDE_DISPATCH(k_wide_qkv_fwd, -1, false, "cr_wide_ln_qkv_fwd", *d);
 }
 
 extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream) {
@@ -708,7 +665,7 @@ extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* s
     CR_REQUIRE(d->o && d->f_in && d->hid && d->y && d->mask_ids && d->w1 && d->b1 && d->w2 && d->b2 && d->ln2_g && d->ln2_b,
                "cr_wide_ln_ffn_fwd: NULL pointer");
     hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_ffn_fwd, cr_ceil_div(d->M, WD_ROWS), false, "cr_wide_ln_ffn_fwd", *d);
+    WIDE_DISPATCH(k_wide_ffn_fwd, -1, false, "cr_wide_ln_ffn_fwd", *d);
 }
 
 extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, int precision, void* stream) {

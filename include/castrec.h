@@ -331,7 +331,8 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
  * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: the weight gradients are NOT
  * formed here (cr_gemm_wgrad takes q_in/x/dqkv, hid/g2 and f_in/g1): the backward entries only write the dgamma / dbeta
  * slabs, and cr_wide_ln_ffn_bwd returns the two operands g2 = dy * dropout * mask and g1 = gated(g2 W2^T), dense [M, D];
- * attn_delta and dq_part are not taken. */
+ * attn_delta and dq_part are not taken; cr_wide_ln_qkv_bwd OVERWRITES d_o (with the gradient of q_in, dQ Wq^T + d_o: the row
+ * of the chain that has to exist in memory between the projection panels and the LayerNorm backward). */
 int cr_wide_supported(const cr_block_desc* d, int precision);   /* 1 / 0 */
 int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream);
 int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream);
