@@ -50,6 +50,39 @@ __device__ __forceinline__ void stage_tile(__bf16* hi, __bf16* lo, const float* 
     }
 }
 
+// stage_tile in two halves, so that a tile's loads fly while the previous tile is multiplied
+struct TileRegs { float v[2][8]; };
+__device__ __forceinline__ void stage_issue(TileRegs& t, const float* src, int ld, int row0, int rows_total, int col0, int cols_total) {
+    const int d = min(64, cols_total - col0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int item = threadIdx.x + 256 * u;
+        const int r = item >> 3, ch = item & 7;
+        const bool rok = row0 + r < rows_total;
+        const int grow = rok ? row0 + r : row0;
+        item_issue(t.v[u], src + (size_t)grow * ld + col0, 8 * ch, d, item_fix(rok, grow == rows_total - 1, 8 * ch, d));
+    }
+}
+template <bool SPLIT>
+__device__ __forceinline__ void stage_put(TileRegs& t, __bf16* hi, __bf16* lo, const float* src, int ld, int row0, int rows_total,
+                                          int col0, int cols_total) {
+    const int d = min(64, cols_total - col0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int item = threadIdx.x + 256 * u;
+        const int r = item >> 3, ch = item & 7;
+        const bool rok = row0 + r < rows_total;
+        const int grow = rok ? row0 + r : row0;
+        const bool fix = item_fix(rok, grow == rows_total - 1, 8 * ch, d);
+        item_mask(t.v[u], 8 * ch, d, rok, fix);
+        if (__builtin_expect(fix, 0)) item_refill(t.v[u], src + (size_t)grow * ld + col0, 8 * ch, d);
+        bf8 h, l;
+        split8<SPLIT>(t.v[u], h, l);
+        *reinterpret_cast<bf8*>(hi + img_off(r, ch)) = h;
+        if (SPLIT) *reinterpret_cast<bf8*>(lo + img_off(r, ch)) = l;
+    }
+}
+
 // A operand whose k order follows tr_frag's: element j <-> column 32 ks + 16 (j >> 2) + 4 lg + (j & 3) of row row0 + li
 __device__ __forceinline__ bf8 row_frag_perm(const __bf16* img, int row0, int ks) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -183,11 +216,22 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_bf(WgradBatchBf batch) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
+    // the next 64-row chunk's loads are requested before this chunk's products (with 32 slabs a workgroup walks 13 chunks at
+    // the C4 shape; stage -> barrier -> multiply in series left the memory pipe idle during the products and vice versa)
+    TileRegs ta, tg;
+    if (mb < me) {
+        stage_issue(ta, d.A, d.lda, mb, me, k0, d.K);                  // rows beyond `me` belong to the next slab: zero filled
+        stage_issue(tg, d.G, d.ldg, mb, me, n0, d.N);
+    }
     for (int mc = mb; mc < me; mc += 64) {
         if (mc != mb) __syncthreads();
-        stage_tile<SPLIT>(Ah, Al, d.A, d.lda, mc, me, k0, d.K);        // rows beyond `me` belong to the next slab: zero filled
-        stage_tile<SPLIT>(Gh, Gl, d.G, d.ldg, mc, me, n0, d.N);
+        stage_put<SPLIT>(ta, Ah, Al, d.A, d.lda, mc, me, k0, d.K);
+        stage_put<SPLIT>(tg, Gh, Gl, d.G, d.ldg, mc, me, n0, d.N);
         __syncthreads();
+        if (mc + 64 < me) {
+            stage_issue(ta, d.A, d.lda, mc + 64, me, k0, d.K);
+            stage_issue(tg, d.G, d.ldg, mc + 64, me, n0, d.N);
+        }
         const int msteps = (min(64, me - mc) + 31) / 32;
         for (int ms = 0; ms < msteps; ++ms) {
             const bf8 ah = tr_frag(Ah, 32 * ms, 32 * ms + 16, wave);  // A^T[k = 16 wave + li][rows of the step]

@@ -27,7 +27,10 @@
 
 // Threads per workgroup: 8 waves (128 rows) at D = 128; 4 waves (64 rows) above, where a row's operands and partial results
 // need more than the 256 registers a wave gets at two waves per SIMD (one wave per SIMD may use all 512).
-template <int NCT> struct WdCfg { static constexpr int NT = NCT <= 8 ? 512 : 256, ROWS = NT / 4, NW = NT / 64, ITEMS = 128 * NCT / NT; };
+#ifndef WD_NT8
+#define WD_NT8 1
+#endif
+template <int NCT> struct WdCfg { static constexpr int NT = WD_NT8 && NCT <= 8 ? 512 : 256, ROWS = NT / 4, NW = NT / 64, ITEMS = 128 * NCT / NT; };
 
 // ---- layout R rows of a dense [*, D] matrix, D = 16 NCT exactly (no boundary cases at these sizes) -------------
 template <int NCT>
@@ -227,14 +230,75 @@ struct WideLds {
     static constexpr int HALF = 16 * NCT * 64;                        // bf16 elements of one image half
     static constexpr int BUF = (SPLIT ? 2 : 1) * HALF;                // one panel buffer
     static constexpr size_t PANEL_BYTES = 2 * (size_t)BUF * 2;        // double buffered
-    static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT>::NW * 2 * 16 * NCT * 4;   // [waves][gamma | beta][D] floats (backward kernels)
+    static constexpr int NV = 5;                                       // column-sum vectors of a backward kernel (dgamma, dbeta, 3 bias gradients)
+    static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT>::NW * NV * 16 * NCT * 4;  // [waves][NV][D] floats (backward kernels)
+    static constexpr size_t TOTAL = PANEL_BYTES + SLOT_BYTES + 3 * 16 * NCT * 4;      // + [3 D] floats of biases (forward kernels)
+    // weight-gradient phase of the backward kernels: two [ROWS][D] images (a, g), each hi (+ lo), over the panel buffers
+    static constexpr int IMG_HALF = WdCfg<NCT>::ROWS * 16 * NCT;       // bf16 elements of one half of one image
+    static constexpr int IMG = (SPLIT ? 2 : 1) * IMG_HALF;
+    static constexpr size_t IMG_BYTES = 2 * (size_t)IMG * 2;
+    static constexpr size_t TOTAL_BWD = (IMG_BYTES > PANEL_BYTES ? IMG_BYTES : PANEL_BYTES) + SLOT_BYTES;
+    static constexpr size_t TOTAL_BWD_NOWG = PANEL_BYTES + SLOT_BYTES;
 };
 
-// The panel loops below are written so that nothing depends on their being unrolled: the operand of a part is ONE register
-// array, reloaded (from rows this lane stored itself) and split again at a part boundary behind a workgroup-uniform branch,
-// and every panel's result goes to memory.  D = 128 unrolls them (static schedule, 6 panels); above that the body stays a loop.
-#define WD_UNROLL _Pragma("unroll")
-#define WD_PANEL_LOOP(NPAN) _Pragma("clang loop unroll_count(NCT <= 8 ? NPAN : 1)")
+// ---- the panel pipeline -------------------------------------------------------------------------------------
+// One iteration per panel, every global LOAD of the steady state at the top of an iteration and for a LATER iteration: the
+// weights of panel i + 2 (D = 128: two register sets; above that i + 1, one set) and the auxiliary rows (residual, gate,
+// running sum) of panel i + 1.  What an iteration consumes was requested one iteration earlier, BEFORE that iteration's result
+// stores: vector-memory operations retire in issue order, so a load issued after a store cannot be waited for without
+// waiting for the store too (the first version loaded bias and residual rows right before the epilogue that used them: every
+// iteration then waited for the previous iteration's stores; 2.9 us per panel for 0.65 us of MFMA time).  Biases sit in LDS.
+// Nothing depends on the loop being unrolled except the choice between the two register sets (D = 128 only, where the loop IS
+// unrolled): the operand of a part is ONE register array, reloaded -- from rows this lane stored itself -- and split again at
+// a part boundary behind a workgroup-uniform branch, and every panel's result goes to memory.
+//   issue(regs, n)      request the weights of panel n
+//   auxload(aux, n)     request panel n's auxiliary rows (may do nothing)
+//   boundary(i) -> bool part-boundary work before iteration i (operand reload, LayerNorm backward ...); true = the
+//                       auxiliary rows prefetched for i are stale (written by this boundary): they are loaded again
+//   epilogue(i, acc, aux)
+template <int NCT, bool SPLIT, bool FWD, int NPAN, class Issue, class AuxLoad, class Boundary, class Epilogue>
+__device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT> (&pr)[NCT <= 8 ? 2 : 1], const bf8 (&oh)[NCT / 2],
+                                               const bf8 (&ol)[NCT / 2], Issue issue, AuxLoad auxload, Boundary boundary,
+                                               Epilogue epilogue) {
+    typedef WideLds<NCT, SPLIT> LD;
+    constexpr bool D2 = NCT <= 8;
+    f32x4 aux_n[4];
+    auxload(aux_n, 0);
+    if (FWD) fpanel_put<NCT, SPLIT>(pr[0], pb); else bpanel_put<NCT, SPLIT>(pr[0], pb);
+    __syncthreads();
+    _Pragma("clang loop unroll_count(NCT <= 8 ? NPAN : 1)")
+    for (int i = 0; i < NPAN; ++i) {
+        const bool stale = boundary(i);
+        f32x4 aux[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) aux[ct] = aux_n[ct];
+        if (stale) auxload(aux, i);
+        if (D2) { if (i + 2 < NPAN) issue(pr[D2 ? (i & 1) : 0], i + 2); }
+        else if (i + 1 < NPAN) issue(pr[0], i + 1);
+        if (i + 1 < NPAN) auxload(aux_n, i + 1);
+        f32x4 acc[4];
+        acc_zero(acc);
+        panel_mma<NCT, SPLIT, FWD>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+        epilogue(i, acc, aux);
+        if (i + 1 < NPAN) {
+            __bf16* dst = pb + ((i + 1) & 1) * LD::BUF;
+            if (FWD) fpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst); else bpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst);
+        }
+        __syncthreads();
+    }
+}
+// n floats global -> LDS (biases), visible after the next barrier
+__device__ __forceinline__ void vec_to_lds(float* dst, const float* src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+__device__ __forceinline__ void lds_vec4(f32x4 (&v)[4], const float* vec, int p) {
+    const int lg = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float4 t = *reinterpret_cast<const float4*>(vec + 64 * p + 16 * ct + 4 * lg);
+        v[ct] = (f32x4){t.x, t.y, t.z, t.w};
+    }
+}
 
 // =====================================================================================================
 // forward: LN1 + Q / K / V projections
@@ -242,14 +306,19 @@ struct WideLds {
 template <int NCT, bool SPLIT>
 __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
+    constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
+    float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [3 D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
     const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
-    PanelRegs<NCT> pr;
-    fpanel_issue<NCT>(pr, d.wqkv, 3 * D, 0);
+    auto issue = [&](PanelRegs<NCT>& r, int n) { fpanel_issue<NCT>(r, d.wqkv, 3 * D, (n / NP) * D + 64 * (n % NP)); };
+    PanelRegs<NCT> pr[D2 ? 2 : 1];
+    issue(pr[0], 0);
+    if (D2) issue(pr[1], 1);
+    vec_to_lds(lbias, d.bqkv, 3 * D);
     bf8 oh[NKS], ol[NKS];                                 // the current operand: q_in for Q, x for K and V
     {
         f32x4 x[NCT];
@@ -279,27 +348,24 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d
         }
         wr_split<NCT, SPLIT>(x, oh, ol);
     }
-    fpanel_put<NCT, SPLIT>(pr, pb);
-    __syncthreads();
-    WD_PANEL_LOOP(NPAN)
-    for (int i = 0; i < NPAN; ++i) {
-        const int part = i / NP, p = i % NP;
-        if (i + 1 < NPAN) fpanel_issue<NCT>(pr, d.wqkv, 3 * D, ((i + 1) / NP) * D + 64 * ((i + 1) % NP));
-        if (i == NP) {                                    // K and V take the un-normalised rows (modules.py:204-205)
-            f32x4 x[NCT];
-            wr_load<NCT>(x, d.x, m, rok);
-            wr_split<NCT, SPLIT>(x, oh, ol);
-        }
-        f32x4 acc[4], bias[4];
-        wr_vec4(bias, d.bqkv + part * D, p);
-        acc_zero(acc);
-        panel_mma<NCT, SPLIT, true>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+    panel_pipeline<NCT, SPLIT, true, NPAN>(pb, pr, oh, ol, issue,
+        [&](f32x4 (&)[4], int) {},
+        [&](int i) {
+            if (i == NP) {                                // K and V take the un-normalised rows (modules.py:204-205)
+                f32x4 x[NCT];
+                wr_load<NCT>(x, d.x, m, rok);
+                wr_split<NCT, SPLIT>(x, oh, ol);
+            }
+            return false;
+        },
+        [&](int i, f32x4 (&acc)[4], const f32x4 (&)[4]) {
+            const int part = i / NP, p = i % NP;
+            f32x4 bias[4];
+            lds_vec4(bias, lbias + part * D, p);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
-        wr_store4(d.qkv + (size_t)part * d.M * D, D, m, rok, p, acc);
-        if (i + 1 < NPAN) fpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
-        __syncthreads();
-    }
+            for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
+            wr_store4(d.qkv + (size_t)part * d.M * D, D, m, rok, p, acc);
+        });
 }
 
 // =====================================================================================================
@@ -308,15 +374,21 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d
 template <int NCT, bool SPLIT>
 __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
+    constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
+    float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [2 D]: b1, b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
     const DropCtx dc1 = drop_ctx(d.drop_ffn1), dc2 = drop_ctx(d.drop_ffn2);
-    PanelRegs<NCT> pr;
-    fpanel_issue<NCT>(pr, d.w1, D, 0);
+    auto issue = [&](PanelRegs<NCT>& r, int n) { fpanel_issue<NCT>(r, n / NP ? d.w2 : d.w1, D, 64 * (n % NP)); };
+    PanelRegs<NCT> pr[D2 ? 2 : 1];
+    issue(pr[0], 0);
+    if (D2) issue(pr[1], 1);
+    vec_to_lds(lbias, d.b1, D);
+    vec_to_lds(lbias + D, d.b2, D);
     bf8 oh[NKS], ol[NKS];                                 // f_in, then hid
     {
         f32x4 x[NCT];
@@ -338,52 +410,50 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d
     }
     const int id = rok ? d.mask_ids[m] : 0;
     const uint32_t xrow = ((d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
-    fpanel_put<NCT, SPLIT>(pr, pb);
-    __syncthreads();
-    WD_PANEL_LOOP(NPAN)
-    for (int i = 0; i < NPAN; ++i) {
-        const int part = i / NP, p = i % NP;
-        if (i + 1 < NPAN) fpanel_issue<NCT>(pr, (i + 1) / NP ? d.w2 : d.w1, D, 64 * ((i + 1) % NP));
-        if (i == NP) {                                    // the second layer's operand: the hidden rows this lane stored
-            f32x4 h[NCT];
-            wr_load<NCT>(h, d.hid, m, rok);
-            wr_split<NCT, SPLIT>(h, oh, ol);
-        }
-        f32x4 acc[4], bias[4], res[4];
-        wr_vec4(bias, part ? d.b2 : d.b1, p);
-        if (part) wr_load4(res, d.f_in, D, m, rok, p);    // own stores (residual = LN2 output, modules.py:313)
-        acc_zero(acc);
-        panel_mma<NCT, SPLIT, true>(acc, pb + (i & 1) * LD::BUF, oh, ol);
-        DropCtx dc;                                       // (field by field: a selected struct reference went through scratch)
-        dc.on = dc1.on;
-        dc.key = part ? dc2.key : dc1.key;
-        dc.thresh = part ? dc2.thresh : dc1.thresh;
-        dc.scale = part ? dc2.scale : dc1.scale;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[ct][r] + bias[ct][r];
-                if (!part) v = fmaxf(v, 0.0f);                                               // modules.py:300
-                if (dc.on) v *= drop_factor_x(dc, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc.key);
-                if (part) v = id ? v + res[ct][r] : 0.0f;                                    // modules.py:313, sasrec.py:83
-                acc[ct][r] = v;
+    panel_pipeline<NCT, SPLIT, true, NPAN>(pb, pr, oh, ol, issue,
+        [&](f32x4 (&aux)[4], int n) {
+            if (n >= NP) wr_load4(aux, d.f_in, D, m, rok, n - NP);     // own stores (residual = LN2 output, modules.py:313)
+        },
+        [&](int i) {
+            if (i == NP) {                                // the second layer's operand: the hidden rows this lane stored
+                f32x4 h[NCT];
+                wr_load<NCT>(h, d.hid, m, rok);
+                wr_split<NCT, SPLIT>(h, oh, ol);
             }
-        wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
-        if (i + 1 < NPAN) fpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
-        __syncthreads();
-    }
+            return false;
+        },
+        [&](int i, f32x4 (&acc)[4], const f32x4 (&res)[4]) {
+            const int part = i / NP, p = i % NP;
+            f32x4 bias[4];
+            lds_vec4(bias, lbias + part * D, p);
+            DropCtx dc;                                   // (field by field: a selected struct reference went through scratch)
+            dc.on = dc1.on;
+            dc.key = part ? dc2.key : dc1.key;
+            dc.thresh = part ? dc2.thresh : dc1.thresh;
+            dc.scale = part ? dc2.scale : dc1.scale;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[ct][r] + bias[ct][r];
+                    if (!part) v = fmaxf(v, 0.0f);                                           // modules.py:300
+                    if (dc.on) v *= drop_factor_x(dc, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc.key);
+                    if (part) v = id ? v + res[ct][r] : 0.0f;                                // modules.py:313, sasrec.py:83
+                    acc[ct][r] = v;
+                }
+            wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
+        });
 }
 
 // ---- column sums of the workgroup's rows into per-thread accumulators ---------------------------------------
-// colsum_put: a[ct][r] = the lane's contributions (row li) at columns 16 ct + 4 lg + r; the wave's sums go to its LDS slot
-// (which = 0: dgamma half, 1: dbeta half).  colsum_fold: after both puts, thread c < D adds this pass's dgamma[c] to tg and
-// dbeta[c] to tb, waves in a fixed order.  Two barriers.
+// colsum_put: a[ct][r] = the lane's contributions (row li) at columns 16 ct + 4 lg + r; the wave's sums go to vector `which`
+// of its LDS slot.  colsum_fold: after the puts, thread c < D adds this pass's sums of column c to t[0 .. NV-1], waves in a
+// fixed order.  Two barriers.
 template <int NCT>
 __device__ __forceinline__ void colsum_put(float* slots, const f32x4 (&a)[NCT], int which) {
-    constexpr int D = 16 * NCT;
+    constexpr int D = 16 * NCT, NV = WideLds<NCT, true>::NV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    float* sg = slots + (size_t)wave * 2 * D + which * D;
+    float* sg = slots + ((size_t)wave * NV + which) * D;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         f32x4 ga;
@@ -392,21 +462,86 @@ __device__ __forceinline__ void colsum_put(float* slots, const f32x4 (&a)[NCT], 
         if (li == 0) *reinterpret_cast<float4*>(sg + 16 * ct + 4 * lg) = make_float4(ga[0], ga[1], ga[2], ga[3]);
     }
 }
-template <int NCT>
-__device__ __forceinline__ void colsum_fold(const float* slots, float& tg, float& tb) {
-    constexpr int D = 16 * NCT, NW = WdCfg<NCT>::NW;
+template <int NCT, int NUSE>
+__device__ __forceinline__ void colsum_fold(const float* slots, float (&t)[NUSE]) {
+    constexpr int D = 16 * NCT, NW = WdCfg<NCT>::NW, NV = WideLds<NCT, true>::NV;
     __syncthreads();
     if ((int)threadIdx.x < D) {
-        float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            s0 += slots[(size_t)w * 2 * D + threadIdx.x];
-            s1 += slots[(size_t)w * 2 * D + D + threadIdx.x];
+        for (int v = 0; v < NUSE; ++v) {
+            float s0 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s0 += slots[((size_t)w * NV + v) * D + threadIdx.x];
+            t[v] += s0;
         }
-        tg += s0;
-        tb += s1;
     }
     __syncthreads();
+}
+
+// ---- weight gradients dW = a^T g of the workgroup's rows (contraction over rows) ----------------------------------
+// The rows of a and g go to LDS as [ROWS][D] bf16 images (pieces of 64 columns, the swizzle of cr_bf16.hpp); both MFMA
+// operands are transposed reads (k = row).  Wave w owns the 16-row tiles w, w + NW, ... of dW (k = columns of a) over all D
+// columns: accumulators acc[NCT].  The result is written -- or, from the workgroup's second row block on, added -- to the
+// workgroup's slab: the same lanes touch the same words, no synchronisation.
+template <int NCT, bool SPLIT>
+__device__ __forceinline__ void wg_row_to_image(__bf16* img, const f32x4 (&x)[NCT]) {
+    typedef WideLds<NCT, SPLIT> LD;
+    constexpr int SUB = WdCfg<NCT>::ROWS * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int row = 16 * wave + li;
+#pragma unroll
+    for (int c2 = 0; c2 < NCT / 2; ++c2) {
+        bf8 h, l;
+        wr_split2<SPLIT>(x[2 * c2], x[2 * c2 + 1], h, l);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ct = 2 * c2 + e;
+            const int o = (ct >> 2) * SUB + img_off<2>(row, 2 * (ct & 3) + (lg >> 1)) + 4 * (lg & 1);
+            *reinterpret_cast<bf4*>(img + o) = e ? __builtin_shufflevector(h, h, 4, 5, 6, 7) : __builtin_shufflevector(h, h, 0, 1, 2, 3);
+            if (SPLIT) *reinterpret_cast<bf4*>(img + LD::IMG_HALF + o) = e ? __builtin_shufflevector(l, l, 4, 5, 6, 7) : __builtin_shufflevector(l, l, 0, 1, 2, 3);
+        }
+    }
+}
+template <int NCT, bool SPLIT>
+__device__ __forceinline__ void wg_product(const __bf16* ia, const __bf16* ig, float* dW, int ldw, bool first) {
+    typedef WideLds<NCT, SPLIT> LD;
+    constexpr int ROWS = WdCfg<NCT>::ROWS, NW = WdCfg<NCT>::NW, SUB = ROWS * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+#pragma unroll 1
+    for (int kt = wave; kt < NCT; kt += NW) {
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int nt = 0; nt < NCT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const __bf16* pa = ia + (kt >> 2) * SUB;
+#pragma unroll
+        for (int s = 0; s < ROWS / 32; ++s) {
+            const bf8 ah = wd_tr(pa, 32 * s, 32 * s + 16, kt & 3, lane);
+            const bf8 al = SPLIT ? wd_tr(pa + LD::IMG_HALF, 32 * s, 32 * s + 16, kt & 3, lane) : ah;
+#pragma unroll
+            for (int n0 = 0; n0 < NCT; n0 += 2) {
+                bf8 gh[2], gl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gh[j] = wd_tr(ig + (n0 >> 2) * SUB, 32 * s, 32 * s + 16, (n0 & 3) + j, lane);
+                    gl[j] = SPLIT ? wd_tr(ig + LD::IMG_HALF + (n0 >> 2) * SUB, 32 * s, 32 * s + 16, (n0 & 3) + j, lane) : gh[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[n0 + j] = mma<SPLIT>(ah, al, gh[j], gl[j], acc[n0 + j]);
+            }
+        }
+        float* q0 = dW + (size_t)(16 * kt + 4 * lg) * ldw + li;
+        if (first) {                                      // workgroup-uniform
+#pragma unroll
+            for (int nt = 0; nt < NCT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q0[(size_t)r * ldw + 16 * nt] = acc[nt][r];
+        } else {
+#pragma unroll 2
+            for (int nt = 0; nt < NCT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q0[(size_t)r * ldw + 16 * nt] += acc[nt][r];
+        }
+    }
 }
 
 // LayerNorm backward of the lane's row (modules.py:74-78): g = gradient of the output row (the dbeta contributions), x = the
@@ -454,25 +589,29 @@ __device__ __forceinline__ void wr_ln_bwd(f32x4 (&g)[NCT], f32x4 (&x)[NCT], cons
 // =====================================================================================================
 // backward: feed-forward + LN2
 // =====================================================================================================
-template <int NCT, bool SPLIT>
+template <int NCT, bool SPLIT, bool WG>
 __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
+    constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
-    float* slots = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES);
+    float* slots = reinterpret_cast<float*>(smem_raw + (WG ? LD::TOTAL_BWD : LD::TOTAL_BWD_NOWG) - LD::SLOT_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const DropCtx dc2 = drop_ctx(d.drop_ffn2);
     const float gate_scale = d.drop_ffn1.rate > 0.0f ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
     const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
-    float tg = 0.0f, tb = 0.0f;
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};                  // dgamma2, dbeta2, db2, db1 of column threadIdx.x
+    constexpr bool wgrad = WG;                            // (a template flag: the phase's registers cost the other shapes a spill)
+    auto issue = [&](PanelRegs<NCT>& r, int n) { bpanel_issue<NCT>(r, n / NP ? d.w1 : d.w2, D, 64 * (n % NP), 0); };
 #pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
-        PanelRegs<NCT> pr;
-        bpanel_issue<NCT>(pr, d.w2, D, 0, 0);
+        PanelRegs<NCT> pr[D2 ? 2 : 1];
+        issue(pr[0], 0);
+        if (D2) issue(pr[1], 1);
         const int id = rok ? d.mask_ids[m] : 0;
         const uint32_t xrow = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
         bf8 oh[NKS], ol[NKS];                             // g2, then g1
@@ -491,35 +630,30 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_de
             wr_store<NCT>(g2out, m, rok, g);
             wr_split<NCT, SPLIT>(g, oh, ol);
         }
-        bpanel_put<NCT, SPLIT>(pr, pb);
-        __syncthreads();
-        WD_PANEL_LOOP(NPAN)
-        for (int i = 0; i < NPAN; ++i) {
-            const int part = i / NP, p = i % NP;
-            if (i + 1 < NPAN) bpanel_issue<NCT>(pr, (i + 1) / NP ? d.w1 : d.w2, D, 64 * ((i + 1) % NP), 0);
-            if (i == NP) {
-                f32x4 g[NCT];
-                wr_load<NCT>(g, g1out, m, rok);           // own stores
-                wr_split<NCT, SPLIT>(g, oh, ol);
-            }
-            f32x4 acc[4], aux[4];
-            wr_load4(aux, part ? bd.dy : d.hid, D, m, rok, p);
-            acc_zero(acc);
-            panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, oh, ol);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // part 0: g1 = (g2 W2^T) gated by the stored post-dropout ReLU output (modules.py:300-303)
-                    // part 1: df_in = (g1 W1^T + dy) * mask (residual branch of modules.py:313), parked in d_o
-                    const float v0 = aux[ct][r] > 0.0f ? acc[ct][r] * gate_scale : 0.0f;
-                    const float v1 = id ? acc[ct][r] + aux[ct][r] : 0.0f;
-                    acc[ct][r] = part ? v1 : v0;
+        panel_pipeline<NCT, SPLIT, false, NPAN>(pb, pr, oh, ol, issue,
+            [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dy : d.hid, D, m, rok, n % NP); },
+            [&](int i) {
+                if (i == NP) {
+                    f32x4 g[NCT];
+                    wr_load<NCT>(g, g1out, m, rok);       // own stores
+                    wr_split<NCT, SPLIT>(g, oh, ol);
                 }
-            wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);
-            if (i + 1 < NPAN) bpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
-            __syncthreads();
-        }
+                return false;
+            },
+            [&](int i, f32x4 (&acc)[4], const f32x4 (&aux)[4]) {
+                const int part = i / NP, p = i % NP;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // part 0: g1 = (g2 W2^T) gated by the stored post-dropout ReLU output (modules.py:300-303)
+                        // part 1: df_in = (g1 W1^T + dy) * mask (residual branch of modules.py:313), parked in d_o
+                        const float v0 = aux[ct][r] > 0.0f ? acc[ct][r] * gate_scale : 0.0f;
+                        const float v1 = id ? acc[ct][r] + aux[ct][r] : 0.0f;
+                        acc[ct][r] = part ? v1 : v0;
+                    }
+                wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);
+            });
         {
             f32x4 df[NCT], xh[NCT];
             wr_load<NCT>(df, bd.d_o, m, rok);             // own stores
@@ -528,84 +662,137 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_de
             wr_ln_bwd<NCT>(df, xh, d.ln2_g);
             wr_store<NCT>(bd.d_o, m, rok, df);
             colsum_put<NCT>(slots, xh, 0);
-            colsum_fold<NCT>(slots, tg, tb);
+        }
+        if (wgrad) {
+            // dW2 = hid^T g2, dW1 = f_in^T g1 (+ the bias gradients: column sums of g2, g1), images over the panel buffers
+            // (every wave is past the pipeline's last barrier)
+            __bf16* ia = pb;
+            __bf16* ig = pb + LD::IMG;
+            const bool first = blk == (int)blockIdx.x;
+            const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+#pragma unroll 1
+            for (int w = 0; w < 2; ++w) {
+                f32x4 t[NCT];
+                wr_load<NCT>(t, w ? d.f_in : d.hid, m, rok);
+                wg_row_to_image<NCT, SPLIT>(ia, t);
+                wr_load<NCT>(t, w ? g1out : g2out, m, rok);   // own stores
+                wg_row_to_image<NCT, SPLIT>(ig, t);
+                colsum_put<NCT>(slots, t, 2 + w);
+                __syncthreads();
+                wg_product<NCT, SPLIT>(ia, ig, (w ? bd.g_w1 : bd.g_w2) + so, D, first);
+                __syncthreads();
+            }
+        }
+        if (wgrad) colsum_fold<NCT, 4>(slots, tot);
+        else {
+            float t2[2] = {0.f, 0.f};
+            colsum_fold<NCT, 2>(slots, t2);
+            tot[0] += t2[0]; tot[1] += t2[1];
         }
     }
     if ((int)threadIdx.x < D) {
-        bd.g_ln2_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tg;
-        bd.g_ln2_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tb;
+        const size_t o = (size_t)blockIdx.x * bd.slab_stride + threadIdx.x;
+        bd.g_ln2_g[o] = tot[0];
+        bd.g_ln2_b[o] = tot[1];
+        if (wgrad) { bd.g_b2[o] = tot[2]; bd.g_b1[o] = tot[3]; }
     }
 }
 
 // =====================================================================================================
 // backward: Q / K / V projections + LN1
 // =====================================================================================================
-template <int NCT, bool SPLIT>
+template <int NCT, bool SPLIT, bool WG>
 __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
+    constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
-    float* slots = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES);
+    float* slots = reinterpret_cast<float*>(smem_raw + (WG ? LD::TOTAL_BWD : LD::TOTAL_BWD_NOWG) - LD::SLOT_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
     const size_t MD = (size_t)d.M * D;
     const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
-    float tg = 0.0f, tb = 0.0f;
+    float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};             // dgamma1, dbeta1, dbq, dbk, dbv of column threadIdx.x
+    constexpr bool wgrad = WG;
+    auto issue = [&](PanelRegs<NCT>& r, int n) { bpanel_issue<NCT>(r, d.wqkv, 3 * D, 64 * (n % NP), (n / NP) * D); };
 #pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
-        PanelRegs<NCT> pr;
-        bpanel_issue<NCT>(pr, d.wqkv, 3 * D, 0, 0);
+        PanelRegs<NCT> pr[D2 ? 2 : 1];
+        issue(pr[0], 0);
+        if (D2) issue(pr[1], 1);
         bf8 oh[NKS], ol[NKS];                             // dQ, dK, dV rows in turn
         {
             f32x4 g[NCT];
             wr_load<NCT>(g, bd.dqkv, m, rok);
             wr_split<NCT, SPLIT>(g, oh, ol);
         }
-        bpanel_put<NCT, SPLIT>(pr, pb);
-        __syncthreads();
         // parts: Wq rows (dq_in = dQ Wq^T + d_o, parked in d_o), then LN1 backward -> dx; Wk rows (dx += dK Wk^T); Wv rows
-        WD_PANEL_LOOP(NPAN)
-        for (int i = 0; i < NPAN; ++i) {
-            const int part = i / NP, p = i % NP;
-            if (i == NP) {                                // (before the next panel's loads: their registers are free here)
-                // LN1 backward of dq_in with respect to x starts dx (this lane re-reads its own stores in the panels below)
-                f32x4 dq[NCT], xh[NCT];
-                wr_load<NCT>(dq, bd.d_o, m, rok);         // own stores
-                wr_load<NCT>(xh, d.x, m, rok);
-                colsum_put<NCT>(slots, dq, 1);
-                wr_ln_bwd<NCT>(dq, xh, d.ln1_g);
-                colsum_put<NCT>(slots, xh, 0);
-                if (bd.dx_accumulate) {
-                    wr_load<NCT>(xh, bd.dx, m, rok);
+        panel_pipeline<NCT, SPLIT, false, NPAN>(pb, pr, oh, ol, issue,
+            [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dx : bd.d_o, D, m, rok, n % NP); },   // residual (modules.py:269) / the sum so far
+            [&](int i) {
+                if (i == NP) {
+                    // LN1 backward of dq_in with respect to x starts dx (this lane re-reads its own stores in the panels below)
+                    f32x4 dq[NCT], xh[NCT];
+                    wr_load<NCT>(dq, bd.d_o, m, rok);     // own stores
+                    wr_load<NCT>(xh, d.x, m, rok);
+                    colsum_put<NCT>(slots, dq, 1);
+                    wr_ln_bwd<NCT>(dq, xh, d.ln1_g);
+                    colsum_put<NCT>(slots, xh, 0);
+                    if (bd.dx_accumulate) {
+                        wr_load<NCT>(xh, bd.dx, m, rok);
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) dq[ct] += xh[ct];
+                        for (int ct = 0; ct < NCT; ++ct) dq[ct] += xh[ct];
+                    }
+                    wr_store<NCT>(bd.dx, m, rok, dq);
                 }
-                wr_store<NCT>(bd.dx, m, rok, dq);
-                colsum_fold<NCT>(slots, tg, tb);          // (workgroup-uniform: once per row block)
-            }
-            if (i + 1 < NPAN) bpanel_issue<NCT>(pr, d.wqkv, 3 * D, 64 * ((i + 1) % NP), ((i + 1) / NP) * D);
-            if (i == NP || i == 2 * NP) {
-                f32x4 g[NCT];
-                wr_load<NCT>(g, bd.dqkv + (size_t)part * MD, m, rok);      // dK / dV rows
-                wr_split<NCT, SPLIT>(g, oh, ol);
-            }
-            f32x4 acc[4], old[4];
-            wr_load4(old, part ? bd.dx : bd.d_o, D, m, rok, p);           // residual (modules.py:269) / the sum so far
-            acc_zero(acc);
-            panel_mma<NCT, SPLIT, false>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+                if (i == NP || i == 2 * NP) {
+                    f32x4 g[NCT];
+                    wr_load<NCT>(g, bd.dqkv + (size_t)(i / NP) * MD, m, rok);      // dK / dV rows
+                    wr_split<NCT, SPLIT>(g, oh, ol);
+                }
+                return i == NP;                           // dx was just written: the prefetched rows are stale
+            },
+            [&](int i, f32x4 (&acc)[4], const f32x4 (&old)[4]) {
+                const int part = i / NP, p = i % NP;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
-            wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);
-            if (i + 1 < NPAN) bpanel_put<NCT, SPLIT>(pr, pb + ((i + 1) & 1) * LD::BUF);
-            __syncthreads();
+                for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
+                wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);
+            });
+        if (wgrad) {
+            // dWq = q_in^T dQ, dWk = x^T dK, dWv = x^T dV: column blocks of the [D, 3 D] gradient (+ bias gradients)
+            __bf16* ia = pb;
+            __bf16* ig = pb + LD::IMG;
+            const bool first = blk == (int)blockIdx.x;
+            const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+#pragma unroll 1
+            for (int w = 0; w < 3; ++w) {
+                f32x4 t[NCT];
+                if (w < 2) {                              // the x image serves dWk and dWv
+                    wr_load<NCT>(t, w ? d.x : d.q_in, m, rok);
+                    wg_row_to_image<NCT, SPLIT>(ia, t);
+                }
+                wr_load<NCT>(t, bd.dqkv + (size_t)w * MD, m, rok);
+                wg_row_to_image<NCT, SPLIT>(ig, t);
+                colsum_put<NCT>(slots, t, 2 + w);
+                __syncthreads();
+                wg_product<NCT, SPLIT>(ia, ig, bd.g_wqkv + so + w * D, 3 * D, first);
+                __syncthreads();
+            }
+            colsum_fold<NCT, 5>(slots, tot);
+        } else {
+            float t2[2] = {0.f, 0.f};
+            colsum_fold<NCT, 2>(slots, t2);
+            tot[0] += t2[0]; tot[1] += t2[1];
         }
     }
     if ((int)threadIdx.x < D) {
-        bd.g_ln1_g[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tg;
-        bd.g_ln1_b[(size_t)blockIdx.x * bd.slab_stride + threadIdx.x] = tb;
+        const size_t o = (size_t)blockIdx.x * bd.slab_stride + threadIdx.x;
+        bd.g_ln1_g[o] = tot[0];
+        bd.g_ln1_b[o] = tot[1];
+        if (wgrad) { bd.g_bqkv[o] = tot[2]; bd.g_bqkv[o + D] = tot[3]; bd.g_bqkv[o + 2 * D] = tot[4]; }
     }
 }
 
@@ -631,20 +818,20 @@ static int wide_launch(K kern, cr_devmask* done, int M, int grid, size_t lds, hi
     return cr_check_launch(who);
 }
 
-#define WIDE_DISPATCH(KERN, GRID, SLOTS, WHO, ...)                                                                        \
+#define WIDE_DISPATCH(KERN, GRID, BWD, WHO, ...)                                                                        \
     do {                                                                                                                  \
         static cr_devmask done[6];                                                                                        \
         const bool sp = precision == CR_PREC_BF16X3;                                                                      \
         switch (d->D / 16) {                                                                                              \
             case 8:                                                                                                       \
-                return sp ? wide_launch<8>(KERN<8, true>, &done[0], d->M, GRID, WideLds<8, true>::PANEL_BYTES + (SLOTS ? WideLds<8, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)      \
-                          : wide_launch<8>(KERN<8, false>, &done[1], d->M, GRID, WideLds<8, false>::PANEL_BYTES + (SLOTS ? WideLds<8, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__);  \
+                return sp ? wide_launch<8>(KERN<8, true>, &done[0], d->M, GRID, WideLds<8, true>::TOTAL, s, WHO, __VA_ARGS__)      \
+                          : wide_launch<8>(KERN<8, false>, &done[1], d->M, GRID, WideLds<8, false>::TOTAL, s, WHO, __VA_ARGS__);  \
             case 12:                                                                                                      \
-                return sp ? wide_launch<12>(KERN<12, true>, &done[2], d->M, GRID, WideLds<12, true>::PANEL_BYTES + (SLOTS ? WideLds<12, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
-                          : wide_launch<12>(KERN<12, false>, &done[3], d->M, GRID, WideLds<12, false>::PANEL_BYTES + (SLOTS ? WideLds<12, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
+                return sp ? wide_launch<12>(KERN<12, true>, &done[2], d->M, GRID, WideLds<12, true>::TOTAL, s, WHO, __VA_ARGS__)   \
+                          : wide_launch<12>(KERN<12, false>, &done[3], d->M, GRID, WideLds<12, false>::TOTAL, s, WHO, __VA_ARGS__); \
             default:                                                                                                      \
-                return sp ? wide_launch<16>(KERN<16, true>, &done[4], d->M, GRID, WideLds<16, true>::PANEL_BYTES + (SLOTS ? WideLds<16, true>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__)   \
-                          : wide_launch<16>(KERN<16, false>, &done[5], d->M, GRID, WideLds<16, false>::PANEL_BYTES + (SLOTS ? WideLds<16, false>::SLOT_BYTES : 0), s, WHO, __VA_ARGS__); \
+                return sp ? wide_launch<16>(KERN<16, true>, &done[4], d->M, GRID, WideLds<16, true>::TOTAL, s, WHO, __VA_ARGS__)   \
+                          : wide_launch<16>(KERN<16, false>, &done[5], d->M, GRID, WideLds<16, false>::TOTAL, s, WHO, __VA_ARGS__); \
         }                                                                                                                 \
     } while (0)
 
@@ -668,6 +855,19 @@ extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* s
     WIDE_DISPATCH(k_wide_ffn_fwd, -1, false, "cr_wide_ln_ffn_fwd", *d);
 }
 
+template <int NCT, bool SPLIT, bool WG>
+static int wide_launch_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, hipStream_t s) {
+    static cr_devmask done = 0;
+    return wide_launch<NCT>(k_wide_ffn_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
+                            WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_ffn_bwd", *bd, g2, g1);
+}
+template <int NCT, bool SPLIT, bool WG>
+static int wide_launch_qkv_bwd(const cr_block_bwd_desc* bd, hipStream_t s) {
+    static cr_devmask done = 0;
+    return wide_launch<NCT>(k_wide_qkv_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
+                            WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_qkv_bwd", *bd);
+}
+
 extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, int precision, void* stream) {
     CR_REQUIRE(bd, "cr_wide_ln_ffn_bwd: NULL description");
     const cr_block_desc* d = &bd->f;
@@ -675,8 +875,20 @@ extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float*
     if (why) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_ffn_bwd: %s", why);
     CR_REQUIRE(bd->dy && bd->d_o && g2 && g1 && d->hid && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_wide_ln_ffn_bwd: NULL pointer");
     CR_REQUIRE(bd->g_ln2_g && bd->g_ln2_b && bd->n_slabs > 0 && bd->slab_stride > 0, "cr_wide_ln_ffn_bwd: NULL gradient pointer / no slabs");
+    const bool wg = bd->g_w1 || bd->g_w2 || bd->g_b1 || bd->g_b2;
+    if (wg) {
+        CR_REQUIRE(d->D == 128, "cr_wide_ln_ffn_bwd: weight gradients are formed at D = 128 only (pass NULL g_w1 g_b1 g_w2 g_b2 and use cr_gemm_wgrad)");
+        CR_REQUIRE(bd->g_w1 && bd->g_w2 && bd->g_b1 && bd->g_b2 && d->f_in, "cr_wide_ln_ffn_bwd: all of g_w1 g_b1 g_w2 g_b2 (and f_in) or none");
+    }
     hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_ffn_bwd, bd->n_slabs, true, "cr_wide_ln_ffn_bwd", *bd, g2, g1);
+    const bool sp = precision == CR_PREC_BF16X3;
+    switch (d->D / 16) {
+        case 8:
+            if (wg) return sp ? wide_launch_ffn_bwd<8, true, true>(bd, g2, g1, s) : wide_launch_ffn_bwd<8, false, true>(bd, g2, g1, s);
+            return sp ? wide_launch_ffn_bwd<8, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<8, false, false>(bd, g2, g1, s);
+        case 12: return sp ? wide_launch_ffn_bwd<12, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<12, false, false>(bd, g2, g1, s);
+        default: return sp ? wide_launch_ffn_bwd<16, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<16, false, false>(bd, g2, g1, s);
+    }
 }
 
 extern "C" int cr_wide_ln_qkv_bwd(const cr_block_bwd_desc* bd, int precision, void* stream) {
@@ -687,6 +899,18 @@ extern "C" int cr_wide_ln_qkv_bwd(const cr_block_bwd_desc* bd, int precision, vo
     CR_REQUIRE(bd->dqkv && bd->d_o && bd->dx && d->x && d->wqkv && d->ln1_g, "cr_wide_ln_qkv_bwd: NULL pointer");
     CR_REQUIRE(bd->g_ln1_g && bd->g_ln1_b && bd->n_slabs > 0 && bd->slab_stride > 0, "cr_wide_ln_qkv_bwd: NULL gradient pointer / no slabs");
     CR_REQUIRE(bd->dq_part == nullptr, "cr_wide_ln_qkv_bwd: dq_part (single-pass fp32 attention backward) is not taken");
+    const bool wg = bd->g_wqkv || bd->g_bqkv;
+    if (wg) {
+        CR_REQUIRE(d->D == 128, "cr_wide_ln_qkv_bwd: weight gradients are formed at D = 128 only (pass NULL g_wqkv g_bqkv and use cr_gemm_wgrad)");
+        CR_REQUIRE(bd->g_wqkv && bd->g_bqkv && d->q_in, "cr_wide_ln_qkv_bwd: both of g_wqkv g_bqkv (and q_in) or none");
+    }
     hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_qkv_bwd, bd->n_slabs, true, "cr_wide_ln_qkv_bwd", *bd);
+    const bool sp = precision == CR_PREC_BF16X3;
+    switch (d->D / 16) {
+        case 8:
+            if (wg) return sp ? wide_launch_qkv_bwd<8, true, true>(bd, s) : wide_launch_qkv_bwd<8, false, true>(bd, s);
+            return sp ? wide_launch_qkv_bwd<8, true, false>(bd, s) : wide_launch_qkv_bwd<8, false, false>(bd, s);
+        case 12: return sp ? wide_launch_qkv_bwd<12, true, false>(bd, s) : wide_launch_qkv_bwd<12, false, false>(bd, s);
+        default: return sp ? wide_launch_qkv_bwd<16, true, false>(bd, s) : wide_launch_qkv_bwd<16, false, false>(bd, s);
+    }
 }

@@ -228,6 +228,11 @@ class Engine:
                 if n_slabs < items <= 512:
                     n_slabs = items
         self.n_slabs = n_slabs
+        # cr_gemm_wgrad reduces over rows in n_wslabs workgroups per output tile: at the large hidden sizes of the unfused / wide
+        # path (D x D weights, 4 blocks) a slab per 128 rows is 264 MB written and read again per step (config C4); 32 suffice
+        # to fill the chip (tiles x slabs workgroups).  cr_adam_step learns per 256-parameter block how many slabs are in use.
+        self.n_wslabs = n_slabs if (self.fused or self.D <= 128) else min(n_slabs, int(os.environ.get("CASTREC_WSLABS", "32")))
+        self._wgrad_ranges = []
         f32 = dict(dtype=torch.float32, device=self.dev)
         if share is not None:
             self.P = share.P
@@ -297,6 +302,15 @@ class Engine:
             # the unfused dense layers (hidden sizes above 64, the CAST mlp) follow the engine's matmul arithmetic
             for i in range(args[1]):
                 args[0][i].precision = ATTN_PRECISIONS[self.attn_precision]
+        if name == "cr_gemm_wgrad":
+            args = args[:3] + (self.n_wslabs,)
+            base = self.Gs.data_ptr()
+            for i in range(args[1]):                      # the slab-0 float ranges this launch writes
+                w = args[0][i]
+                o = (w.dW - base) // 4
+                self._wgrad_ranges += [(o + k * w.ldw, o + k * w.ldw + w.N) for k in range(w.K)]
+                if w.db:
+                    self._wgrad_ranges.append(((w.db - base) // 4, (w.db - base) // 4 + w.N))
         fn = getattr(L.lib, name)
         self._keep.append(args)
         lst.append((name, fn, args))
@@ -516,19 +530,27 @@ class Engine:
                                      self._acc(id(dx)), G(pfx + "ln1.gamma"), G(pfx + "ln1.beta"), G(pfx + "wqkv"), G(pfx + "bqkv"),
                                      G(pfx + "ln2.gamma"), G(pfx + "ln2.beta"), G(pfx + "w1"), G(pfx + "b1"), G(pfx + "w2"), G(pfx + "b2"),
                                      S, self.n_slabs)
-                # dy -> g2, g1, d_o (+ dgamma2 / dbeta2 slabs); then dW2 db2 dW1 db1
+                # dy -> g2, g1, d_o, slabs of dgamma2 dbeta2 (and dW2 db2 dW1 db1 unless left to cr_gemm_wgrad)
+                # (the kernels form the weight gradients themselves at D = 128: a [D, D] slab per 128 rows is what an activation
+                #  row block costs; at 192 / 256 the slab of a 64-row block is 4 x its rows, and cr_gemm_wgrad reduces more rows
+                #  per slab)
+                own_w = D == 128 and os.environ.get("CASTREC_WIDE_NO_WGRAD") != "1"
+                if not own_w:
+                    bbd.g_w1 = bbd.g_b1 = bbd.g_w2 = bbd.g_b2 = bbd.g_wqkv = bbd.g_bqkv = None
                 self._call(lst, "cr_wide_ln_ffn_bwd", C.byref(bbd), g2.data_ptr(), g1.data_ptr(), prec)
-                w = (L.WgradDesc * 2)(L.WgradDesc(hid.data_ptr(), D, g2.data_ptr(), D, G(pfx + "w2"), D, G(pfx + "b2"), M, D, D),
-                                      L.WgradDesc(f_in.data_ptr(), D, g1.data_ptr(), D, G(pfx + "w1"), D, G(pfx + "b1"), M, D, D))
-                self._call(lst, "cr_gemm_wgrad", w, 2, S, self.n_slabs)
+                if not own_w:
+                    w = (L.WgradDesc * 2)(L.WgradDesc(hid.data_ptr(), D, g2.data_ptr(), D, G(pfx + "w2"), D, G(pfx + "b2"), M, D, D),
+                                          L.WgradDesc(f_in.data_ptr(), D, g1.data_ptr(), D, G(pfx + "w1"), D, G(pfx + "b1"), M, D, D))
+                    self._call(lst, "cr_gemm_wgrad", w, 2, S, self.n_slabs)
                 dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + MD4, dqkv.data_ptr() + 2 * MD4
                 abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dq, dk, dv, D, stats.data_ptr())
                 self._call(lst, "cr_attn_bwd", C.byref(abd))
-                gw, gb = G(pfx + "wqkv"), G(pfx + "bqkv")
-                w2 = (L.WgradDesc * 3)(L.WgradDesc(q_in.data_ptr(), D, dq, D, gw, 3 * D, gb, M, D, D),
-                                       L.WgradDesc(x.data_ptr(), D, dk, D, gw + 4 * D, 3 * D, gb + 4 * D, M, D, D),
-                                       L.WgradDesc(x.data_ptr(), D, dv, D, gw + 8 * D, 3 * D, gb + 8 * D, M, D, D))
-                self._call(lst, "cr_gemm_wgrad", w2, 3, S, self.n_slabs)
+                if not own_w:
+                    gw, gb = G(pfx + "wqkv"), G(pfx + "bqkv")
+                    w2 = (L.WgradDesc * 3)(L.WgradDesc(q_in.data_ptr(), D, dq, D, gw, 3 * D, gb, M, D, D),
+                                           L.WgradDesc(x.data_ptr(), D, dk, D, gw + 4 * D, 3 * D, gb + 4 * D, M, D, D),
+                                           L.WgradDesc(x.data_ptr(), D, dv, D, gw + 8 * D, 3 * D, gb + 8 * D, M, D, D))
+                    self._call(lst, "cr_gemm_wgrad", w2, 3, S, self.n_slabs)
                 # (dQ | dK | dV, d_o) -> dx (+ dgamma1 / dbeta1 slabs)
                 self._call(lst, "cr_wide_ln_qkv_bwd", C.byref(bbd), prec)
                 return lst
@@ -892,17 +914,30 @@ class Engine:
                 # them over, dist.DataParallel.exchange): every replica must update the same rows
                 self.lazy_ids = self.ids_all[:3].reshape(-1) if world == 1 else torch.zeros(world * 3 * self.M, dtype=torch.int32, device=self.dev)
                 lazy = (self.lazy_ids.data_ptr(), self.lazy_ids.numel(), self.itemnum + 1, self.D, self.lazy_flags.data_ptr())
+            # slabs in use per 256-parameter block: n_wslabs where cr_gemm_wgrad is the only writer, n_slabs elsewhere
+            counts = None
+            if self.n_wslabs < self.n_slabs and self._wgrad_ranges:
+                cov = np.zeros(lay.n_dense + 1, np.int32)
+                for a, b in self._wgrad_ranges:
+                    cov[a] += 1; cov[b] -= 1
+                only_w = np.cumsum(cov[:-1]) > 0
+                nb = (lay.n_dense + 255) // 256
+                pad = np.ones(nb * 256, bool)
+                pad[:lay.n_dense] = only_w
+                cnt = np.where(pad.reshape(nb, 256).all(1), self.n_wslabs, self.n_slabs).astype(np.int32)
+                self.slab_counts = torch.from_numpy(cnt).to(self.dev)
+                counts = self.slab_counts.data_ptr()
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
                             lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr(),
-                            snap, tsnap, l2, n_l2, *lazy)
+                            snap, tsnap, l2, n_l2, *lazy, counts)
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
-                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap, l2, n_l2, *lazy)
+                             1e-8, self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, tsnap, l2, n_l2, *lazy, None)
             self._adam_flat = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad1),))
             self._reduce = ("cr_reduce_slabs", L.lib.cr_reduce_slabs,
                             (self.Gs.data_ptr(), self.n_slabs, lay.n_dense, self.Gflat.data_ptr() + 4 * lay.n_table,
-                             self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total))
+                             self.state.data_ptr(), self.Gflat.data_ptr() + 4 * lay.n_total, counts))
             # l2_emb != 0: the penalty of the CURRENT parameters, just before Adam moves them (one more launch; every
             # reference run uses 0.0)
             self._l2 = ("cr_l2_penalty", L.lib.cr_l2_penalty, (self.P.data_ptr(), n_l2, 0.5 * l2, self.state.data_ptr())) if n_l2 else None

@@ -118,7 +118,7 @@ class AdamDesc(C.Structure):
     _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
                 ("n_table", C.c_int64), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
                 ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", C.c_int64),
-                ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p)]
+                ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p), ("slab_counts", c_p)]
 
 
 def _sig(name, restype, argtypes):
@@ -164,7 +164,7 @@ _sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
 _sig("cr_head_fwd_bwd_ln", c_i, [C.POINTER(HeadDesc), C.POINTER(LnBwdDesc), c_p])
 _sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 _sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
-_sig("cr_reduce_slabs", c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p])
+_sig("cr_reduce_slabs", c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p])
 _sig("cr_l2_penalty", c_i, [c_p, C.c_int64, c_f, c_p, c_p])
 _sig("cr_graph_begin", c_i, [c_p])
 _sig("cr_graph_end", c_i, [c_p, C.POINTER(c_p)])

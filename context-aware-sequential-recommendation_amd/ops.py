@@ -131,7 +131,7 @@ def adam_step(p, m, v, table_grad, dense_slabs, n_table, n_dense, n_slabs, lr, s
     d = L.AdamDesc(_p(p), _p(m), _p(v), _p(table_grad), _p(dense_slabs), n_table, n_dense, n_slabs, lr, beta1, beta2,
                    eps, _p(state), _p(stats) if stats is not None else None,
                    _p(step_snapshot) if step_snapshot is not None else None, 0.0, 0,
-                   _p(lazy_ids), 0 if lazy_ids is None else lazy_ids.numel(), lazy_rows, lazy_D, _p(lazy_flags))
+                   _p(lazy_ids), 0 if lazy_ids is None else lazy_ids.numel(), lazy_rows, lazy_D, _p(lazy_flags), None)
     L.call("cr_adam_step", C.byref(d), _stream())
 
 

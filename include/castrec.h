@@ -399,6 +399,9 @@ typedef struct {
      * gradient of the other rows are not touched.  Rows updated in every step so far match dense Adam exactly. */
     const int32_t* lazy_ids; int n_lazy_ids, lazy_rows, lazy_D;
     uint32_t* lazy_flags;             /* [lazy_rows] */
+    const int32_t* slab_counts;       /* optional (device) [ceil(n_dense / 256)]: slabs that hold gradient for the 256 dense
+                                         parameters of block b (the others are known zero and are not read): producers that
+                                         reduce more rows per workgroup (cr_gemm_wgrad at large hidden sizes) write fewer slabs */
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 
@@ -411,7 +414,7 @@ int cr_l2_penalty(const float* p, int64_t n, float scale, float* state, void* st
  * statistics state[0..2] to stats_out (the tail of the all-reduce bucket).  cr_adam_step is then
  * called with n_slabs = 1 on the reduced vector. */
 int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dense, float* out,
-                    const float* state, float* stats_out, void* stream);
+                    const float* state, float* stats_out, const int32_t* slab_counts /* optional, as cr_adam_desc's */, void* stream);
 
 /* ---- HIP graph capture of a whole step (launch-bound inner loop) ---------------------- */
 int cr_graph_begin(void* stream);
