@@ -161,3 +161,34 @@ class EngineReplica:
         (embedding backward: modules.py:157; head: sasrec.py:89-90)."""
         e = self.e
         return dict(n_item=(e.itemnum + 1) * e.D, D=e.D, n_slots=3 * e.M, ids=lambda: e.ids_all[:3].reshape(-1))
+
+
+class HostBounce:
+    """Replica adapter whose bucket and parameter vector travel through host memory, for a `gloo` process group: ranks that
+    SHARE one card (RCCL refuses two ranks per device: the one-GPU test box) or a host without RCCL.  Everything else is the
+    production path -- row shards, global-row dropout keys, un-normalised shard gradients + target counts in one bucket, Adam
+    dividing by the reduced count (tests/test_dist_gpu.py, the 2-rank main.py test).  Selected by CASTREC_DIST_BACKEND=gloo."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.host_p = inner.param_vector().cpu()
+        self.host_g = None
+
+    def param_vector(self):
+        return self.host_p
+
+    def adopt_params(self):
+        """after DataParallel's broadcast of the (host) parameter vector: rank 0's parameters onto this card"""
+        self.inner.param_vector().copy_(self.host_p)
+
+    def backward_to_flat(self, shard):
+        self.host_g = self.inner.backward_to_flat(shard).cpu()
+        return self.host_g
+
+    def adam_from_flat(self):
+        self.inner.e.Gflat.copy_(self.host_g)
+        self.inner.adam_from_flat()
+
+    def sparse_spec(self):
+        return self.inner.sparse_spec()
+

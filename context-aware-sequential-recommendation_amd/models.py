@@ -33,8 +33,38 @@ class _Model(object):
         self.attention_weights = None
 
     # -- training ---------------------------------------------------------------------------------
+    def data_parallel(self, rank, world, process_group=None, sparse=None):
+        """One replica per rank (the reference has no multi-GPU path): every rank feeds train_step the SAME
+        global batch (one sampler stream, same seed everywhere), takes rows [rank * B / world, (rank + 1) * B / world) of it,
+        and the gradients meet in castrec_amd.dist.DataParallel (RCCL all-reduce of one bucket, or the sparse item-row
+        exchange for large tables) before an identical Adam step on every rank.  Call before the first train_step."""
+        if self._train is not None:
+            raise RuntimeError("data_parallel() must be called before the first train_step")
+        self._dp_cfg = (int(rank), int(world), process_group, sparse)
+
     def _train_engine(self, B):
         if self._train is None:
+            dp_cfg = getattr(self, "_dp_cfg", None)
+            if dp_cfg is not None and dp_cfg[1] > 1:
+                from . import dist as D_
+                rank, world, pg, sparse = dp_cfg
+                lo, hi = D_.shard_rows(B, rank, world)
+                self._train = Engine(self.name, self.usernum, self.itemnum, self.hp, hi - lo, training=True, share=self._owner,
+                                     n_slabs=self._n_slabs, batch_global=B, row_offset=lo * self.hp.maxlen)
+                self._dp_rows = (lo, hi, B)
+                rep = D_.EngineReplica(self._train, use_graph=self._graph)
+                bounce = os.environ.get("CASTREC_DIST_BACKEND") == "gloo"     # gloo cannot reduce device tensors: through host memory
+                if bounce:
+                    rep = D_.HostBounce(rep)
+                self._dp = D_.DataParallel(rep, rank, world, pg, sparse=sparse)
+                if bounce:
+                    rep.adopt_params()
+                if self._graph:
+                    self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
+                if self._pending_opt is not None:
+                    self._apply_opt(*self._pending_opt)
+                    self._pending_opt = None
+                return self._train
             self._train = Engine(self.name, self.usernum, self.itemnum, self.hp, B, training=True, share=self._owner,
                                  n_slabs=self._n_slabs, batch_global=self._batch_global, row_offset=self._row_offset)
             if self._graph and self._batch_global is None:
@@ -43,6 +73,10 @@ class _Model(object):
             if self._pending_opt is not None:          # a checkpoint's Adam slots and step count (saver.restore, main.py:165-175)
                 self._apply_opt(*self._pending_opt)
                 self._pending_opt = None
+        if getattr(self, "_dp", None) is not None:
+            if self._dp_rows[2] != B:
+                raise ValueError("global batch size changed from %d to %d (static graph)" % (self._dp_rows[2], B))
+            return self._train
         if self._train.B != B:
             raise ValueError("batch size changed from %d to %d (static graph)" % (self._train.B, B))
         return self._train
@@ -52,8 +86,12 @@ class _Model(object):
         seq = np.asarray(seq)
         eng = self._train_engine(seq.shape[0])
         z = np.zeros_like(seq) if (time_seq is None or hours is None or days is None) else None
-        eng.train_step(seq, np.asarray(pos), np.asarray(neg), z if time_seq is None else np.asarray(time_seq),
-                       z if hours is None else np.asarray(hours), z if days is None else np.asarray(days))
+        arrs = (seq, np.asarray(pos), np.asarray(neg), z if time_seq is None else np.asarray(time_seq),
+                z if hours is None else np.asarray(hours), z if days is None else np.asarray(days))
+        if getattr(self, "_dp", None) is not None:
+            self._dp.step(arrs)                            # this rank's rows -> backward -> exchange -> Adam (loss / auc: global)
+        else:
+            eng.train_step(*arrs)
         if fetch:
             loss, auc = eng.loss_auc()
             return auc, loss

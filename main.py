@@ -80,6 +80,15 @@ def main(argv=None):
         print("provide model from", MODELS)
         sys.exit(0)
     model = build_model(args.model, usernum, itemnum, ratingnum, args)
+    # Data parallelism (not in the reference): under `python -m torch.distributed.run --nproc-per-node N
+    # main.py ...` every rank runs this same program -- same seed, same sampler stream, --batch_size is the GLOBAL batch --
+    # and trains on its rows of each batch; gradients meet over RCCL (castrec_amd.dist).  Rank 0 evaluates, logs and saves.
+    rank, world = 0, 1
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from castrec_amd import dist as cr_dist
+        import torch.distributed as tdist
+        rank, _, world = cr_dist.init_from_env(os.environ.get("CASTREC_DIST_BACKEND"))
+        model.data_parallel(rank, world)
     sampler = WarpSampler(args, train_corpus(train, usernum, itemnum), usernum, itemnum,
                           batch_size=args.batch_size, maxlen=args.maxlen, n_workers=1)
     model_path = os.path.abspath('saved_models')
@@ -108,6 +117,8 @@ def main(argv=None):
         sampler.close()
         return 0
 
+    if rank != 0:
+        files_path = os.path.join(files_path, 'rank%d' % rank)     # (the other ranks write nothing of interest)
     os.makedirs(files_path, exist_ok=True)
     with open(os.path.join(files_path, 'params.txt'), 'w') as f:   # main.py:196-197
         json.dump(args.__dict__, f, indent=2)
@@ -121,7 +132,10 @@ def main(argv=None):
                 out = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq, fetch=last)
             if out is not None:
                 logger.info('epoch %d: TRAIN/loss %.5f TRAIN/auc %.5f' % (epoch, out[1], out[0]))
-            if epoch % args.eval_every == 0:
+            if epoch % args.eval_every == 0 and rank != 0:
+                tdist.barrier()                                    # rank 0 evaluates; parameters are identical everywhere
+                t0 = time.time()
+            elif epoch % args.eval_every == 0:
                 logger.info('Model saved in path: %s' % model.save(save_path))
                 logger.info('Evaluating')
                 T += time.time() - t0
@@ -131,6 +145,8 @@ def main(argv=None):
                     epoch, T, t_valid[0], t_valid[1], t_test[0], t_test[1]))
                 f.write(str(t_valid) + ' ' + str(t_test) + '\n')
                 f.flush()
+                if world > 1:
+                    tdist.barrier()
                 t0 = time.time()
     except Exception as e:                                         # main.py:253-257
         logger.error(e)

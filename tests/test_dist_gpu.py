@@ -31,37 +31,11 @@ def hyper(E):
     return E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=10, seed=4)
 
 
-class HostBounce:
-    """EngineReplica whose bucket and parameter vector travel through host memory (gloo)."""
-
-    def __init__(self, inner):
-        self.inner = inner
-        self.host_p = inner.param_vector().cpu()
-        self.host_g = None
-
-    def param_vector(self):
-        return self.host_p
-
-    def adopt_params(self):
-        self.inner.param_vector().copy_(self.host_p)
-
-    def backward_to_flat(self, shard):
-        self.host_g = self.inner.backward_to_flat(shard).cpu()
-        return self.host_g
-
-    def adam_from_flat(self):
-        self.inner.e.Gflat.copy_(self.host_g)
-        self.inner.adam_from_flat()
-
-    def sparse_spec(self):
-        return self.inner.sparse_spec()
-
-
 def _worker(rank, world, port, q, items=ITEMS, sparse=False):
     import torch.distributed as dist
     import castrec_amd  # noqa: F401
     from castrec_amd import engine as E
-    from castrec_amd.dist import DataParallel, EngineReplica, shard_rows
+    from castrec_amd.dist import DataParallel, EngineReplica, HostBounce, shard_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_rows(B, rank, world)

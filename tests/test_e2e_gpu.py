@@ -167,3 +167,51 @@ def test_checkpoint_restores_the_optimiser_state(tmp_path):
     c = models.CAST1(9, itemnum, 5, args)                # without the slots the same step differs (fresh Adam at t = 1)
     c.load_params({k: v.cpu() for k, v in a.get_params().items()})
     assert a._train.step_number() == 5 and b._train.step_number() == 5
+
+
+@pytest.mark.timeout(600)
+def test_main_cli_two_ranks_equal_one_process(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 main.py ...` (both ranks on the box's one card, bucket over gloo
+    through host memory: CASTREC_DIST_BACKEND=gloo) ends with the numbers of the one-process run on the same GLOBAL batch:
+    same sampler stream, row shards, global-row dropout keys, global target count."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = [os.path.join(root, "main.py"), "--dataset", "synthetic:tiny", "--train_dir", "t", "--model", "cast_1", "--maxlen", "12",
+            "--batch_size", "4", "--hidden_units", "16", "--num_epochs", "3", "--eval_every", "3", "--max_bins", "20"]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    r = subprocess.run([sys.executable] + argv, cwd=one, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port)] + argv, cwd=two, env=dict(env, CASTREC_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def last_log(d):
+        runs = [x for x in os.listdir(d / "saved_models" / "synthetic_tiny")]
+        assert len(runs) == 1
+        run = d / "saved_models" / "synthetic_tiny" / runs[0]
+        return run, (run / "log.txt").read_text().strip().splitlines()[-1]
+
+    run1, l1 = last_log(one)
+    run2, l2 = last_log(two)
+    import re
+    num = re.compile(r"(?<![\w.])\d+\.\d+(?:e-?\d+)?")           # "(np.float64(0.31), ...)": the decimal numbers, not the 64
+    v1 = [float(x) for x in num.findall(l1)]
+    v2 = [float(x) for x in num.findall(l2)]
+    assert len(v1) == 4 and np.allclose(v1, v2, atol=2e-3), (l1, l2)             # NDCG / HR of valid and test
+    assert (run2 / "model.ckpt").exists() and (run2 / "rank1" / "params.txt").exists()
+    # the trained parameters agree to rounding (the two runs add the same shard gradients in a different order)
+    a = torch.load(run1 / "model.ckpt", map_location="cpu", weights_only=False)
+    b = torch.load(run2 / "model.ckpt", map_location="cpu", weights_only=False)
+    assert a["P"].numel() == b["P"].numel() > 100
+    # (elements whose gradient nearly cancels -- b_k above all -- take O(lr) Adam moves decided by rounding, in any
+    #  implementation: DESIGN.md section 2; here the 4 x 16 key biases of the four blocks, 0.9 % of the vector)
+    dp = np.abs(a["P"].numpy() - b["P"].numpy())
+    assert (dp > 5e-5).mean() < 1.2e-2 and dp.max() < 5e-3, ((dp > 5e-5).mean(), dp.max())
+    dm = np.abs(a["M"].numpy() - b["M"].numpy()).max()
+    assert dm <= 1e-3 * np.abs(a["M"].numpy()).max(), (dm, np.abs(a["M"].numpy()).max())     # first moments, to their own scale
