@@ -392,6 +392,25 @@ def test_config_c5_shape(E, prec):
     _other_shapes(E, "sasrec", 256, 4, 512, 2, B=2, prec=prec, itemnum=3000)
 
 
+@pytest.mark.parametrize("model,D,H,T,L,B,prec", [("sasrec", 192, 3, 40, 1, 3, "bf16x3"),     # 4 waves per workgroup, 3 panels per weight
+                                                    ("cast_1", 128, 2, 37, 2, 3, "bf16x3"),     # 111 rows: a ragged last row block
+                                                    ("cast_1", 128, 2, 37, 2, 3, "bf16"),       # plain bf16 operands
+                                                    ("sasrec", 256, 4, 50, 1, 5, "bf16"),
+                                                    ("cast_4", 128, 4, 24, 1, 3, "bf16x3")])    # wide blocks + the CAST mlp
+def test_wide_row_kernels(E, model, D, H, T, L, B, prec):
+    """cr_wide_* (hidden sizes 128 / 192 / 256, one launch per row phase) against the oracle; n_slabs = 5 < row blocks, so the
+    backward kernels walk several row blocks per workgroup and ADD to their slab from the second one on."""
+    _other_shapes(E, model, D, H, T, L, B, prec=prec)
+
+
+@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD"])
+def test_wide_alternative_paths_stay_green(E, env, monkeypatch):
+    """the unfused chain (cr_layernorm_* / cr_gemm_rows / cr_eltwise) and the wide kernels with cr_gemm_wgrad forming the
+    weight gradients: what the engine falls back to outside D = 128 / 192 / 256"""
+    monkeypatch.setenv(env, "1")
+    _other_shapes(E, "sasrec", 128, 4, 40, 2, prec="bf16x3")
+
+
 @pytest.mark.parametrize("model", ["cast_%d" % i for i in range(2, 10)])
 def test_every_cast_graph_at_the_headline_shape(E, model):
     """cast_2 ... cast_9 once at D = 50, T = 200 (cast_1 is the bench workload and has its own tests)."""
