@@ -27,11 +27,14 @@
 
 // Threads per workgroup: 8 waves (128 rows) at D = 128; 4 waves (64 rows) above, where a row's operands and partial results
 // need more than the 256 registers a wave gets at two waves per SIMD (one wave per SIMD may use all 512).
-#ifndef WD_NT8
-#define WD_NT8 1
-#endif
-template <int NCT> struct WdCfg { static constexpr int NT = WD_NT8 && NCT <= 8 ? 512 : 256, ROWS = NT / 4, NW = NT / 64, ITEMS = 128 * NCT / NT; };
-
+// Threads per workgroup.  Forward kernels: 8 waves (128 rows) at every size.  Backward kernels: 8 waves at D = 128, 4 waves
+// (64 rows) above, where a row's operands and partial results need more than the 256 registers a wave gets at two waves per
+// SIMD (one wave per SIMD may use all 512).  More rows per workgroup = fewer passes of the weights through LDS: at D = 256
+// a workgroup reads 768 KB of weights per 64 KB of activation rows.
+// MODE 0: forward, 8 waves; 1: backward; 2: forward, 4 waves (row counts that leave CUs idle at 128 rows per workgroup)
+template <int NCT, int MODE> struct WdCfg {
+    static constexpr int NT = MODE == 0 ? 512 : (MODE == 2 ? 256 : (NCT <= 8 ? 512 : 256)), ROWS = NT / 4, NW = NT / 64, ITEMS = 128 * NCT / NT;
+};
 // ---- layout R rows of a dense [*, D] matrix, D = 16 NCT exactly (no boundary cases at these sizes) -------------
 template <int NCT>
 __device__ __forceinline__ void wr_load(f32x4 (&x)[NCT], const float* base, int m, bool rok) {
@@ -121,14 +124,14 @@ __device__ __forceinline__ void wr_split2(const f32x4& a, const f32x4& b, bf8& h
 // ---- weight panels ----------------------------------------------------------------------------------------
 // An item is 8 consecutive floats of a weight row (two dword-aligned 16-byte loads).  D * 8 items per panel,
 // D / 64 per thread.
-template <int NCT> struct PanelRegs { float v[WdCfg<NCT>::ITEMS][8]; };
+template <int NCT, int MODE> struct PanelRegs { float v[WdCfg<NCT, MODE>::ITEMS][8]; };
 
 // forward panel: W[k][c0 .. c0 + 63], k < D; item = (k, chunk of 8 columns)
-template <int NCT>
-__device__ __forceinline__ void fpanel_issue(PanelRegs<NCT>& r, const float* W, int ld, int c0) {
+template <int NCT, int MODE>
+__device__ __forceinline__ void fpanel_issue(PanelRegs<NCT, MODE>& r, const float* W, int ld, int c0) {
 #pragma unroll
-    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
-        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
+    for (int u = 0; u < WdCfg<NCT, MODE>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT, MODE>::NT * u;
         const int k = item >> 3, ch = item & 7;
         const float* p = W + (size_t)k * ld + c0 + 8 * ch;
         const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
@@ -136,11 +139,11 @@ __device__ __forceinline__ void fpanel_issue(PanelRegs<NCT>& r, const float* W, 
         r.v[u][4] = b.x; r.v[u][5] = b.y; r.v[u][6] = b.z; r.v[u][7] = b.w;
     }
 }
-template <int NCT, bool SPLIT>
-__device__ __forceinline__ void fpanel_put(const PanelRegs<NCT>& r, __bf16* img) {
+template <int NCT, bool SPLIT, int MODE>
+__device__ __forceinline__ void fpanel_put(const PanelRegs<NCT, MODE>& r, __bf16* img) {
 #pragma unroll
-    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
-        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
+    for (int u = 0; u < WdCfg<NCT, MODE>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT, MODE>::NT * u;
         const int k = item >> 3, ch = item & 7;
         bf8 h, l;
         split8<SPLIT>(r.v[u], h, l);
@@ -151,10 +154,10 @@ __device__ __forceinline__ void fpanel_put(const PanelRegs<NCT>& r, __bf16* img)
 }
 // backward panel: W[j0 + j][c0 + n], j < 64, n < D; item = (j, chunk of 8 columns n); stored in the operand's k order
 template <int NCT>
-__device__ __forceinline__ void bpanel_issue(PanelRegs<NCT>& r, const float* W, int ld, int j0, int c0) {
+__device__ __forceinline__ void bpanel_issue(PanelRegs<NCT, 1>& r, const float* W, int ld, int j0, int c0) {
 #pragma unroll
-    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
-        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
+    for (int u = 0; u < WdCfg<NCT, 1>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT, 1>::NT * u;
         const int j = item / (2 * NCT), c8 = item % (2 * NCT);
         const float* p = W + (size_t)(j0 + j) * ld + c0 + 8 * c8;
         const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
@@ -163,10 +166,10 @@ __device__ __forceinline__ void bpanel_issue(PanelRegs<NCT>& r, const float* W, 
     }
 }
 template <int NCT, bool SPLIT>
-__device__ __forceinline__ void bpanel_put(const PanelRegs<NCT>& r, __bf16* img) {
+__device__ __forceinline__ void bpanel_put(const PanelRegs<NCT, 1>& r, __bf16* img) {
 #pragma unroll
-    for (int u = 0; u < WdCfg<NCT>::ITEMS; ++u) {
-        const int item = threadIdx.x + WdCfg<NCT>::NT * u;
+    for (int u = 0; u < WdCfg<NCT, 1>::ITEMS; ++u) {
+        const int item = threadIdx.x + WdCfg<NCT, 1>::NT * u;
         const int j = item / (2 * NCT), c8 = item % (2 * NCT);
         const int ks = c8 >> 2, q = c8 & 3, h4 = 4 * (q >> 1);
         const int chA = 4 * (ks & 1) + 2 * (q & 1);
@@ -231,10 +234,10 @@ struct WideLds {
     static constexpr int BUF = (SPLIT ? 2 : 1) * HALF;                // one panel buffer
     static constexpr size_t PANEL_BYTES = 2 * (size_t)BUF * 2;        // double buffered
     static constexpr int NV = 5;                                       // column-sum vectors of a backward kernel (dgamma, dbeta, 3 bias gradients)
-    static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT>::NW * NV * 16 * NCT * 4;  // [waves][NV][D] floats (backward kernels)
+    static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT, 1>::NW * NV * 16 * NCT * 4;  // [waves][NV][D] floats (backward kernels)
     static constexpr size_t TOTAL = PANEL_BYTES + SLOT_BYTES + 3 * 16 * NCT * 4;      // + [3 D] floats of biases (forward kernels)
     // weight-gradient phase of the backward kernels: two [ROWS][D] images (a, g), each hi (+ lo), over the panel buffers
-    static constexpr int IMG_HALF = WdCfg<NCT>::ROWS * 16 * NCT;       // bf16 elements of one half of one image
+    static constexpr int IMG_HALF = WdCfg<NCT, 1>::ROWS * 16 * NCT;       // bf16 elements of one half of one image
     static constexpr int IMG = (SPLIT ? 2 : 1) * IMG_HALF;
     static constexpr size_t IMG_BYTES = 2 * (size_t)IMG * 2;
     static constexpr size_t TOTAL_BWD = (IMG_BYTES > PANEL_BYTES ? IMG_BYTES : PANEL_BYTES) + SLOT_BYTES;
@@ -256,15 +259,15 @@ struct WideLds {
 //   boundary(i) -> bool part-boundary work before iteration i (operand reload, LayerNorm backward ...); true = the
 //                       auxiliary rows prefetched for i are stale (written by this boundary): they are loaded again
 //   epilogue(i, acc, aux)
-template <int NCT, bool SPLIT, bool FWD, int NPAN, class Issue, class AuxLoad, class Boundary, class Epilogue>
-__device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT> (&pr)[NCT <= 8 ? 2 : 1], const bf8 (&oh)[NCT / 2],
+template <int NCT, bool SPLIT, int MODE, int NPAN, class Issue, class AuxLoad, class Boundary, class Epilogue>
+__device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT, MODE> (&pr)[NCT <= 8 ? 2 : 1], const bf8 (&oh)[NCT / 2],
                                                const bf8 (&ol)[NCT / 2], Issue issue, AuxLoad auxload, Boundary boundary,
                                                Epilogue epilogue) {
     typedef WideLds<NCT, SPLIT> LD;
-    constexpr bool D2 = NCT <= 8;
+    constexpr bool D2 = NCT <= 8, FWD = MODE != 1;
     f32x4 aux_n[4];
     auxload(aux_n, 0);
-    if (FWD) fpanel_put<NCT, SPLIT>(pr[0], pb); else bpanel_put<NCT, SPLIT>(pr[0], pb);
+    if constexpr (FWD) fpanel_put<NCT, SPLIT, MODE>(pr[0], pb); else bpanel_put<NCT, SPLIT>(pr[0], pb);
     __syncthreads();
     _Pragma("clang loop unroll_count(NCT <= 8 ? NPAN : 1)")
     for (int i = 0; i < NPAN; ++i) {
@@ -282,7 +285,7 @@ __device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT> (&pr)[
         epilogue(i, acc, aux);
         if (i + 1 < NPAN) {
             __bf16* dst = pb + ((i + 1) & 1) * LD::BUF;
-            if (FWD) fpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst); else bpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst);
+            if constexpr (FWD) fpanel_put<NCT, SPLIT, MODE>(pr[D2 ? ((i + 1) & 1) : 0], dst); else bpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst);
         }
         __syncthreads();
     }
@@ -303,8 +306,8 @@ __device__ __forceinline__ void lds_vec4(f32x4 (&v)[4], const float* vec, int p)
 // =====================================================================================================
 // forward: LN1 + Q / K / V projections
 // =====================================================================================================
-template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d) {
+template <int NCT, bool SPLIT, int MODE>
+__global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
@@ -312,12 +315,12 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [3 D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
-    const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
+    const int m = blockIdx.x * WdCfg<NCT, MODE>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
-    auto issue = [&](PanelRegs<NCT>& r, int n) { fpanel_issue<NCT>(r, d.wqkv, 3 * D, (n / NP) * D + 64 * (n % NP)); };
-    PanelRegs<NCT> pr[D2 ? 2 : 1];
+    auto issue = [&](PanelRegs<NCT, MODE>& r, int n) { fpanel_issue<NCT, MODE>(r, d.wqkv, 3 * D, (n / NP) * D + 64 * (n % NP)); };
+    PanelRegs<NCT, MODE> pr[D2 ? 2 : 1];
     issue(pr[0], 0);
-    if (D2) issue(pr[1], 1);
+    if constexpr (D2) issue(pr[1], 1);
     vec_to_lds(lbias, d.bqkv, 3 * D);
     bf8 oh[NKS], ol[NKS];                                 // the current operand: q_in for Q, x for K and V
     {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d
         }
         wr_split<NCT, SPLIT>(x, oh, ol);
     }
-    panel_pipeline<NCT, SPLIT, true, NPAN>(pb, pr, oh, ol, issue,
+    panel_pipeline<NCT, SPLIT, MODE, NPAN>(pb, pr, oh, ol, issue,
         [&](f32x4 (&)[4], int) {},
         [&](int i) {
             if (i == NP) {                                // K and V take the un-normalised rows (modules.py:204-205)
@@ -371,8 +374,8 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_fwd(cr_block_desc d
 // =====================================================================================================
 // forward: LN2 + feed-forward
 // =====================================================================================================
-template <int NCT, bool SPLIT>
-__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d) {
+template <int NCT, bool SPLIT, int MODE>
+__global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_block_desc d) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
@@ -380,13 +383,13 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [2 D]: b1, b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int m = blockIdx.x * WdCfg<NCT>::ROWS + 16 * wave + li;
+    const int m = blockIdx.x * WdCfg<NCT, MODE>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
     const DropCtx dc1 = drop_ctx(d.drop_ffn1), dc2 = drop_ctx(d.drop_ffn2);
-    auto issue = [&](PanelRegs<NCT>& r, int n) { fpanel_issue<NCT>(r, n / NP ? d.w2 : d.w1, D, 64 * (n % NP)); };
-    PanelRegs<NCT> pr[D2 ? 2 : 1];
+    auto issue = [&](PanelRegs<NCT, MODE>& r, int n) { fpanel_issue<NCT, MODE>(r, n / NP ? d.w2 : d.w1, D, 64 * (n % NP)); };
+    PanelRegs<NCT, MODE> pr[D2 ? 2 : 1];
     issue(pr[0], 0);
-    if (D2) issue(pr[1], 1);
+    if constexpr (D2) issue(pr[1], 1);
     vec_to_lds(lbias, d.b1, D);
     vec_to_lds(lbias + D, d.b2, D);
     bf8 oh[NKS], ol[NKS];                                 // f_in, then hid
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_fwd(cr_block_desc d
     }
     const int id = rok ? d.mask_ids[m] : 0;
     const uint32_t xrow = ((d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
-    panel_pipeline<NCT, SPLIT, true, NPAN>(pb, pr, oh, ol, issue,
+    panel_pipeline<NCT, SPLIT, MODE, NPAN>(pb, pr, oh, ol, issue,
         [&](f32x4 (&aux)[4], int n) {
             if (n >= NP) wr_load4(aux, d.f_in, D, m, rok, n - NP);     // own stores (residual = LN2 output, modules.py:313)
         },
@@ -464,7 +467,7 @@ __device__ __forceinline__ void colsum_put(float* slots, const f32x4 (&a)[NCT], 
 }
 template <int NCT, int NUSE>
 __device__ __forceinline__ void colsum_fold(const float* slots, float (&t)[NUSE]) {
-    constexpr int D = 16 * NCT, NW = WdCfg<NCT>::NW, NV = WideLds<NCT, true>::NV;
+    constexpr int D = 16 * NCT, NW = WdCfg<NCT, 1>::NW, NV = WideLds<NCT, true>::NV;
     __syncthreads();
     if ((int)threadIdx.x < D) {
 #pragma unroll
@@ -486,7 +489,7 @@ __device__ __forceinline__ void colsum_fold(const float* slots, float (&t)[NUSE]
 template <int NCT, bool SPLIT>
 __device__ __forceinline__ void wg_row_to_image(__bf16* img, const f32x4 (&x)[NCT]) {
     typedef WideLds<NCT, SPLIT> LD;
-    constexpr int SUB = WdCfg<NCT>::ROWS * 64;
+    constexpr int SUB = WdCfg<NCT, 1>::ROWS * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int row = 16 * wave + li;
 #pragma unroll
@@ -505,7 +508,7 @@ __device__ __forceinline__ void wg_row_to_image(__bf16* img, const f32x4 (&x)[NC
 template <int NCT, bool SPLIT>
 __device__ __forceinline__ void wg_product(const __bf16* ia, const __bf16* ig, float* dW, int ldw, bool first) {
     typedef WideLds<NCT, SPLIT> LD;
-    constexpr int ROWS = WdCfg<NCT>::ROWS, NW = WdCfg<NCT>::NW, SUB = ROWS * 64;
+    constexpr int ROWS = WdCfg<NCT, 1>::ROWS, NW = WdCfg<NCT, 1>::NW, SUB = ROWS * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
 #pragma unroll 1
     for (int kt = wave; kt < NCT; kt += NW) {
@@ -590,7 +593,7 @@ __device__ __forceinline__ void wr_ln_bwd(f32x4 (&g)[NCT], f32x4 (&x)[NCT], cons
 // backward: feed-forward + LN2
 // =====================================================================================================
 template <int NCT, bool SPLIT, bool WG>
-__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
+__global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
@@ -601,17 +604,17 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_de
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const DropCtx dc2 = drop_ctx(d.drop_ffn2);
     const float gate_scale = d.drop_ffn1.rate > 0.0f ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-    const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
+    const int nblk = (d.M + WdCfg<NCT, 1>::ROWS - 1) / WdCfg<NCT, 1>::ROWS;
     float tot[4] = {0.f, 0.f, 0.f, 0.f};                  // dgamma2, dbeta2, db2, db1 of column threadIdx.x
     constexpr bool wgrad = WG;                            // (a template flag: the phase's registers cost the other shapes a spill)
-    auto issue = [&](PanelRegs<NCT>& r, int n) { bpanel_issue<NCT>(r, n / NP ? d.w1 : d.w2, D, 64 * (n % NP), 0); };
+    auto issue = [&](PanelRegs<NCT, 1>& r, int n) { bpanel_issue<NCT>(r, n / NP ? d.w1 : d.w2, D, 64 * (n % NP), 0); };
 #pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
+        const int m = blk * WdCfg<NCT, 1>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
-        PanelRegs<NCT> pr[D2 ? 2 : 1];
+        PanelRegs<NCT, 1> pr[D2 ? 2 : 1];
         issue(pr[0], 0);
-        if (D2) issue(pr[1], 1);
+        if constexpr (D2) issue(pr[1], 1);
         const int id = rok ? d.mask_ids[m] : 0;
         const uint32_t xrow = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
         bf8 oh[NKS], ol[NKS];                             // g2, then g1
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_de
             wr_store<NCT>(g2out, m, rok, g);
             wr_split<NCT, SPLIT>(g, oh, ol);
         }
-        panel_pipeline<NCT, SPLIT, false, NPAN>(pb, pr, oh, ol, issue,
+        panel_pipeline<NCT, SPLIT, 1, NPAN>(pb, pr, oh, ol, issue,
             [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dy : d.hid, D, m, rok, n % NP); },
             [&](int i) {
                 if (i == NP) {
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_ffn_bwd(cr_block_bwd_de
 // backward: Q / K / V projections + LN1
 // =====================================================================================================
 template <int NCT, bool SPLIT, bool WG>
-__global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
+__global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_bwd_desc bd) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
@@ -712,17 +715,17 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_bwd(cr_block_bwd_de
     float* slots = reinterpret_cast<float*>(smem_raw + (WG ? LD::TOTAL_BWD : LD::TOTAL_BWD_NOWG) - LD::SLOT_BYTES);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
     const size_t MD = (size_t)d.M * D;
-    const int nblk = (d.M + WdCfg<NCT>::ROWS - 1) / WdCfg<NCT>::ROWS;
+    const int nblk = (d.M + WdCfg<NCT, 1>::ROWS - 1) / WdCfg<NCT, 1>::ROWS;
     float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};             // dgamma1, dbeta1, dbq, dbk, dbv of column threadIdx.x
     constexpr bool wgrad = WG;
-    auto issue = [&](PanelRegs<NCT>& r, int n) { bpanel_issue<NCT>(r, d.wqkv, 3 * D, 64 * (n % NP), (n / NP) * D); };
+    auto issue = [&](PanelRegs<NCT, 1>& r, int n) { bpanel_issue<NCT>(r, d.wqkv, 3 * D, 64 * (n % NP), (n / NP) * D); };
 #pragma unroll 1
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int m = blk * WdCfg<NCT>::ROWS + 16 * wave + li;
+        const int m = blk * WdCfg<NCT, 1>::ROWS + 16 * wave + li;
         const bool rok = m < d.M;
-        PanelRegs<NCT> pr[D2 ? 2 : 1];
+        PanelRegs<NCT, 1> pr[D2 ? 2 : 1];
         issue(pr[0], 0);
-        if (D2) issue(pr[1], 1);
+        if constexpr (D2) issue(pr[1], 1);
         bf8 oh[NKS], ol[NKS];                             // dQ, dK, dV rows in turn
         {
             f32x4 g[NCT];
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(WdCfg<NCT>::NT) void k_wide_qkv_bwd(cr_block_bwd_de
             wr_split<NCT, SPLIT>(g, oh, ol);
         }
         // parts: Wq rows (dq_in = dQ Wq^T + d_o, parked in d_o), then LN1 backward -> dx; Wk rows (dx += dK Wk^T); Wv rows
-        panel_pipeline<NCT, SPLIT, false, NPAN>(pb, pr, oh, ol, issue,
+        panel_pipeline<NCT, SPLIT, 1, NPAN>(pb, pr, oh, ol, issue,
             [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dx : bd.d_o, D, m, rok, n % NP); },   // residual (modules.py:269) / the sum so far
             [&](int i) {
                 if (i == NP) {
@@ -809,31 +812,36 @@ static const char* wide_why(const cr_block_desc* d, int precision) {
 extern "C" int cr_wide_supported(const cr_block_desc* d, int precision) { return d && wide_why(d, precision) == nullptr; }
 
 // grid < 0: one workgroup per row block (forward); else the slab count
-template <int NCT, typename K, typename... A>
+template <int NCT, int MODE, typename K, typename... A>
 static int wide_launch(K kern, cr_devmask* done, int M, int grid, size_t lds, hipStream_t s, const char* who, A... args) {
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(kern), done);
     if (rc != CR_OK) return rc;
-    if (grid < 0) grid = cr_ceil_div(M, WdCfg<NCT>::ROWS);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WdCfg<NCT>::NT), lds, s, args...);
+    if (grid < 0) grid = cr_ceil_div(M, WdCfg<NCT, MODE>::ROWS);          // forward: one workgroup per row block
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WdCfg<NCT, MODE>::NT), lds, s, args...);
     return cr_check_launch(who);
 }
-
-#define WIDE_DISPATCH(KERN, GRID, BWD, WHO, ...)                                                                        \
-    do {                                                                                                                  \
-        static cr_devmask done[6];                                                                                        \
-        const bool sp = precision == CR_PREC_BF16X3;                                                                      \
-        switch (d->D / 16) {                                                                                              \
-            case 8:                                                                                                       \
-                return sp ? wide_launch<8>(KERN<8, true>, &done[0], d->M, GRID, WideLds<8, true>::TOTAL, s, WHO, __VA_ARGS__)      \
-                          : wide_launch<8>(KERN<8, false>, &done[1], d->M, GRID, WideLds<8, false>::TOTAL, s, WHO, __VA_ARGS__);  \
-            case 12:                                                                                                      \
-                return sp ? wide_launch<12>(KERN<12, true>, &done[2], d->M, GRID, WideLds<12, true>::TOTAL, s, WHO, __VA_ARGS__)   \
-                          : wide_launch<12>(KERN<12, false>, &done[3], d->M, GRID, WideLds<12, false>::TOTAL, s, WHO, __VA_ARGS__); \
-            default:                                                                                                      \
-                return sp ? wide_launch<16>(KERN<16, true>, &done[4], d->M, GRID, WideLds<16, true>::TOTAL, s, WHO, __VA_ARGS__)   \
-                          : wide_launch<16>(KERN<16, false>, &done[5], d->M, GRID, WideLds<16, false>::TOTAL, s, WHO, __VA_ARGS__); \
-        }                                                                                                                 \
-    } while (0)
+// forward: 128 rows per workgroup when that still gives every CU one (or at D = 128, where the registers allow two waves per
+// SIMD anyway), else 64
+template <int NCT, bool SPLIT>
+static int wide_launch_fwd(bool qkv, const cr_block_desc* d, hipStream_t s) {
+    static cr_devmask done[4];
+    const bool w8 = NCT <= 8 || cr_ceil_div(d->M, 128) >= 256;
+    const size_t lds = WideLds<NCT, SPLIT>::TOTAL;
+    if (qkv) {
+        if (w8) return wide_launch<NCT, 0>(k_wide_qkv_fwd<NCT, SPLIT, 0>, &done[0], d->M, -1, lds, s, "cr_wide_ln_qkv_fwd", *d);
+        return wide_launch<NCT, 2>(k_wide_qkv_fwd<NCT, SPLIT, 2>, &done[1], d->M, -1, lds, s, "cr_wide_ln_qkv_fwd", *d);
+    }
+    if (w8) return wide_launch<NCT, 0>(k_wide_ffn_fwd<NCT, SPLIT, 0>, &done[2], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d);
+    return wide_launch<NCT, 2>(k_wide_ffn_fwd<NCT, SPLIT, 2>, &done[3], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d);
+}
+static int wide_dispatch_fwd(bool qkv, const cr_block_desc* d, int precision, hipStream_t s) {
+    const bool sp = precision == CR_PREC_BF16X3;
+    switch (d->D / 16) {
+        case 8: return sp ? wide_launch_fwd<8, true>(qkv, d, s) : wide_launch_fwd<8, false>(qkv, d, s);
+        case 12: return sp ? wide_launch_fwd<12, true>(qkv, d, s) : wide_launch_fwd<12, false>(qkv, d, s);
+        default: return sp ? wide_launch_fwd<16, true>(qkv, d, s) : wide_launch_fwd<16, false>(qkv, d, s);
+    }
+}
 
 extern "C" int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream) {
     CR_REQUIRE(d, "cr_wide_ln_qkv_fwd: NULL description");
@@ -841,8 +849,7 @@ extern "C" int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* s
     if (why) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_qkv_fwd: %s", why);
     CR_REQUIRE(d->x && d->q_in && d->qkv && d->k_valid && d->q_valid && d->wqkv && d->bqkv && d->ln1_g && d->ln1_b,
                "cr_wide_ln_qkv_fwd: NULL pointer");
-    hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_qkv_fwd, -1, false, "cr_wide_ln_qkv_fwd", *d);
+    return wide_dispatch_fwd(true, d, precision, cr_stream(stream));
 }
 
 extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream) {
@@ -851,20 +858,19 @@ extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* s
     if (why) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_ffn_fwd: %s", why);
     CR_REQUIRE(d->o && d->f_in && d->hid && d->y && d->mask_ids && d->w1 && d->b1 && d->w2 && d->b2 && d->ln2_g && d->ln2_b,
                "cr_wide_ln_ffn_fwd: NULL pointer");
-    hipStream_t s = cr_stream(stream);
-    WIDE_DISPATCH(k_wide_ffn_fwd, -1, false, "cr_wide_ln_ffn_fwd", *d);
+    return wide_dispatch_fwd(false, d, precision, cr_stream(stream));
 }
 
 template <int NCT, bool SPLIT, bool WG>
 static int wide_launch_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, hipStream_t s) {
     static cr_devmask done = 0;
-    return wide_launch<NCT>(k_wide_ffn_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
+    return wide_launch<NCT, 1>(k_wide_ffn_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
                             WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_ffn_bwd", *bd, g2, g1);
 }
 template <int NCT, bool SPLIT, bool WG>
 static int wide_launch_qkv_bwd(const cr_block_bwd_desc* bd, hipStream_t s) {
     static cr_devmask done = 0;
-    return wide_launch<NCT>(k_wide_qkv_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
+    return wide_launch<NCT, 1>(k_wide_qkv_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
                             WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_qkv_bwd", *bd);
 }
 
