@@ -116,6 +116,18 @@ def algo_work(name, fnargs, eng):
         return 2.0 * M * D * 6 * D, None, "mfma"
     if name in ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln"):
         return 2.0 * M * D * 4 * D, None, "mfma"
+    # hidden sizes 128 / 192 / 256 (cr_wide.hip): the activations do not fit the caches at these sizes (M x D x 4 = 13 MB per
+    # tensor at config C4, ~20 tensors per block), so the row phases are priced against HBM: rows read + rows written
+    if name == "cr_wide_ln_qkv_fwd":
+        return 2.0 * M * D * 3 * D, 5.0 * M * D * 4, "hbm"        # x in; q_in, Q, K, V out
+    if name == "cr_wide_ln_ffn_fwd":
+        return 2.0 * M * D * 2 * D, 4.0 * M * D * 4, "hbm"        # o in; f_in, hid, y out
+    if name == "cr_wide_ln_ffn_bwd":
+        own = bool(fnargs[0]._obj.g_w1)
+        return 2.0 * M * D * (4 if own else 2) * D, (9.0 if own else 7.0) * M * D * 4, "hbm"   # dy, hid, o (+ f_in, g rows again) in; g2, g1, d_o out
+    if name == "cr_wide_ln_qkv_bwd":
+        own = bool(fnargs[0]._obj.g_wqkv)
+        return 2.0 * M * D * (6 if own else 3) * D, (11.0 if own else 6.0) * M * D * 4, "hbm"  # dQ dK dV d_o x (+ q_in, x, dQ dK dV again) in; dx out
     if name == "cr_stack_fwd":
         # per block: Q K V projections + causal attention (QK^T + PV, causal half) + the two feed-forward layers
         nb = fnargs[0]._obj.n_blocks
@@ -173,7 +185,9 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
               "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
-              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"]}
+              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"],
+              "cr_wide_ln_qkv_fwd": ["k_wide_qkv_fwd"], "cr_wide_ln_ffn_fwd": ["k_wide_ffn_fwd"], "cr_wide_ln_ffn_bwd": ["k_wide_ffn_bwd"],
+              "cr_wide_ln_qkv_bwd": ["k_wide_qkv_bwd"], "cr_gemm_rows": ["k_gemm_rows"], "cr_gemm_wgrad": ["k_gemm_wgrad"]}
 
 
 def pmc_lookup(abi_name, precision):
