@@ -244,6 +244,23 @@ struct WideLds {
     static constexpr size_t TOTAL_BWD_NOWG = PANEL_BYTES + SLOT_BYTES;
 };
 
+// Per-wave phase stamps (compiled only with -DWD_TS=1; tools/wide_ts.py): slot k of wave w of workgroup b, core clocks
+#ifdef WD_TS
+__device__ unsigned long long g_wd_ts[512 * 8 * 64];
+#define WTS(slot)                                                                                                   \
+    do {                                                                                                            \
+        if (ts_on && (threadIdx.x & 63) == 0 && blockIdx.x < 512 && (slot) < 64)                                    \
+            g_wd_ts[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (slot)] = clock64();                       \
+    } while (0)
+extern "C" int cr_wide_ts_read(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wd_ts), sizeof(g_wd_ts)) == hipSuccess ? 0 : -3;
+}
+#define WTS_KERNEL(id) const bool ts_on = (WD_TS == (id) + 1)
+#else
+#define WTS(slot) do { } while (0)
+#define WTS_KERNEL(id) const bool ts_on = false
+#endif
+
 // ---- the panel pipeline -------------------------------------------------------------------------------------
 // One iteration per panel, every global LOAD of the steady state at the top of an iteration and for a LATER iteration: the
 // weights of panel i + 2 (D = 128: two register sets; above that i + 1, one set) and the auxiliary rows (residual, gate,
@@ -262,7 +279,8 @@ struct WideLds {
 template <int NCT, bool SPLIT, int MODE, int NPAN, class Issue, class AuxLoad, class Boundary, class Epilogue>
 __device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT, MODE> (&pr)[NCT <= 8 ? 2 : 1], const bf8 (&oh)[NCT / 2],
                                                const bf8 (&ol)[NCT / 2], Issue issue, AuxLoad auxload, Boundary boundary,
-                                               Epilogue epilogue) {
+                                               Epilogue epilogue, const bool ts_on) {
+    (void)ts_on;
     typedef WideLds<NCT, SPLIT> LD;
     constexpr bool D2 = NCT <= 8, FWD = MODE != 1;
     f32x4 aux_n[4];
@@ -271,6 +289,7 @@ __device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT, MODE> 
     __syncthreads();
     _Pragma("clang loop unroll_count(NCT <= 8 ? NPAN : 1)")
     for (int i = 0; i < NPAN; ++i) {
+        WTS(8 + 4 * i);
         const bool stale = boundary(i);
         f32x4 aux[4];
 #pragma unroll
@@ -282,13 +301,20 @@ __device__ __forceinline__ void panel_pipeline(__bf16* pb, PanelRegs<NCT, MODE> 
         f32x4 acc[4];
         acc_zero(acc);
         panel_mma<NCT, SPLIT, FWD>(acc, pb + (i & 1) * LD::BUF, oh, ol);
+#ifdef WD_TS
+        asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));     // the products are done
+#endif
+        WTS(9 + 4 * i);
         epilogue(i, acc, aux);
+        WTS(10 + 4 * i);
         if (i + 1 < NPAN) {
             __bf16* dst = pb + ((i + 1) & 1) * LD::BUF;
             if constexpr (FWD) fpanel_put<NCT, SPLIT, MODE>(pr[D2 ? ((i + 1) & 1) : 0], dst); else bpanel_put<NCT, SPLIT>(pr[D2 ? ((i + 1) & 1) : 0], dst);
         }
+        WTS(11 + 4 * i);
         __syncthreads();
     }
+    WTS(8 + 4 * NPAN);
 }
 // n floats global -> LDS (biases), visible after the next barrier
 __device__ __forceinline__ void vec_to_lds(float* dst, const float* src, int n) {
@@ -311,12 +337,14 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 3 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
+    WTS_KERNEL(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [3 D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
     const int m = blockIdx.x * WdCfg<NCT, MODE>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
+    WTS(0);
     auto issue = [&](PanelRegs<NCT, MODE>& r, int n) { fpanel_issue<NCT, MODE>(r, d.wqkv, 3 * D, (n / NP) * D + 64 * (n % NP)); };
     PanelRegs<NCT, MODE> pr[D2 ? 2 : 1];
     issue(pr[0], 0);
@@ -328,6 +356,7 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
         wr_load<NCT>(x, d.x, m, rok);
         float mean, rs, sum;
         wr_stats<NCT>(x, mean, rs, sum);
+        WTS(1);
         float ys = 0.0f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -351,6 +380,7 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
         }
         wr_split<NCT, SPLIT>(x, oh, ol);
     }
+    WTS(2);
     panel_pipeline<NCT, SPLIT, MODE, NPAN>(pb, pr, oh, ol, issue,
         [&](f32x4 (&)[4], int) {},
         [&](int i) {
@@ -368,7 +398,7 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
             wr_store4(d.qkv + (size_t)part * d.M * D, D, m, rok, p, acc);
-        });
+        }, ts_on);
 }
 
 // =====================================================================================================
@@ -379,6 +409,7 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
+    WTS_KERNEL(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [2 D]: b1, b2
@@ -445,7 +476,7 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
                     acc[ct][r] = v;
                 }
             wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
-        });
+        }, ts_on);
 }
 
 // ---- column sums of the workgroup's rows into per-thread accumulators ---------------------------------------
@@ -598,6 +629,7 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
+    WTS_KERNEL(2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* slots = reinterpret_cast<float*>(smem_raw + (WG ? LD::TOTAL_BWD : LD::TOTAL_BWD_NOWG) - LD::SLOT_BYTES);
@@ -656,7 +688,7 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
                         acc[ct][r] = part ? v1 : v0;
                     }
                 wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);
-            });
+            }, ts_on);
         {
             f32x4 df[NCT], xh[NCT];
             wr_load<NCT>(df, bd.d_o, m, rok);             // own stores
@@ -710,6 +742,7 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_b
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
     const cr_block_desc& d = bd.f;
+    WTS_KERNEL(3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
     float* slots = reinterpret_cast<float*>(smem_raw + (WG ? LD::TOTAL_BWD : LD::TOTAL_BWD_NOWG) - LD::SLOT_BYTES);
@@ -763,7 +796,7 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_b
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
                 wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);
-            });
+            }, ts_on);
         if (wgrad) {
             // dWq = q_in^T dQ, dWk = x^T dK, dWv = x^T dV: column blocks of the [D, 3 D] gradient (+ bias gradients)
             __bf16* ia = pb;
