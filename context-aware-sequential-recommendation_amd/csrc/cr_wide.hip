@@ -518,22 +518,40 @@ __device__ __forceinline__ void colsum_fold(const float* slots, float (&t)[NUSE]
 // columns: accumulators acc[NCT].  The result is written -- or, from the workgroup's second row block on, added -- to the
 // workgroup's slab: the same lanes touch the same words, no synchronisation.
 template <int NCT, bool SPLIT>
-__device__ __forceinline__ void wg_row_to_image(__bf16* img, const f32x4 (&x)[NCT]) {
+__device__ __forceinline__ void wg_split_to_image(__bf16* img, const bf8 (&h)[NCT / 2], const bf8 (&l)[NCT / 2]) {
     typedef WideLds<NCT, SPLIT> LD;
     constexpr int SUB = WdCfg<NCT, 1>::ROWS * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int row = 16 * wave + li;
 #pragma unroll
     for (int c2 = 0; c2 < NCT / 2; ++c2) {
-        bf8 h, l;
-        wr_split2<SPLIT>(x[2 * c2], x[2 * c2 + 1], h, l);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int ct = 2 * c2 + e;
             const int o = (ct >> 2) * SUB + img_off<2>(row, 2 * (ct & 3) + (lg >> 1)) + 4 * (lg & 1);
-            *reinterpret_cast<bf4*>(img + o) = e ? __builtin_shufflevector(h, h, 4, 5, 6, 7) : __builtin_shufflevector(h, h, 0, 1, 2, 3);
-            if (SPLIT) *reinterpret_cast<bf4*>(img + LD::IMG_HALF + o) = e ? __builtin_shufflevector(l, l, 4, 5, 6, 7) : __builtin_shufflevector(l, l, 0, 1, 2, 3);
+            *reinterpret_cast<bf4*>(img + o) = e ? __builtin_shufflevector(h[c2], h[c2], 4, 5, 6, 7) : __builtin_shufflevector(h[c2], h[c2], 0, 1, 2, 3);
+            if (SPLIT) *reinterpret_cast<bf4*>(img + LD::IMG_HALF + o) = e ? __builtin_shufflevector(l[c2], l[c2], 4, 5, 6, 7) : __builtin_shufflevector(l[c2], l[c2], 0, 1, 2, 3);
         }
+    }
+}
+template <int NCT, bool SPLIT>
+__device__ __forceinline__ void wg_row_to_image(__bf16* img, const f32x4 (&x)[NCT]) {
+    bf8 h[NCT / 2], l[NCT / 2];
+    wr_split<NCT, SPLIT>(x, h, l);
+    wg_split_to_image<NCT, SPLIT>(img, h, l);
+}
+// the column sums of one panel's four tiles (columns 64 p ..) into vector `which` of the wave's slot
+template <int NCT>
+__device__ __forceinline__ void colsum_put4(float* slots, const f32x4 (&a)[4], int which, int p) {
+    constexpr int D = 16 * NCT, NV = WideLds<NCT, true>::NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    float* sg = slots + ((size_t)wave * NV + which) * D + 64 * p;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        f32x4 ga;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ga[r] = cr_row16_sum(a[ct][r]);
+        if (li == 0) *reinterpret_cast<float4*>(sg + 16 * ct + 4 * lg) = make_float4(ga[0], ga[1], ga[2], ga[3]);
     }
 }
 template <int NCT, bool SPLIT>
@@ -650,6 +668,13 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
         const int id = rok ? d.mask_ids[m] : 0;
         const uint32_t xrow = ((d.drop_ffn2.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
         bf8 oh[NKS], ol[NKS];                             // g2, then g1
+        // WG (D = 128: the panel loop is unrolled, every index below is static): g1 and df_in stay in registers and the g2 /
+        // g1 rows reach the weight-gradient products as LDS images written from registers -- none of them goes through
+        // memory (the first version stored g2, g1 and df_in and read them back: 218 MB per launch for 117 algorithmic)
+        bf8 nh[NKS], nl[NKS];                             // g1 as the next operand (WG)
+        f32x4 df[NCT];                                    // df_in (WG)
+        __bf16* ia = pb;                                  // the `a` image lies over the panel buffers, the `g` image behind them
+        __bf16* ig = pb + LD::IMG;
         {
             // g2 = dy * dropout(ffn2) * mask: gradient of the second dense layer's output
             f32x4 g[NCT];
@@ -662,16 +687,26 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
                     if (dc2.on) v *= drop_factor_x(dc2, xrow + (uint32_t)(16 * ct + r) * CR_PHI + dc2.key);
                     g[ct][r] = id ? v : 0.0f;
                 }
-            wr_store<NCT>(g2out, m, rok, g);
             wr_split<NCT, SPLIT>(g, oh, ol);
+            if constexpr (WG) {
+                wg_split_to_image<NCT, SPLIT>(ig, oh, ol);
+                colsum_put<NCT>(slots, g, 2);
+            } else {
+                wr_store<NCT>(g2out, m, rok, g);
+            }
         }
         panel_pipeline<NCT, SPLIT, 1, NPAN>(pb, pr, oh, ol, issue,
             [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dy : d.hid, D, m, rok, n % NP); },
             [&](int i) {
                 if (i == NP) {
-                    f32x4 g[NCT];
-                    wr_load<NCT>(g, g1out, m, rok);       // own stores
-                    wr_split<NCT, SPLIT>(g, oh, ol);
+                    if constexpr (WG) {
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks) { oh[ks] = nh[ks]; ol[ks] = nl[ks]; }
+                    } else {
+                        f32x4 g[NCT];
+                        wr_load<NCT>(g, g1out, m, rok);   // own stores
+                        wr_split<NCT, SPLIT>(g, oh, ol);
+                    }
                 }
                 return false;
             },
@@ -682,41 +717,55 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // part 0: g1 = (g2 W2^T) gated by the stored post-dropout ReLU output (modules.py:300-303)
-                        // part 1: df_in = (g1 W1^T + dy) * mask (residual branch of modules.py:313), parked in d_o
+                        // part 1: df_in = (g1 W1^T + dy) * mask (residual branch of modules.py:313)
                         const float v0 = aux[ct][r] > 0.0f ? acc[ct][r] * gate_scale : 0.0f;
                         const float v1 = id ? acc[ct][r] + aux[ct][r] : 0.0f;
                         acc[ct][r] = part ? v1 : v0;
                     }
-                wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);
+                if constexpr (WG) {
+                    if (part == 0) {
+                        wr_split2<SPLIT>(acc[0], acc[1], nh[2 * p], nl[2 * p]);
+                        wr_split2<SPLIT>(acc[2], acc[3], nh[2 * p + 1], nl[2 * p + 1]);
+                        colsum_put4<NCT>(slots, acc, 3, p);
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) df[4 * p + ct] = acc[ct];
+                    }
+                } else {
+                    wr_store4(part ? bd.d_o : g1out, D, m, rok, p, acc);      // (df_in parked in d_o)
+                }
             }, ts_on);
         {
-            f32x4 df[NCT], xh[NCT];
-            wr_load<NCT>(df, bd.d_o, m, rok);             // own stores
+            f32x4 xh[NCT];
+            if constexpr (!WG) wr_load<NCT>(df, bd.d_o, m, rok);           // own stores
             wr_load<NCT>(xh, d.o, m, rok);
             colsum_put<NCT>(slots, df, 1);
             wr_ln_bwd<NCT>(df, xh, d.ln2_g);
             wr_store<NCT>(bd.d_o, m, rok, df);
             colsum_put<NCT>(slots, xh, 0);
         }
-        if (wgrad) {
-            // dW2 = hid^T g2, dW1 = f_in^T g1 (+ the bias gradients: column sums of g2, g1), images over the panel buffers
-            // (every wave is past the pipeline's last barrier)
-            __bf16* ia = pb;
-            __bf16* ig = pb + LD::IMG;
+        if constexpr (WG) {
+            // dW2 = hid^T g2, dW1 = f_in^T g1 (the bias gradients, column sums of g2 and g1, are in the slots already);
+            // every wave is past the pipeline's last barrier: the panel buffers are free for the `a` image
             const bool first = blk == (int)blockIdx.x;
             const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-#pragma unroll 1
-            for (int w = 0; w < 2; ++w) {
+            {
                 f32x4 t[NCT];
-                wr_load<NCT>(t, w ? d.f_in : d.hid, m, rok);
+                wr_load<NCT>(t, d.hid, m, rok);
                 wg_row_to_image<NCT, SPLIT>(ia, t);
-                wr_load<NCT>(t, w ? g1out : g2out, m, rok);   // own stores
-                wg_row_to_image<NCT, SPLIT>(ig, t);
-                colsum_put<NCT>(slots, t, 2 + w);
-                __syncthreads();
-                wg_product<NCT, SPLIT>(ia, ig, (w ? bd.g_w1 : bd.g_w2) + so, D, first);
-                __syncthreads();
             }
+            __syncthreads();
+            wg_product<NCT, SPLIT>(ia, ig, bd.g_w2 + so, D, first);
+            __syncthreads();
+            wg_split_to_image<NCT, SPLIT>(ig, oh, ol);                     // g1: the second part's operand, still in registers
+            {
+                f32x4 t[NCT];
+                wr_load<NCT>(t, d.f_in, m, rok);
+                wg_row_to_image<NCT, SPLIT>(ia, t);
+            }
+            __syncthreads();
+            wg_product<NCT, SPLIT>(ia, ig, bd.g_w1 + so, D, first);
+            __syncthreads();
         }
         if (wgrad) colsum_fold<NCT, 4>(slots, tot);
         else {
@@ -760,19 +809,30 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_b
         issue(pr[0], 0);
         if constexpr (D2) issue(pr[1], 1);
         bf8 oh[NKS], ol[NKS];                             // dQ, dK, dV rows in turn
+        // WG (D = 128, unrolled panel loop): dq_in, then dx, accumulate in registers -- no parking in d_o, no read-modify-write
+        // of dx between the parts (that was 78 of the 247 MB a launch moved)
+        f32x4 dq[NCT];
+        __bf16* ia = pb;
+        __bf16* ig = pb + LD::IMG;
         {
             f32x4 g[NCT];
             wr_load<NCT>(g, bd.dqkv, m, rok);
             wr_split<NCT, SPLIT>(g, oh, ol);
+            if constexpr (WG) {                           // dQ's image for dWq, from the registers that hold it now
+                wg_split_to_image<NCT, SPLIT>(ig, oh, ol);
+                colsum_put<NCT>(slots, g, 2);
+            }
         }
-        // parts: Wq rows (dq_in = dQ Wq^T + d_o, parked in d_o), then LN1 backward -> dx; Wk rows (dx += dK Wk^T); Wv rows
+        // parts: Wq rows (dq_in = dQ Wq^T + d_o), then LN1 backward -> dx; Wk rows (dx += dK Wk^T); Wv rows (dx += dV Wv^T)
         panel_pipeline<NCT, SPLIT, 1, NPAN>(pb, pr, oh, ol, issue,
-            [&](f32x4 (&aux)[4], int n) { wr_load4(aux, n / NP ? bd.dx : bd.d_o, D, m, rok, n % NP); },   // residual (modules.py:269) / the sum so far
+            [&](f32x4 (&aux)[4], int n) {
+                if (!WG || n < NP) wr_load4(aux, n / NP ? bd.dx : bd.d_o, D, m, rok, n % NP);   // residual (modules.py:269) / the sum so far
+            },
             [&](int i) {
                 if (i == NP) {
-                    // LN1 backward of dq_in with respect to x starts dx (this lane re-reads its own stores in the panels below)
-                    f32x4 dq[NCT], xh[NCT];
-                    wr_load<NCT>(dq, bd.d_o, m, rok);     // own stores
+                    // LN1 backward of dq_in with respect to x starts dx
+                    f32x4 xh[NCT];
+                    if constexpr (!WG) wr_load<NCT>(dq, bd.d_o, m, rok);     // own stores
                     wr_load<NCT>(xh, d.x, m, rok);
                     colsum_put<NCT>(slots, dq, 1);
                     wr_ln_bwd<NCT>(dq, xh, d.ln1_g);
@@ -782,25 +842,29 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_b
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) dq[ct] += xh[ct];
                     }
-                    wr_store<NCT>(bd.dx, m, rok, dq);
+                    if constexpr (!WG) wr_store<NCT>(bd.dx, m, rok, dq);     // (this lane re-reads its own stores in the panels below)
                 }
                 if (i == NP || i == 2 * NP) {
                     f32x4 g[NCT];
                     wr_load<NCT>(g, bd.dqkv + (size_t)(i / NP) * MD, m, rok);      // dK / dV rows
                     wr_split<NCT, SPLIT>(g, oh, ol);
                 }
-                return i == NP;                           // dx was just written: the prefetched rows are stale
+                return !WG && i == NP;                    // dx was just written: the prefetched rows are stale
             },
             [&](int i, f32x4 (&acc)[4], const f32x4 (&old)[4]) {
                 const int part = i / NP, p = i % NP;
+                if constexpr (WG) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
-                wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);
+                    for (int ct = 0; ct < 4; ++ct) dq[4 * p + ct] = part ? dq[4 * p + ct] + acc[ct] : acc[ct] + old[ct];
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[ct] += old[ct];
+                    wr_store4(part ? bd.dx : bd.d_o, D, m, rok, p, acc);   // (dq_in parked in d_o)
+                }
             }, ts_on);
-        if (wgrad) {
+        if constexpr (WG) {
+            wr_store<NCT>(bd.dx, m, rok, dq);
             // dWq = q_in^T dQ, dWk = x^T dK, dWv = x^T dV: column blocks of the [D, 3 D] gradient (+ bias gradients)
-            __bf16* ia = pb;
-            __bf16* ig = pb + LD::IMG;
             const bool first = blk == (int)blockIdx.x;
             const size_t so = (size_t)blockIdx.x * bd.slab_stride;
 #pragma unroll 1
@@ -810,9 +874,11 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_qkv_bwd(cr_block_b
                     wr_load<NCT>(t, w ? d.x : d.q_in, m, rok);
                     wg_row_to_image<NCT, SPLIT>(ia, t);
                 }
-                wr_load<NCT>(t, bd.dqkv + (size_t)w * MD, m, rok);
-                wg_row_to_image<NCT, SPLIT>(ig, t);
-                colsum_put<NCT>(slots, t, 2 + w);
+                if (w > 0) {                              // (dQ's image was written in the prologue)
+                    wr_load<NCT>(t, bd.dqkv + (size_t)w * MD, m, rok);
+                    wg_row_to_image<NCT, SPLIT>(ig, t);
+                    colsum_put<NCT>(slots, t, 2 + w);
+                }
                 __syncthreads();
                 wg_product<NCT, SPLIT>(ia, ig, bd.g_wqkv + so + w * D, 3 * D, first);
                 __syncthreads();

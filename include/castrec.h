@@ -328,11 +328,13 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
 /* ---- the same four row phases for hidden sizes 128 / 192 / 256 (configs C4, C5) on the bf16 matrix pipe (cr_wide.hip):
  * one launch each where the unfused path runs cr_layernorm_* + cr_gemm_rows (+ cr_eltwise) chains -- modules.py:53-80
  * (normalize), 203-205 (Q/K/V dense layers), 280-318 (feedforward) and their gradients.  Same descriptions and buffers as
- * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: the weight gradients are NOT
- * formed here (cr_gemm_wgrad takes q_in/x/dqkv, hid/g2 and f_in/g1): the backward entries only write the dgamma / dbeta
- * slabs, and cr_wide_ln_ffn_bwd returns the two operands g2 = dy * dropout * mask and g1 = gated(g2 W2^T), dense [M, D];
- * attn_delta and dq_part are not taken; cr_wide_ln_qkv_bwd OVERWRITES d_o (with the gradient of q_in, dQ Wq^T + d_o: the row
- * of the chain that has to exist in memory between the projection panels and the LayerNorm backward). */
+ * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: attn_delta and dq_part are not
+ * taken.  Weight gradients: at D = 128 the backward entries form them themselves when the g_w* / g_b* pointers are given
+ * (slab per workgroup, as cr_block_*), and then nothing of the chain goes through memory (g2, g1 are not written).  With
+ * NULL weight-gradient pointers -- the only form at D = 192 / 256 -- they write only the dgamma / dbeta slabs,
+ * cr_wide_ln_ffn_bwd returns the two operands cr_gemm_wgrad needs, g2 = dy * dropout * mask and g1 = gated(g2 W2^T), dense
+ * [M, D], and cr_wide_ln_qkv_bwd OVERWRITES d_o (with the gradient of q_in, dQ Wq^T + d_o: the row of the chain that has to
+ * exist in memory between the projection panels and the LayerNorm backward). */
 int cr_wide_supported(const cr_block_desc* d, int precision);   /* 1 / 0 */
 int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream);
 int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream);
