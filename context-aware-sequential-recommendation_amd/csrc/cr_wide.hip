@@ -351,11 +351,13 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
     if constexpr (D2) issue(pr[1], 1);
     vec_to_lds(lbias, d.bqkv, 3 * D);
     bf8 oh[NKS], ol[NKS];                                 // the current operand: q_in for Q, x for K and V
+    bf8 xh[NKS], xl[NKS];                                 // D = 128: x's operand form, kept for the K and V parts (else x is re-read)
     {
         f32x4 x[NCT];
         wr_load<NCT>(x, d.x, m, rok);
         float mean, rs, sum;
         wr_stats<NCT>(x, mean, rs, sum);
+        if constexpr (D2) wr_split<NCT, SPLIT>(x, xh, xl);
         WTS(1);
         float ys = 0.0f;
 #pragma unroll
@@ -385,9 +387,14 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
         [&](f32x4 (&)[4], int) {},
         [&](int i) {
             if (i == NP) {                                // K and V take the un-normalised rows (modules.py:204-205)
-                f32x4 x[NCT];
-                wr_load<NCT>(x, d.x, m, rok);
-                wr_split<NCT, SPLIT>(x, oh, ol);
+                if constexpr (D2) {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) { oh[ks] = xh[ks]; ol[ks] = xl[ks]; }
+                } else {
+                    f32x4 x[NCT];
+                    wr_load<NCT>(x, d.x, m, rok);
+                    wr_split<NCT, SPLIT>(x, oh, ol);
+                }
             }
             return false;
         },
@@ -424,6 +431,8 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
     vec_to_lds(lbias, d.b1, D);
     vec_to_lds(lbias + D, d.b2, D);
     bf8 oh[NKS], ol[NKS];                                 // f_in, then hid
+    bf8 nh[NKS], nl[NKS];                                 // D = 128: hid as the next operand, built panel by panel (else re-read)
+    f32x4 fin[NCT];                                       // D = 128: the residual rows (else re-read per panel)
     {
         f32x4 x[NCT];
         wr_load<NCT>(x, d.o, m, rok);
@@ -441,18 +450,27 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
         }
         wr_store<NCT>(d.f_in, m, rok, x);
         wr_split<NCT, SPLIT>(x, oh, ol);
+        if constexpr (D2) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) fin[ct] = x[ct];
+        }
     }
     const int id = rok ? d.mask_ids[m] : 0;
     const uint32_t xrow = ((d.drop_ffn1.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI;
     panel_pipeline<NCT, SPLIT, MODE, NPAN>(pb, pr, oh, ol, issue,
         [&](f32x4 (&aux)[4], int n) {
-            if (n >= NP) wr_load4(aux, d.f_in, D, m, rok, n - NP);     // own stores (residual = LN2 output, modules.py:313)
+            if (!D2 && n >= NP) wr_load4(aux, d.f_in, D, m, rok, n - NP);     // own stores (residual = LN2 output, modules.py:313)
         },
         [&](int i) {
-            if (i == NP) {                                // the second layer's operand: the hidden rows this lane stored
-                f32x4 h[NCT];
-                wr_load<NCT>(h, d.hid, m, rok);
-                wr_split<NCT, SPLIT>(h, oh, ol);
+            if (i == NP) {                                // the second layer's operand: the hidden rows
+                if constexpr (D2) {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) { oh[ks] = nh[ks]; ol[ks] = nl[ks]; }
+                } else {
+                    f32x4 h[NCT];
+                    wr_load<NCT>(h, d.hid, m, rok);       // own stores
+                    wr_split<NCT, SPLIT>(h, oh, ol);
+                }
             }
             return false;
         },
@@ -472,9 +490,15 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
                     float v = acc[ct][r] + bias[ct][r];
                     if (!part) v = fmaxf(v, 0.0f);                                           // modules.py:300
                     if (dc.on) v *= drop_factor_x(dc, xrow + (uint32_t)(64 * p + 16 * ct + r) * CR_PHI + dc.key);
-                    if (part) v = id ? v + res[ct][r] : 0.0f;                                // modules.py:313, sasrec.py:83
+                    if (part) v = id ? v + (D2 ? fin[4 * p + ct][r] : res[ct][r]) : 0.0f;    // modules.py:313, sasrec.py:83
                     acc[ct][r] = v;
                 }
+            if constexpr (D2) {
+                if (part == 0) {
+                    wr_split2<SPLIT>(acc[0], acc[1], nh[2 * p], nl[2 * p]);
+                    wr_split2<SPLIT>(acc[2], acc[3], nh[2 * p + 1], nl[2 * p + 1]);
+                }
+            }
             wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
         }, ts_on);
 }
