@@ -666,7 +666,7 @@ __device__ __forceinline__ void wr_ln_bwd(f32x4 (&g)[NCT], f32x4 (&x)[NCT], cons
 // backward: feed-forward + LN2
 // =====================================================================================================
 template <int NCT, bool SPLIT, bool WG>
-__global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out) {
+__global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_bwd_desc bd, float* g2out, float* g1out, int heads) {
     constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
     constexpr bool D2 = NCT <= 8;
     typedef WideLds<NCT, SPLIT> LD;
@@ -767,6 +767,26 @@ __global__ __launch_bounds__((WdCfg<NCT, 1>::NT)) void k_wide_ffn_bwd(cr_block_b
             wr_ln_bwd<NCT>(df, xh, d.ln2_g);
             wr_store<NCT>(bd.d_o, m, rok, df);
             colsum_put<NCT>(slots, xh, 0);
+            if (heads > 0) {
+                // the softmax-backward row term of every head, delta[h][m] = sum over the head's columns of d_o * (o - q_in)
+                // (o - q_in is the head's A V, modules.py:262-269): with it cr_attn_bwd runs its two passes in ONE launch
+                const int tph = NCT / heads;              // column tiles per head (the host checks the head dim is 16 k)
+                float a = 0.0f;
+                int hcur = 0;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int lg4 = 4 * ((threadIdx.x & 63) >> 4);
+                    const size_t o = (size_t)(rok ? m : 0) * D + 16 * ct + lg4;
+                    const f4u ov = *reinterpret_cast<const f4u*>(d.o + o), qv = *reinterpret_cast<const f4u*>(d.q_in + o);
+                    a += df[ct][0] * (ov.x - qv.x) + df[ct][1] * (ov.y - qv.y) + df[ct][2] * (ov.z - qv.z) + df[ct][3] * (ov.w - qv.w);
+                    if ((ct + 1) % tph == 0) {            // wave-uniform
+                        const float sm = grp_sum(a);
+                        if (rok && lg4 == 0) bd.attn_delta[(size_t)hcur * d.M + m] = sm;
+                        a = 0.0f;
+                        ++hcur;
+                    }
+                }
+            }
         }
         if constexpr (WG) {
             // dW2 = hid^T g2, dW1 = f_in^T g1 (the bias gradients, column sums of g2 and g1, are in the slots already);
@@ -985,10 +1005,10 @@ extern "C" int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* s
 }
 
 template <int NCT, bool SPLIT, bool WG>
-static int wide_launch_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, hipStream_t s) {
+static int wide_launch_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, int heads, hipStream_t s) {
     static cr_devmask done = 0;
     return wide_launch<NCT, 1>(k_wide_ffn_bwd<NCT, SPLIT, WG>, &done, bd->f.M, bd->n_slabs,
-                            WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_ffn_bwd", *bd, g2, g1);
+                            WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_ffn_bwd", *bd, g2, g1, heads);
 }
 template <int NCT, bool SPLIT, bool WG>
 static int wide_launch_qkv_bwd(const cr_block_bwd_desc* bd, hipStream_t s) {
@@ -997,14 +1017,21 @@ static int wide_launch_qkv_bwd(const cr_block_bwd_desc* bd, hipStream_t s) {
                             WG ? WideLds<NCT, SPLIT>::TOTAL_BWD : WideLds<NCT, SPLIT>::TOTAL_BWD_NOWG, s, "cr_wide_ln_qkv_bwd", *bd);
 }
 
-extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, int precision, void* stream) {
+extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float* g1, int heads, int precision, void* stream) {
     CR_REQUIRE(bd, "cr_wide_ln_ffn_bwd: NULL description");
     const cr_block_desc* d = &bd->f;
     const char* why = wide_why(d, precision);
     if (why) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_ffn_bwd: %s", why);
-    CR_REQUIRE(bd->dy && bd->d_o && g2 && g1 && d->hid && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_wide_ln_ffn_bwd: NULL pointer");
+    CR_REQUIRE(bd->dy && bd->d_o && d->hid && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "cr_wide_ln_ffn_bwd: NULL pointer");
+    if (bd->attn_delta) {
+        CR_REQUIRE(heads > 0 && d->D % heads == 0 && (d->D / heads) % 16 == 0 && d->q_in,
+                   "cr_wide_ln_ffn_bwd: attn_delta needs heads whose width is a multiple of 16 columns (and q_in)");
+    } else {
+        heads = 0;
+    }
     CR_REQUIRE(bd->g_ln2_g && bd->g_ln2_b && bd->n_slabs > 0 && bd->slab_stride > 0, "cr_wide_ln_ffn_bwd: NULL gradient pointer / no slabs");
     const bool wg = bd->g_w1 || bd->g_w2 || bd->g_b1 || bd->g_b2;
+    CR_REQUIRE(wg || (g2 && g1), "cr_wide_ln_ffn_bwd: g2 / g1 are needed when the weight gradients are left to cr_gemm_wgrad");
     if (wg) {
         CR_REQUIRE(d->D == 128, "cr_wide_ln_ffn_bwd: weight gradients are formed at D = 128 only (pass NULL g_w1 g_b1 g_w2 g_b2 and use cr_gemm_wgrad)");
         CR_REQUIRE(bd->g_w1 && bd->g_w2 && bd->g_b1 && bd->g_b2 && d->f_in, "cr_wide_ln_ffn_bwd: all of g_w1 g_b1 g_w2 g_b2 (and f_in) or none");
@@ -1013,10 +1040,10 @@ extern "C" int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* bd, float* g2, float*
     const bool sp = precision == CR_PREC_BF16X3;
     switch (d->D / 16) {
         case 8:
-            if (wg) return sp ? wide_launch_ffn_bwd<8, true, true>(bd, g2, g1, s) : wide_launch_ffn_bwd<8, false, true>(bd, g2, g1, s);
-            return sp ? wide_launch_ffn_bwd<8, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<8, false, false>(bd, g2, g1, s);
-        case 12: return sp ? wide_launch_ffn_bwd<12, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<12, false, false>(bd, g2, g1, s);
-        default: return sp ? wide_launch_ffn_bwd<16, true, false>(bd, g2, g1, s) : wide_launch_ffn_bwd<16, false, false>(bd, g2, g1, s);
+            if (wg) return sp ? wide_launch_ffn_bwd<8, true, true>(bd, g2, g1, heads, s) : wide_launch_ffn_bwd<8, false, true>(bd, g2, g1, heads, s);
+            return sp ? wide_launch_ffn_bwd<8, true, false>(bd, g2, g1, heads, s) : wide_launch_ffn_bwd<8, false, false>(bd, g2, g1, heads, s);
+        case 12: return sp ? wide_launch_ffn_bwd<12, true, false>(bd, g2, g1, heads, s) : wide_launch_ffn_bwd<12, false, false>(bd, g2, g1, heads, s);
+        default: return sp ? wide_launch_ffn_bwd<16, true, false>(bd, g2, g1, heads, s) : wide_launch_ffn_bwd<16, false, false>(bd, g2, g1, heads, s);
     }
 }
 

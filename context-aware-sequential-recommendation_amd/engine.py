@@ -537,13 +537,23 @@ class Engine:
                 own_w = D == 128 and os.environ.get("CASTREC_WIDE_NO_WGRAD") != "1"
                 if not own_w:
                     bbd.g_w1 = bbd.g_b1 = bbd.g_w2 = bbd.g_b2 = bbd.g_wqkv = bbd.g_bqkv = None
-                self._call(lst, "cr_wide_ln_ffn_bwd", C.byref(bbd), g2.data_ptr(), g1.data_ptr(), prec)
+                # The one-launch attention backward (both passes side by side) needs the per-head row term delta up front;
+                # the FFN backward can emit it.  Off by default: at these shapes B * H (sample, head) pairs fill the chip in
+                # either form (C4: 85 us as two launches, 85 us as one) and the FFN backward reads o and q_in once more.
+                dh = D // H
+                fuse_attn = (T <= 256 and 8 <= dh <= 64 and dh % 16 == 0 and os.environ.get("CASTREC_WIDE_DELTA") == "1")
+                if fuse_attn:
+                    delta = self.vec("attn_delta_heads", H * M)
+                    bbd.attn_delta = delta.data_ptr()
+                self._call(lst, "cr_wide_ln_ffn_bwd", C.byref(bbd), g2.data_ptr(), g1.data_ptr(), H if fuse_attn else 0, prec)
                 if not own_w:
                     w = (L.WgradDesc * 2)(L.WgradDesc(hid.data_ptr(), D, g2.data_ptr(), D, G(pfx + "w2"), D, G(pfx + "b2"), M, D, D),
                                           L.WgradDesc(f_in.data_ptr(), D, g1.data_ptr(), D, G(pfx + "w1"), D, G(pfx + "b1"), M, D, D))
                     self._call(lst, "cr_gemm_wgrad", w, 2, S, self.n_slabs)
                 dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + MD4, dqkv.data_ptr() + 2 * MD4
                 abd = L.AttnBwdDesc(L.AttnDesc.from_buffer_copy(ad), do.data_ptr(), D, dq, dk, dv, D, stats.data_ptr())
+                if fuse_attn:
+                    abd.delta = delta.data_ptr()
                 self._call(lst, "cr_attn_bwd", C.byref(abd))
                 if not own_w:
                     gw, gb = G(pfx + "wqkv"), G(pfx + "bqkv")

@@ -158,7 +158,7 @@ _sig("cr_block_ln_qkv_bwd_scatter", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(Emb
 _sig("cr_wide_supported", c_i, [C.POINTER(BlockDesc), c_i])
 _sig("cr_wide_ln_qkv_fwd", c_i, [C.POINTER(BlockDesc), c_i, c_p])
 _sig("cr_wide_ln_ffn_fwd", c_i, [C.POINTER(BlockDesc), c_i, c_p])
-_sig("cr_wide_ln_ffn_bwd", c_i, [C.POINTER(BlockBwdDesc), c_p, c_p, c_i, c_p])
+_sig("cr_wide_ln_ffn_bwd", c_i, [C.POINTER(BlockBwdDesc), c_p, c_p, c_i, c_i, c_p])
 _sig("cr_wide_ln_qkv_bwd", c_i, [C.POINTER(BlockBwdDesc), c_i, c_p])
 _sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
 _sig("cr_head_fwd_bwd_ln", c_i, [C.POINTER(HeadDesc), C.POINTER(LnBwdDesc), c_p])

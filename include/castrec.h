@@ -328,8 +328,8 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
 /* ---- the same four row phases for hidden sizes 128 / 192 / 256 (configs C4, C5) on the bf16 matrix pipe (cr_wide.hip):
  * one launch each where the unfused path runs cr_layernorm_* + cr_gemm_rows (+ cr_eltwise) chains -- modules.py:53-80
  * (normalize), 203-205 (Q/K/V dense layers), 280-318 (feedforward) and their gradients.  Same descriptions and buffers as
- * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: attn_delta and dq_part are not
- * taken.  Weight gradients: at D = 128 the backward entries form them themselves when the g_w* / g_b* pointers are given
+ * the cr_block_* entry points; precision: CR_PREC_BF16X3 or CR_PREC_BF16.  Differences: dq_part is not taken, attn_delta is
+ * per head (below).  Weight gradients: at D = 128 the backward entries form them themselves when the g_w* / g_b* pointers are given
  * (slab per workgroup, as cr_block_*), and then nothing of the chain goes through memory (g2, g1 are not written).  With
  * NULL weight-gradient pointers -- the only form at D = 192 / 256 -- they write only the dgamma / dbeta slabs,
  * cr_wide_ln_ffn_bwd returns the two operands cr_gemm_wgrad needs, g2 = dy * dropout * mask and g1 = gated(g2 W2^T), dense
@@ -338,7 +338,9 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
 int cr_wide_supported(const cr_block_desc* d, int precision);   /* 1 / 0 */
 int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream);
 int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream);
-int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* d, float* g2, float* g1, int precision, void* stream);
+/* heads: with d->attn_delta != NULL, [heads, M] floats: delta[h][m] = sum over head h's columns of d_o * (o - q_in), the row term
+ * cr_attn_bwd's bf16 kernels take (cr_attn_bwd_desc.delta) to run both passes in one launch; head width a multiple of 16 */
+int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* d, float* g2, float* g1, int heads, int precision, void* stream);
 int cr_wide_ln_qkv_bwd(const cr_block_bwd_desc* d, int precision, void* stream);
 
 /* cr_block_ln_qkv_bwd of a stack's FIRST block whose input x was composed by an embedding gather: instead of

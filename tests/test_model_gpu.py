@@ -403,10 +403,11 @@ def test_wide_row_kernels(E, model, D, H, T, L, B, prec):
     _other_shapes(E, model, D, H, T, L, B, prec=prec)
 
 
-@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD"])
+@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_DELTA"])
 def test_wide_alternative_paths_stay_green(E, env, monkeypatch):
     """the unfused chain (cr_layernorm_* / cr_gemm_rows / cr_eltwise) and the wide kernels with cr_gemm_wgrad forming the
-    weight gradients: what the engine falls back to outside D = 128 / 192 / 256"""
+    weight gradients: what the engine falls back to outside D = 128 / 192 / 256; the per-head delta from the FFN backward
+    with the attention backward as one launch"""
     monkeypatch.setenv(env, "1")
     _other_shapes(E, "sasrec", 128, 4, 40, 2, prec="bf16x3")
 
