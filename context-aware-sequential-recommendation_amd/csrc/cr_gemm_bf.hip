@@ -107,12 +107,23 @@ __global__ __launch_bounds__(256) void k_gemm_rows_bf(GemmBatchBf batch) {
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the next K chunk's loads are requested before this chunk's products (stage -> barrier -> multiply in series exposed one
+    // memory round trip per chunk)
+    TileRegs ta, tb;
+    stage_issue(ta, d.A, d.lda, m0, d.M, 0, d.K);
+    if (!d.trans_b) stage_issue(tb, d.B, d.ldb, 0, d.K, n0, d.N);
+    else stage_issue(tb, d.B, d.ldb, n0, d.N, 0, d.K);
     for (int k0 = 0; k0 < d.K; k0 += 64) {
         if (k0) __syncthreads();
-        stage_tile<SPLIT>(Ah, Al, d.A, d.lda, m0, d.M, k0, d.K);
-        if (!d.trans_b) stage_tile<SPLIT>(Bh, Bl, d.B, d.ldb, k0, d.K, n0, d.N);      // image [k][n]
-        else stage_tile<SPLIT>(Bh, Bl, d.B, d.ldb, n0, d.N, k0, d.K);                  // image [n][k]
+        stage_put<SPLIT>(ta, Ah, Al, d.A, d.lda, m0, d.M, k0, d.K);
+        if (!d.trans_b) stage_put<SPLIT>(tb, Bh, Bl, d.B, d.ldb, k0, d.K, n0, d.N);   // image [k][n]
+        else stage_put<SPLIT>(tb, Bh, Bl, d.B, d.ldb, n0, d.N, k0, d.K);               // image [n][k]
         __syncthreads();
+        if (k0 + 64 < d.K) {
+            stage_issue(ta, d.A, d.lda, m0, d.M, k0 + 64, d.K);
+            if (!d.trans_b) stage_issue(tb, d.B, d.ldb, k0 + 64, d.K, n0, d.N);
+            else stage_issue(tb, d.B, d.ldb, n0, d.N, k0 + 64, d.K);
+        }
         const int ksteps = (min(64, d.K - k0) + 31) / 32;
         for (int ks = 0; ks < ksteps; ++ks) {
             bf8 ah, al, bh[4], bl[4];
