@@ -273,6 +273,37 @@ def cpu_baseline(model, maxlen, args, batches, usernum, itemnum, budget_s=25.0, 
                        "logical CPUs, %s" % (n, B, maxlen, model, torch.get_num_threads(), os.cpu_count(), cpu_info()))
 
 
+OTHER_CONFIGS = [
+    ("C1 configs[0]: ml-1m SASRec maxlen=50 hidden_units=50 num_blocks=2 num_heads=1", ["--model", "sasrec", "--maxlen", "50"]),
+    ("C3 configs[2] shape: Beauty-sized vocabulary (57 289 items, Zipf 1.1), SASRec maxlen=50 hidden_units=64 num_heads=2",
+     ["--model", "sasrec", "--maxlen", "50", "--hidden_units", "64", "--num_heads", "2", "--dropout_rate", "0.5", "--corpus", "beauty"]),
+    ("C4 configs[3] shape on one GPU: SASRec maxlen=200 hidden_units=128 num_blocks=4 num_heads=4, ml-1m-sized table",
+     ["--model", "sasrec", "--maxlen", "200", "--hidden_units", "128", "--num_heads", "4", "--num_blocks", "4"]),
+    ("C5 configs[4] shape on one GPU at batch 32: SASRec maxlen=512 hidden_units=256 num_blocks=2 num_heads=4, ml-1m-sized table "
+     "(the 10 M-item table: --corpus c5 [--lazy_adam], profiles/r02d_c5_*_bench.json)",
+     ["--model", "sasrec", "--maxlen", "512", "--hidden_units", "256", "--num_heads", "4", "--num_blocks", "2", "--batch_size", "32"]),
+]
+
+
+def other_configs(steps=100, warmup=10):
+    """The other BASELINE.json shapes through this same program, one short child run each (not the headline line: sequences/s,
+    ms per step and launches per step of fwd + bwd + dense TF-Adam at batch 128 per GPU unless the label says otherwise)."""
+    import subprocess
+    res = []
+    for label, flags in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-gather", "--no-extra-precisions", "--no-other-configs",
+               "--steps", str(steps), "--warmup", str(warmup)] + flags
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            res.append(dict(config=label, value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"],
+                            launches_per_step=d["config"]["launches_per_step"], attn_precision=d["config"]["attn_precision"],
+                            dominant=dict(kernel=d["roofline"]["kernel"], bound=d["roofline"]["bound"], frac=d["roofline"]["frac"])))
+        except Exception as e:                                # a failed side run must not cost the headline line
+            res.append(dict(config=label, error=repr(e)[:200]))
+    return res
+
+
 def gather_block(reps=20):
     """HBM roofline of the item-embedding gather at config C5's table (10 M x 256 fp32 = 10.24 GB, far beyond the 256 MiB
     Infinity Cache), uniformly random rows.  (a) cr_embed_fwd on one C5 step (65 536 rows: table row x sqrt(D) + positional
@@ -341,6 +372,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the C5-table gather block (allocates 10.24 GB)")
     ap.add_argument("--no-extra-precisions", action="store_true", help="skip the short runs in the other attention precisions")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE.json shapes (child processes)")
     ap.add_argument("--corpus", default="ml-1m", choices=["ml-1m", "beauty", "books", "c5"],
                     help="synthetic corpus preset (castrec_amd/synth.py); the headline line is ml-1m")
     ap.add_argument("--lazy_adam", action="store_true", help="row-sparse Adam on the item table (a deviation, DESIGN.md section 8)")
@@ -523,6 +555,8 @@ def main():
                 del e2
                 torch.cuda.empty_cache()
             out["other_precisions"] = others
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs()
         if world == 1 and not args.no_gather:
             out["gather"] = gather_block()
         if world == 1 and not args.no_cpu_baseline:

@@ -233,6 +233,7 @@ class Engine:
         # to fill the chip (tiles x slabs workgroups).  cr_adam_step learns per 256-parameter block how many slabs are in use.
         self.n_wslabs = n_slabs if (self.fused or self.D <= 128) else min(n_slabs, int(os.environ.get("CASTREC_WSLABS", "32")))
         self._wgrad_ranges = []
+        self.slab_counts = None
         f32 = dict(dtype=torch.float32, device=self.dev)
         if share is not None:
             self.P = share.P

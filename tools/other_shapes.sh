@@ -1,6 +1,6 @@
 #!/bin/bash
 # The other BASELINE shapes through the same bench.py (not the headline line): one JSON value per shape.
-run() { out=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-gather --no-extra-precisions "$@" --steps 200 --warmup 20 2>/dev/null | tail -n 1); echo "$* -> $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "seq/s", d["ms_per_step"], "ms", d["config"]["launches_per_step"], "launches")')"; }
+run() { out=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-gather --no-extra-precisions --no-other-configs "$@" --steps 200 --warmup 20 2>/dev/null | tail -n 1); echo "$* -> $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "seq/s", d["ms_per_step"], "ms", d["config"]["launches_per_step"], "launches")')"; }
 run --model sasrec --maxlen 50
 run --model sasrec --maxlen 200
 run --model sasrec --maxlen 50 --hidden_units 64 --num_heads 2 --dropout_rate 0.5
