@@ -2,10 +2,10 @@
 // the same four steps as cr_block.hip (D <= 64), modules.py:53-80,203-205,280-318 and their backward,
 //   cr_wide_ln_qkv_fwd : q_in = LN1(x) (+ key / query masks); Q = q_in Wq + bq; K = x Wk + bk; V = x Wv + bv
 //   cr_wide_ln_ffn_fwd : f_in = LN2(o); hid = drop(relu(f_in W1 + b1)); y = (drop(hid W2 + b2) + f_in) * mask
-//   cr_wide_ln_ffn_bwd : dy -> g2, g1 (the operands of the weight-gradient products), d_o, slabs of dgamma2 dbeta2
-//   cr_wide_ln_qkv_bwd : (dQ|dK|dV, d_o) -> dx (= or +=), slabs of dgamma1 dbeta1
-// each ONE launch where the unfused path runs 3 to 6 (cr_layernorm_*, cr_gemm_rows, cr_eltwise).  The weight gradients
-// stay with cr_gemm_wgrad (contraction over rows).
+//   cr_wide_ln_ffn_bwd : dy -> d_o, slabs of dgamma2 dbeta2 (+ dW2 db2 dW1 db1 at D = 128; else g2, g1 for cr_gemm_wgrad)
+//   cr_wide_ln_qkv_bwd : (dQ|dK|dV, d_o) -> dx (= or +=), slabs of dgamma1 dbeta1 (+ dWqkv dbqkv at D = 128)
+// each ONE launch where the unfused path runs 3 to 6 (cr_layernorm_*, cr_gemm_rows, cr_eltwise, cr_gemm_wgrad).
+// DESIGN.md section 4 has the measurements behind the choices (timing variants, per-wave timeline, HBM counters).
 //
 // Structure.  A workgroup of 8 waves owns 128 rows, a wave 16 of them, in register layout R (cr_rlayout.hpp): lane
 // (li, lg) holds row li, columns 16 ct + 4 lg + r -- the D-operand layout of v_mfma_f32_16x16x32_bf16 for the
@@ -22,11 +22,14 @@
 // Both images use the conflict-free swizzle of cr_bf16.hpp on [rows][64] pieces.
 // Column sums (dgamma, dbeta) are DPP row reductions per wave, folded over the waves through LDS slots in a fixed order
 // and written as one slab per workgroup (no atomics, bitwise reproducible), as cr_layernorm_bwd does.
+// Weight gradients (D = 128, where the panel loop is unrolled and a [D, D] slab per 128 rows costs what a row block costs):
+// the workgroup's rows of `a` and `g` become [128][128] bf16 images in LDS -- `g` from the registers that hold it, behind the
+// panel buffers; `a` over them once the panels are done -- both MFMA operands are transposed reads with k = row, and wave w
+// owns row tile w of dW.  At D = 128 nothing of a chain goes through memory between its parts (static register indices); above,
+// a part's result is stored and the next part's operand re-read by the lane that stored it.
 #include "cr_attn_common.hpp"
 #include "cr_bf16.hpp"
 
-// Threads per workgroup: 8 waves (128 rows) at D = 128; 4 waves (64 rows) above, where a row's operands and partial results
-// need more than the 256 registers a wave gets at two waves per SIMD (one wave per SIMD may use all 512).
 // Threads per workgroup.  Forward kernels: 8 waves (128 rows) at every size.  Backward kernels: 8 waves at D = 128, 4 waves
 // (64 rows) above, where a row's operands and partial results need more than the 256 registers a wave gets at two waves per
 // SIMD (one wave per SIMD may use all 512).  More rows per workgroup = fewer passes of the weights through LDS: at D = 256
