@@ -22,14 +22,15 @@ def chain_corpus(n_users=200, n_items=60, length=30, seed=0):
     return synth.from_dict(d, n_users, n_items)
 
 
-def test_sasrec_learns_chain_and_evaluate_reports_high_hr():
+@pytest.mark.parametrize("D", [32, 128])          # the register-layout kernels / the wide row kernels (cr_wide.hip, eval: unfused chain sizes too)
+def test_sasrec_learns_chain_and_evaluate_reports_high_hr(D):
     import castrec_amd  # noqa: F401
     from castrec_amd.models import SASRec
     from castrec_amd.sampler import WarpSampler
     from castrec_amd import util as U
     c = chain_corpus()
     dataset = U.partition(c.to_dict(), c.usernum, c.itemnum)
-    args = types.SimpleNamespace(maxlen=20, hidden_units=32, num_blocks=2, num_heads=2, dropout_rate=0.1, l2_emb=0.0, lr=3e-3,
+    args = types.SimpleNamespace(maxlen=20, hidden_units=D, num_blocks=2, num_heads=2, dropout_rate=0.1, l2_emb=0.0, lr=3e-3 if D == 32 else 1e-3,
                                  max_bins=20, num_context_blocks=1, seed=5, bin_in_hours=24, log_scale=False,
                                  test_model=None, test_seq_len=None)
     np.random.seed(5)
