@@ -238,7 +238,7 @@ struct WideLds {
     static constexpr size_t PANEL_BYTES = 2 * (size_t)BUF * 2;        // double buffered
     static constexpr int NV = 5;                                       // column-sum vectors of a backward kernel (dgamma, dbeta, 3 bias gradients)
     static constexpr size_t SLOT_BYTES = (size_t)WdCfg<NCT, 1>::NW * NV * 16 * NCT * 4;  // [waves][NV][D] floats (backward kernels)
-    static constexpr size_t TOTAL = PANEL_BYTES + SLOT_BYTES + 3 * 16 * NCT * 4;      // + [3 D] floats of biases (forward kernels)
+    static constexpr size_t TOTAL = PANEL_BYTES + SLOT_BYTES + 5 * 16 * NCT * 4;      // + [5 D] floats of biases (forward kernels)
     // weight-gradient phase of the backward kernels: two [ROWS][D] images (a, g), each hi (+ lo), over the panel buffers
     static constexpr int IMG_HALF = WdCfg<NCT, 1>::ROWS * 16 * NCT;       // bf16 elements of one half of one image
     static constexpr int IMG = (SPLIT ? 2 : 1) * IMG_HALF;
@@ -412,30 +412,40 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_qkv_fwd(cr_bloc
 }
 
 // =====================================================================================================
-// forward: LN2 + feed-forward
+// forward: LN2 + feed-forward (+ a tail on the output rows while they are in registers, D = 128:
+//          TAIL 1 = the NEXT block's LN1 + Q / K / V projections, TAIL 2 = the stack's final LayerNorm)
 // =====================================================================================================
-template <int NCT, bool SPLIT, int MODE>
-__global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_block_desc d) {
-    constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = 2 * NP;
+struct WideTail {
+    cr_block_desc next;                                   // TAIL 1
+    const float* lnf_g; const float* lnf_b; float* out; int ld_out, col_out;   // TAIL 2
+};
+template <int NCT, bool SPLIT, int MODE, int TAIL>
+__global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_block_desc d, WideTail tl) {
+    constexpr int D = 16 * NCT, NKS = NCT / 2, NP = NCT / 4, NPAN = (TAIL == 1 ? 5 : 2) * NP;
     constexpr bool D2 = NCT <= 8;
+    static_assert(TAIL == 0 || D2, "the tails keep the output rows in registers (unrolled panel loop)");
     typedef WideLds<NCT, SPLIT> LD;
     WTS_KERNEL(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* pb = reinterpret_cast<__bf16*>(smem_raw);
-    float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [2 D]: b1, b2
+    float* lbias = reinterpret_cast<float*>(smem_raw + LD::PANEL_BYTES + LD::SLOT_BYTES);       // [5 D]: b1, b2, the next block's bqkv
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int m = blockIdx.x * WdCfg<NCT, MODE>::ROWS + 16 * wave + li;
     const bool rok = m < d.M;
     const DropCtx dc1 = drop_ctx(d.drop_ffn1), dc2 = drop_ctx(d.drop_ffn2);
-    auto issue = [&](PanelRegs<NCT, MODE>& r, int n) { fpanel_issue<NCT, MODE>(r, n / NP ? d.w2 : d.w1, D, 64 * (n % NP)); };
+    auto issue = [&](PanelRegs<NCT, MODE>& r, int n) {
+        if (TAIL == 1 && n >= 2 * NP) fpanel_issue<NCT, MODE>(r, tl.next.wqkv, 3 * D, ((n - 2 * NP) / NP) * D + 64 * (n % NP));
+        else fpanel_issue<NCT, MODE>(r, n / NP ? d.w2 : d.w1, D, 64 * (n % NP));
+    };
     PanelRegs<NCT, MODE> pr[D2 ? 2 : 1];
     issue(pr[0], 0);
     if constexpr (D2) issue(pr[1], 1);
     vec_to_lds(lbias, d.b1, D);
     vec_to_lds(lbias + D, d.b2, D);
-    bf8 oh[NKS], ol[NKS];                                 // f_in, then hid
+    if (TAIL == 1) vec_to_lds(lbias + 2 * D, tl.next.bqkv, 3 * D);
+    bf8 oh[NKS], ol[NKS];                                 // f_in, then hid (then the next block's q_in, x)
     bf8 nh[NKS], nl[NKS];                                 // D = 128: hid as the next operand, built panel by panel (else re-read)
-    f32x4 fin[NCT];                                       // D = 128: the residual rows (else re-read per panel)
+    f32x4 fin[NCT];                                       // D = 128: the residual rows (else re-read per panel); then the output rows y
     {
         f32x4 x[NCT];
         wr_load<NCT>(x, d.o, m, rok);
@@ -475,12 +485,52 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
                     wr_split<NCT, SPLIT>(h, oh, ol);
                 }
             }
+            if constexpr (TAIL == 1) {
+                if (i == 2 * NP) {
+                    // the next block's first phase on y (in `fin` now): x' = y; q_in' = LN1'(y); key / query masks; operand q_in'
+                    wr_split<NCT, SPLIT>(fin, nh, nl);    // y's operand form, for the K and V parts
+                    float mean, rs, sum;
+                    wr_stats<NCT>(fin, mean, rs, sum);
+                    float ys = 0.0f;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        f32x4 g[4], b[4];
+                        wr_vec4(g, tl.next.ln1_g, p);
+                        wr_vec4(b, tl.next.ln1_b, p);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float y = fmaf(g[ct][r], (fin[4 * p + ct][r] - mean) * rs, b[ct][r]);
+                                fin[4 * p + ct][r] = y;
+                                ys += y;
+                            }
+                    }
+                    ys = grp_sum(ys);
+                    wr_store<NCT>(tl.next.q_in, m, rok, fin);
+                    if (rok && lg == 0) {                 // modules.py:222 (keys = x), 248-249 (queries = LN1(x))
+                        tl.next.k_valid[m] = (sum != 0.0f) ? 1.0f : 0.0f;
+                        tl.next.q_valid[m] = (ys != 0.0f) ? 1.0f : 0.0f;
+                    }
+                    wr_split<NCT, SPLIT>(fin, oh, ol);
+                }
+                if (i == 3 * NP) {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) { oh[ks] = nh[ks]; ol[ks] = nl[ks]; }
+                }
+            }
             return false;
         },
         [&](int i, f32x4 (&acc)[4], const f32x4 (&res)[4]) {
             const int part = i / NP, p = i % NP;
             f32x4 bias[4];
             lds_vec4(bias, lbias + part * D, p);
+            if (TAIL == 1 && part >= 2) {                 // the next block's Q / K / V
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] += bias[ct];
+                wr_store4(tl.next.qkv + (size_t)(part - 2) * d.M * D, D, m, rok, p, acc);
+                return;
+            }
             DropCtx dc;                                   // (field by field: a selected struct reference went through scratch)
             dc.on = dc1.on;
             dc.key = part ? dc2.key : dc1.key;
@@ -500,10 +550,34 @@ __global__ __launch_bounds__((WdCfg<NCT, MODE>::NT)) void k_wide_ffn_fwd(cr_bloc
                 if (part == 0) {
                     wr_split2<SPLIT>(acc[0], acc[1], nh[2 * p], nl[2 * p]);
                     wr_split2<SPLIT>(acc[2], acc[3], nh[2 * p + 1], nl[2 * p + 1]);
+                } else if (TAIL != 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) fin[4 * p + ct] = acc[ct];                // y takes the residual's registers, panel by panel
                 }
             }
             wr_store4(part ? d.y : d.hid, D, m, rok, p, acc);
         }, ts_on);
+    if constexpr (TAIL == 2) {
+        // the stack's final LayerNorm (sasrec.py:85) on y, into a column block of `out`
+        float mean, rs, sum;
+        wr_stats<NCT>(fin, mean, rs, sum);
+        float* q = tl.out + (size_t)(rok ? m : 0) * tl.ld_out + tl.col_out + 4 * lg;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            f32x4 g[4], b[4];
+            wr_vec4(g, tl.lnf_g, p);
+            wr_vec4(b, tl.lnf_b, p);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                f4u v;
+                v.x = fmaf(g[ct][0], (fin[4 * p + ct][0] - mean) * rs, b[ct][0]);
+                v.y = fmaf(g[ct][1], (fin[4 * p + ct][1] - mean) * rs, b[ct][1]);
+                v.z = fmaf(g[ct][2], (fin[4 * p + ct][2] - mean) * rs, b[ct][2]);
+                v.w = fmaf(g[ct][3], (fin[4 * p + ct][3] - mean) * rs, b[ct][3]);
+                if (rok) *reinterpret_cast<f4u*>(q + 64 * p + 16 * ct) = v;
+            }
+        }
+    }
 }
 
 // ---- column sums of the workgroup's rows into per-thread accumulators ---------------------------------------
@@ -977,8 +1051,9 @@ static int wide_launch_fwd(bool qkv, const cr_block_desc* d, hipStream_t s) {
         if (w8) return wide_launch<NCT, 0>(k_wide_qkv_fwd<NCT, SPLIT, 0>, &done[0], d->M, -1, lds, s, "cr_wide_ln_qkv_fwd", *d);
         return wide_launch<NCT, 2>(k_wide_qkv_fwd<NCT, SPLIT, 2>, &done[1], d->M, -1, lds, s, "cr_wide_ln_qkv_fwd", *d);
     }
-    if (w8) return wide_launch<NCT, 0>(k_wide_ffn_fwd<NCT, SPLIT, 0>, &done[2], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d);
-    return wide_launch<NCT, 2>(k_wide_ffn_fwd<NCT, SPLIT, 2>, &done[3], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d);
+    WideTail none = {};
+    if (w8) return wide_launch<NCT, 0>(k_wide_ffn_fwd<NCT, SPLIT, 0, 0>, &done[2], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d, none);
+    return wide_launch<NCT, 2>(k_wide_ffn_fwd<NCT, SPLIT, 2, 0>, &done[3], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd", *d, none);
 }
 static int wide_dispatch_fwd(bool qkv, const cr_block_desc* d, int precision, hipStream_t s) {
     const bool sp = precision == CR_PREC_BF16X3;
@@ -1072,4 +1147,34 @@ extern "C" int cr_wide_ln_qkv_bwd(const cr_block_bwd_desc* bd, int precision, vo
         case 12: return sp ? wide_launch_qkv_bwd<12, true, false>(bd, s) : wide_launch_qkv_bwd<12, false, false>(bd, s);
         default: return sp ? wide_launch_qkv_bwd<16, true, false>(bd, s) : wide_launch_qkv_bwd<16, false, false>(bd, s);
     }
+}
+
+extern "C" int cr_wide_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t, int precision, void* stream) {
+    CR_REQUIRE(d && t, "cr_wide_ln_ffn_fwd_tail: NULL description");
+    if (t->kind == 0) return cr_wide_ln_ffn_fwd(d, precision, stream);
+    const char* why = wide_why(d, precision);
+    if (why) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_ffn_fwd_tail: %s", why);
+    if (d->D != 128) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_wide_ln_ffn_fwd_tail: the tails are taken at D = 128 only");
+    CR_REQUIRE(d->o && d->f_in && d->hid && d->y && d->mask_ids && d->w1 && d->b1 && d->w2 && d->b2 && d->ln2_g && d->ln2_b,
+               "cr_wide_ln_ffn_fwd_tail: NULL pointer");
+    WideTail tl = {};
+    if (t->kind == 1) {
+        const cr_block_desc* n = t->next;
+        CR_REQUIRE(n && n->x == d->y && n->M == d->M && n->D == d->D, "cr_wide_ln_ffn_fwd_tail: next->x must be this block's y (same shape)");
+        CR_REQUIRE(n->q_in && n->qkv && n->k_valid && n->q_valid && n->wqkv && n->bqkv && n->ln1_g && n->ln1_b, "cr_wide_ln_ffn_fwd_tail: NULL pointer in next");
+        tl.next = *n;
+    } else {
+        CR_REQUIRE(t->kind == 2 && t->lnf_gamma && t->lnf_beta && t->out && t->ld_out >= t->col_out + d->D && t->col_out % 4 == 0 && t->ld_out % 4 == 0,
+                   "cr_wide_ln_ffn_fwd_tail: bad final-LayerNorm tail");
+        tl.lnf_g = t->lnf_gamma; tl.lnf_b = t->lnf_beta; tl.out = t->out; tl.ld_out = t->ld_out; tl.col_out = t->col_out;
+    }
+    hipStream_t s = cr_stream(stream);
+    static cr_devmask done[4];
+    const bool sp = precision == CR_PREC_BF16X3;
+    const size_t lds = sp ? WideLds<8, true>::TOTAL : WideLds<8, false>::TOTAL;
+    if (t->kind == 1)
+        return sp ? wide_launch<8, 0>(k_wide_ffn_fwd<8, true, 0, 1>, &done[0], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd_tail", *d, tl)
+                  : wide_launch<8, 0>(k_wide_ffn_fwd<8, false, 0, 1>, &done[1], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd_tail", *d, tl);
+    return sp ? wide_launch<8, 0>(k_wide_ffn_fwd<8, true, 0, 2>, &done[2], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd_tail", *d, tl)
+              : wide_launch<8, 0>(k_wide_ffn_fwd<8, false, 0, 2>, &done[3], d->M, -1, lds, s, "cr_wide_ln_ffn_fwd_tail", *d, tl);
 }

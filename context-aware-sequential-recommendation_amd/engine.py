@@ -478,9 +478,12 @@ class Engine:
         wbd = self._block_desc(x, y, pfx)
         wide = bool(self.fuse_wide and prec != L.PREC_F32 and L.lib.cr_wide_supported(C.byref(wbd), prec))
         MD4 = 4 * M * D
-        if wide:
+        if wide and skip_qkv:
+            pass                                          # ran as the tail of the previous block's FFN kernel
+        elif wide:
             self._call(self.fwd, "cr_wide_ln_qkv_fwd", C.byref(wbd), prec)
         else:
+            assert not skip_qkv and tail is None, "tails need the fused or the wide (D = 128) row kernels"
             # LN1 (+ data-dependent key / query masks, modules.py:222,248-249)
             ln1 = L.LnDesc(x.data_ptr(), D, self._pptr(pfx + "ln1.gamma"), self._pptr(pfx + "ln1.beta"), q_in.data_ptr(), D, M, D,
                            1e-8, kvalid.data_ptr(), qvalid.data_ptr())
@@ -503,7 +506,16 @@ class Engine:
             ad.row_stats = self.vec(pfx + "row_stats", H * B * T * 4).data_ptr()
         self._call(self.fwd, "cr_attn_fwd", C.byref(ad))
         # LN2 + FFN (modules.py:280-318), residual = LN2 output, then * mask (sasrec.py:83)
-        if wide:
+        if wide and tail is not None and tail[0] == "next":
+            nbd = self._block_desc(y, tail[2], tail[1])
+            td = L.BlockTailDesc(1, C.pointer(nbd), None, None, None, 0, 0)
+            self._keep.append(nbd)
+            self._call(self.fwd, "cr_wide_ln_ffn_fwd_tail", C.byref(wbd), C.byref(td), prec)
+        elif wide and tail is not None:
+            _, pname, lo, lo_ld, lo_col = tail
+            td = L.BlockTailDesc(2, None, self._pptr(pname + ".gamma"), self._pptr(pname + ".beta"), lo.data_ptr(), lo_ld, lo_col)
+            self._call(self.fwd, "cr_wide_ln_ffn_fwd_tail", C.byref(wbd), C.byref(td), prec)
+        elif wide:
             self._call(self.fwd, "cr_wide_ln_ffn_fwd", C.byref(wbd), prec)
         else:
             ln2 = L.LnDesc(o.data_ptr(), D, self._pptr(pfx + "ln2.gamma"), self._pptr(pfx + "ln2.beta"), f_in.data_ptr(), D, M, D,
@@ -744,7 +756,10 @@ class Engine:
         """block loop + final LayerNorm (sasrec.py:65-85); returns nothing, writes `out` columns.
         Fused path: block i+1's LN1 + QKV phase and the final LayerNorm run as tails of the FFN kernels; where the
         whole-stack kernel fits (cr_stack_fwd) the forward of up to four blocks + the final LayerNorm is ONE launch."""
-        tails = self.fused and self.fuse_tails and nblocks > 0
+        # (the wide row kernels take the same tails at D = 128: cr_wide_ln_ffn_fwd_tail)
+        wide_tails = (not self.fused and self.fuse_wide and self.attn_precision != "f32" and self.D == 128
+                      and os.environ.get("CASTREC_WIDE_NO_TAILS") != "1")
+        tails = (self.fused or wide_tails) and self.fuse_tails and nblocks > 0
         stack = self._stack_kernel_fits(nblocks, want_attn)
         emb = None
         if stack and x.data_ptr() in self._pending_embed:                # the stack kernel composes its input itself

@@ -338,6 +338,9 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
 int cr_wide_supported(const cr_block_desc* d, int precision);   /* 1 / 0 */
 int cr_wide_ln_qkv_fwd(const cr_block_desc* d, int precision, void* stream);
 int cr_wide_ln_ffn_fwd(const cr_block_desc* d, int precision, void* stream);
+/* ... with a tail applied to the output rows while they are in registers (D = 128 only), as cr_block_ln_ffn_fwd_tail:
+ * kind 1 = the NEXT block's cr_wide_ln_qkv_fwd (next->x must be this block's y), kind 2 = the stack's final LayerNorm */
+int cr_wide_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t, int precision, void* stream);
 /* heads: with d->attn_delta != NULL, [heads, M] floats: delta[h][m] = sum over head h's columns of d_o * (o - q_in), the row term
  * cr_attn_bwd's bf16 kernels take (cr_attn_bwd_desc.delta) to run both passes in one launch; head width a multiple of 16 */
 int cr_wide_ln_ffn_bwd(const cr_block_bwd_desc* d, float* g2, float* g1, int heads, int precision, void* stream);

@@ -403,7 +403,7 @@ def test_wide_row_kernels(E, model, D, H, T, L, B, prec):
     _other_shapes(E, model, D, H, T, L, B, prec=prec)
 
 
-@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_DELTA"])
+@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_DELTA", "CASTREC_WIDE_NO_TAILS"])
 def test_wide_alternative_paths_stay_green(E, env, monkeypatch):
     """the unfused chain (cr_layernorm_* / cr_gemm_rows / cr_eltwise) and the wide kernels with cr_gemm_wgrad forming the
     weight gradients: what the engine falls back to outside D = 128 / 192 / 256; the per-head delta from the FFN backward
