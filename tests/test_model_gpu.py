@@ -403,6 +403,27 @@ def test_wide_row_kernels(E, model, D, H, T, L, B, prec):
     _other_shapes(E, model, D, H, T, L, B, prec=prec)
 
 
+@pytest.mark.parametrize("D,H", [(128, 4), (256, 4)])
+def test_wide_dense_gradients_are_bitwise_reproducible(E, D, H):
+    """the slabs of the wide kernels (LayerNorm column sums folded in a fixed wave order, weight gradients one slab per
+    workgroup, added to in row-block order) hold the same bits on every run of the same step"""
+    rs = np.random.RandomState(3)
+    B, T, itemnum = 6, 40, 41
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=9, num_context_blocks=1, lr=1e-3, seed=11)
+    eng = E.Engine("sasrec", 9, itemnum, hp, B, training=True, n_slabs=2)          # 240 rows on 2 slabs: several row blocks per workgroup
+    seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, 9)
+    got = []
+    for _ in range(3):
+        eng.set_batch(seq, pos, neg, time, hours, days)
+        eng.set_step(1)
+        eng.Gflat.zero_()
+        eng.launch_step(apply=False)
+        torch.cuda.synchronize()
+        got.append(eng.Gs.clone())
+    assert float(got[0].abs().max()) > 0
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+
+
 @pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_DELTA", "CASTREC_WIDE_NO_TAILS"])
 def test_wide_alternative_paths_stay_green(E, env, monkeypatch):
     """the unfused chain (cr_layernorm_* / cr_gemm_rows / cr_eltwise) and the wide kernels with cr_gemm_wgrad forming the
