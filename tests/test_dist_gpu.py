@@ -27,11 +27,11 @@ def make_batch(step, items=ITEMS):
     return seq, pos, neg, time, z, z
 
 
-def hyper(E):
-    return E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=10, seed=4)
+def hyper(E, D=D, H=1):
+    return E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=10, seed=4)
 
 
-def _worker(rank, world, port, q, items=ITEMS, sparse=False):
+def _worker(rank, world, port, q, items=ITEMS, sparse=False, D=D, H=1):
     import torch.distributed as dist
     import castrec_amd  # noqa: F401
     from castrec_amd import engine as E
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q, items=ITEMS, sparse=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_rows(B, rank, world)
-    hp = hyper(E)
+    hp = hyper(E, D, H)
     hp.seed = 4                                                # same dropout key on every rank ...
     eng = E.Engine("cast_1", USERS, items, hp, hi - lo, training=True, n_slabs=8, batch_global=B, row_offset=lo * T)
     if rank != 0:
@@ -57,8 +57,9 @@ def _worker(rank, world, port, q, items=ITEMS, sparse=False):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("items,sparse", [(ITEMS, False), (ITEMS, True), (5000, True)])
-def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, sparse):
+@pytest.mark.parametrize("items,sparse,D,H", [(ITEMS, False, D, 1), (ITEMS, True, D, 1), (5000, True, D, 1),
+                                              (ITEMS, False, 128, 4)])       # the wide row kernels (cr_wide.hip) under the same wrapper
+def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, sparse, D, H):
     """dense: the whole bucket in one all-reduce.  sparse: the item table's touched rows as an all-gather of
     de-duplicated (row id, gradient row) pairs -- 60 items: every row is hot and shared by both ranks; 5000 items:
     V >> the 3 * 8 * 24 row slots a rank touches (the regime of config C5)."""
@@ -68,14 +69,14 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, items, sparse)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, items, sparse, D, H)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    one = E.Engine("cast_1", USERS, items, hyper(E), B, training=True, n_slabs=8)
+    one = E.Engine("cast_1", USERS, items, hyper(E, D, H), B, training=True, n_slabs=8)
     for s in range(STEPS):
         one.train_step(*make_batch(s, items))
     torch.cuda.synchronize()
