@@ -42,6 +42,10 @@ struct BfGeom {
     int M;                        // rows of the operand matrices (B * T): the vector loads may run into the NEXT row, never past the last
     float isd, isd_log2e, invT;
     unsigned long long* ts;       // debug: per-wave phase stamps [waves][16] (tools/attn_bf_ts.py); NULL in production
+    // fused launch (one workgroup of 8 waves runs a whole pass of its sample): the tiles of wave w, heaviest first, up to three
+    // 5-bit tile numbers (31 = none) -- dealt on the host so that the two waves of a SIMD (w and w + 4) together get an equal
+    // share of the pair iterations (bf_deal_tiles)
+    unsigned qpk[8], kpk[8];
 };
 #ifdef CR_TIMELINE
 #define BT_TS(slot)                                                                                          \
@@ -602,14 +606,18 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     // `wave` when T > 256).  PAIRED (the fused kernel: this workgroup runs the whole pass of its sample): tiles w and
     // nkt-1-w, a heavy and a light one -- nkt + 1 tile pairs for every wave.
     const int rank = sched_rank(sch);
-    int tiles[2];
+    unsigned tpk = 0x7FFFu;                              // up to three 5-bit tile numbers, 31 = none
     int ntile = 1;
     if (PAIRED) {
-        tiles[0] = g.nkt - 1 - wave; tiles[1] = wave;                     // heavy one first
-        ntile = tiles[0] > tiles[1] ? 2 : (tiles[0] == tiles[1] ? 1 : 0);
-    } else {
-        tiles[0] = multi ? (int)blockIdx.y * nw + wave : rank; tiles[1] = -1;
+        tpk = g.qpk[wave & 7];                                            // dealt on the host (bf_deal_tiles), heaviest first
+        ntile = ((tpk & 31u) != 31u) + (((tpk >> 5) & 31u) != 31u) + (((tpk >> 10) & 31u) != 31u);
     }
+    const int t_single = multi ? (int)blockIdx.y * nw + wave : rank;      // separate kernels: ONE tile (up to 64 of them at T = 1024)
+    auto tile_at = [&](int ti) {
+        if (!PAIRED) return t_single;
+        const int t = (int)((tpk >> (5 * ti)) & 31u);
+        return t == 31 ? -1 : t;
+    };
     // the first tile's fragments and row constants, requested ahead of the staging
     GFrag<NKS> qn, on, un, rn;                           // Q, dOut and (delta formed here) out, residual
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
@@ -629,7 +637,7 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
             gfrag_issue<NKS>(rn, d.residual, d.ldr, base_row + q0n, hoff, T - q0n, d.d, g.M);
         }
     };
-    if (!PAIRED && tiles[0] >= 0 && tiles[0] < g.nkt) issue_tile(tiles[0]);
+    if (!PAIRED && tile_at(0) >= 0 && tile_at(0) < g.nkt) issue_tile(tile_at(0));
     int kt_first = 0;
     if (!multi) {
         stage(0);
@@ -648,7 +656,7 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
 #pragma unroll 1
     for (int ti = 0; ti < (PAIRED ? ntile : 1); ++ti) {
         const int round = ti;
-        const int qt = tiles[ti];
+        const int qt = tile_at(ti);
         const bool have = (PAIRED || ntile > 0) && qt >= 0 && qt < g.nkt;
         const int q0 = 16 * (have ? qt : 0), q = q0 + li;
         if (PAIRED && have) issue_tile(qt);             // paired tiles are not prefetched: a fragment live across the loop spills
@@ -896,14 +904,18 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
         }
     };
     const int rank = sched_rank(sch);
-    int tiles[2];
+    unsigned tpk = 0x7FFFu;                              // see bf_bwd_q_pass
     int ntile = 1;
-    if (PAIRED) {                                        // see bf_bwd_q_pass
-        tiles[0] = wave; tiles[1] = g.nkt - 1 - wave;                     // heavy one (low key tile) first
-        ntile = tiles[0] < tiles[1] ? 2 : (tiles[0] == tiles[1] ? 1 : 0);
-    } else {
-        tiles[0] = multi ? (int)blockIdx.y * nw + wave : rank; tiles[1] = -1;   // key tile 0 meets every query tile: rank == kt
+    if (PAIRED) {
+        tpk = g.kpk[wave & 7];
+        ntile = ((tpk & 31u) != 31u) + (((tpk >> 5) & 31u) != 31u) + (((tpk >> 10) & 31u) != 31u);
     }
+    const int t_single = multi ? (int)blockIdx.y * nw + wave : rank;      // key tile 0 meets every query tile: rank == kt
+    auto tile_at = [&](int ti) {
+        if (!PAIRED) return t_single;
+        const int t = (int)((tpk >> (5 * ti)) & 31u);
+        return t == 31 ? -1 : t;
+    };
     GFrag<NKS> kn, vn;                                   // K / V fragments of the wave's next key tile, requested ahead
     float kvn = 0.0f;
     auto issue_tile = [&](int kt) {
@@ -911,7 +923,7 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
         gfrag_issue<NKS>(vn, d.V, d.ld, base_row + 16 * kt, hoff, T - 16 * kt, d.d, g.M);
         kvn = d.k_valid[base_row + min(16 * kt + li, T - 1)];
     };
-    if (!PAIRED && tiles[0] >= 0 && tiles[0] < g.nkt) issue_tile(tiles[0]);
+    if (!PAIRED && tile_at(0) >= 0 && tile_at(0) < g.nkt) issue_tile(tile_at(0));
     int fvk = 0;
     if (!multi) {
         stage(0);
@@ -932,7 +944,7 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
 #pragma unroll 1
     for (int ti = 0; ti < (PAIRED ? ntile : 1); ++ti) {
         const int round = ti;
-        const int kt = tiles[ti];
+        const int kt = tile_at(ti);
         const bool have = (PAIRED || ntile > 0) && kt >= 0 && kt < g.nkt;
         const int key0 = 16 * (have ? kt : 0), key = key0 + li;
         const float key_in_T = (have && key < T) ? 1.0f : 0.0f;
@@ -1151,6 +1163,38 @@ __global__ __launch_bounds__(512) void k_bf_bwd_fused(cr_attn_bwd_desc bd, BfGeo
 // =====================================================================================================
 // host side
 // =====================================================================================================
+// Tiles of the fused launch's waves.  A query tile qt meets key tiles 0..qt, a key tile kt query tiles kt..nkt-1, two per loop
+// iteration: ceil(count / 2) iterations.  These kernels are bound by instruction issue, and waves w and w + 4 of a workgroup
+// share a SIMD (waves go to SIMDs in a cyclic order), so what counts is the iterations per SIMD: heaviest tile first, each to
+// the SIMD with the fewest iterations so far, there to the wave with the fewer (at most three tiles per wave).  The first
+// version paired tiles w and nkt - 1 - w on seven waves: 16 / 14 / 12 / 7 iterations on the four SIMDs at T = 200, now 13 / 12 /
+// 12 / 12.
+static void bf_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
+    int cost[32], order[32], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 8; ++w) pk[w] = 0x7FFFu;                          // three "none" entries
+    if (nkt > 24) return;                                                  // (the fused launch takes T <= 256: nkt <= 16)
+    for (int t = 0; t < nkt; ++t) {
+        cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2;
+        order[t] = t;
+    }
+    for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
+        for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
+    for (int i = 0; i < nkt; ++i) {
+        const int t = order[i];
+        int best = -1;
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (cnt[s4] >= 3 && cnt[s4 + 4] >= 3) continue;
+            if (best < 0 || load[s4] + load[s4 + 4] < load[best] + load[best + 4]) best = s4;
+        }
+        if (best < 0) return;                                              // more than 24 tiles: cannot happen (checked above)
+        int w = best;
+        if (cnt[w] >= 3 || (cnt[w + 4] < 3 && load[w + 4] < load[w])) w = best + 4;
+        pk[w] = (pk[w] & ~(31u << (5 * cnt[w]))) | ((unsigned)t << (5 * cnt[w]));
+        ++cnt[w];
+        load[w] += cost[t];
+    }
+}
+
 static int bf_geom(const cr_attn_desc* d, BfGeom* g) {
     g->T16 = (d->T + 15) / 16 * 16;
     g->nkt = g->T16 / 16;
@@ -1161,6 +1205,8 @@ static int bf_geom(const cr_attn_desc* d, BfGeom* g) {
     g->isd_log2e = (float)(1.4426950408889634 / sqrt((double)d->d));
     g->invT = 1.0f / (float)d->T;
     g->ts = nullptr;
+    bf_deal_tiles(g->nkt, true, g->qpk);
+    bf_deal_tiles(g->nkt, false, g->kpk);
     return CR_OK;
 }
 
