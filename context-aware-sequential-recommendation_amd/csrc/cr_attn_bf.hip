@@ -1164,11 +1164,11 @@ __global__ __launch_bounds__(512) void k_bf_bwd_fused(cr_attn_bwd_desc bd, BfGeo
 // host side
 // =====================================================================================================
 // Tiles of the fused launch's waves.  A query tile qt meets key tiles 0..qt, a key tile kt query tiles kt..nkt-1, two per loop
-// iteration: ceil(count / 2) iterations.  These kernels are bound by instruction issue, and waves w and w + 4 of a workgroup
-// share a SIMD (waves go to SIMDs in a cyclic order), so what counts is the iterations per SIMD: heaviest tile first, each to
-// the SIMD with the fewest iterations so far, there to the wave with the fewer (at most three tiles per wave).  The first
-// version paired tiles w and nkt - 1 - w on seven waves: 16 / 14 / 12 / 7 iterations on the four SIMDs at T = 200, now 13 / 12 /
-// 12 / 12.
+// iteration: ceil(count / 2) iterations.  A wave's loop is a serial chain (it issues an instruction every ~5 clocks whatever
+// its SIMD neighbour does), so the launch ends with the wave that has the most iterations.  The first version paired tiles w
+// and nkt - 1 - w on seven waves: 8 / 7 / 8 / 7 / 8 / 7 / 4 iterations at T = 200 and an idle eighth wave.  Here the tiles go
+// heaviest first to the SIMD (waves w and w + 4 share one) with the fewest iterations so far, there to the wave with the fewer
+// (at most three tiles per wave): 7 / 6 / 6 / 6 / 6 / 6 / 6 / 6.
 static void bf_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
     int cost[32], order[32], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < 8; ++w) pk[w] = 0x7FFFu;                          // three "none" entries
