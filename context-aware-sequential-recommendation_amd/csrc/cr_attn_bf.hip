@@ -401,7 +401,10 @@ __global__ __launch_bounds__(512) void k_bf_fwd_long(cr_attn_desc d, BfGeom g) {
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const DropCtx dc = drop_ctx(d.drop);
-    const int qt = (int)blockIdx.y * nw + wave;
+    // (the workgroups of the late, heavy query tiles get the low block indices: they are dispatched first and the light ones
+    //  fill the tail of the launch)
+    const int yq = (int)gridDim.y - 1 - (int)blockIdx.y;
+    const int qt = yq * nw + wave;
     const bool have = qt < g.nkt;
     const int q0 = 16 * (have ? qt : 0), q = q0 + li;
     const int qc = min(q, T - 1);
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(512) void k_bf_fwd_long(cr_attn_desc d, BfGeom g) {
 #pragma unroll
     for (int jt = 0; jt < NDT; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // chunks this workgroup walks: up to the chunk of its last query row; all of them when it may hold a uniform row
-    const int blk_q0 = 16 * (int)blockIdx.y * nw;
+    const int blk_q0 = 16 * yq * nw;
     const int c_hi = (blk_q0 < fvk) ? g.nch - 1 : min(g.nch - 1, (blk_q0 + 16 * nw - 1) / BF_CH);
     for (int c = 0; c <= c_hi; ++c) {
         __syncthreads();
@@ -612,7 +615,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
         tpk = g.qpk[wave & 7];                                            // dealt on the host (bf_deal_tiles), heaviest first
         ntile = ((tpk & 31u) != 31u) + (((tpk >> 5) & 31u) != 31u) + (((tpk >> 10) & 31u) != 31u);
     }
-    const int t_single = multi ? (int)blockIdx.y * nw + wave : rank;      // separate kernels: ONE tile (up to 64 of them at T = 1024)
+    const int yq = (int)gridDim.y - 1 - (int)blockIdx.y;                  // T > 256: heavy (late) query tiles in the workgroups dispatched first
+    const int t_single = multi ? yq * nw + wave : rank;                   // separate kernels: ONE tile (up to 64 of them at T = 1024)
     auto tile_at = [&](int ti) {
         if (!PAIRED) return t_single;
         const int t = (int)((tpk >> (5 * ti)) & 31u);
@@ -696,7 +700,7 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
 #pragma unroll
         for (int jt = 0; jt < NDT; ++jt) dq[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // chunk range: causal -- the chunk of the workgroup's last query tile bounds the loop (workgroup-uniform)
-        const int c_hi = multi ? min(g.nch - 1, (16 * ((int)blockIdx.y * nw + nw - 1) + 15) / BF_CH) : 0;
+        const int c_hi = multi ? min(g.nch - 1, (16 * (yq * nw + nw - 1) + 15) / BF_CH) : 0;
         for (int c = 0; c <= c_hi; ++c) {
             if (multi) {
                 __syncthreads();
