@@ -550,11 +550,12 @@ class Engine:
                 own_w = D == 128 and os.environ.get("CASTREC_WIDE_NO_WGRAD") != "1"
                 if not own_w:
                     bbd.g_w1 = bbd.g_b1 = bbd.g_w2 = bbd.g_b2 = bbd.g_wqkv = bbd.g_bqkv = None
-                # The one-launch attention backward (both passes side by side) needs the per-head row term delta up front;
-                # the FFN backward can emit it.  Off by default: at these shapes B * H (sample, head) pairs fill the chip in
-                # either form (C4: 85 us as two launches, 85 us as one) and the FFN backward reads o and q_in once more.
+                # The one-launch attention backward (both passes side by side, tiles dealt to eight waves) needs the per-head row
+                # term delta up front; the FFN backward emits it (it reads o and q_in once more for that).  C4 shape: 1.136 ->
+                # 1.094 ms per step since the fused kernel deals its tiles by iteration count (before that: equal).
                 dh = D // H
-                fuse_attn = (T <= 256 and 8 <= dh <= 64 and dh % 16 == 0 and os.environ.get("CASTREC_WIDE_DELTA") == "1")
+                fuse_attn = (T <= 256 and 8 <= dh <= 64 and dh % 16 == 0 and os.environ.get("CASTREC_WIDE_NO_DELTA") != "1"
+                             and os.environ.get("CASTREC_BF_TWO_KERNELS") is None)
                 if fuse_attn:
                     delta = self.vec("attn_delta_heads", H * M)
                     bbd.attn_delta = delta.data_ptr()

@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-B, T, D, ITEMS, USERS, STEPS = 16, 24, 20, 60, 9, 3
+B, T, D, ITEMS, USERS, STEPS = 16, 24, 20, 60, 9, int(os.environ.get("CASTREC_TEST_STEPS", "3"))
 
 
 def make_batch(step, items=ITEMS):
@@ -94,11 +94,55 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
         # element nearly cancel, m / (sqrt(v) + eps) turns the re-association-level ABSOLUTE gradient difference into a
         # relative one (seen: 2 elements of the 5001 x 20 item table at 3e-6 and 2e-5, each moved 4e-4 in 3 steps)
         d = np.abs(res[0][1][k] - ref[k])
+        if D == 128:
+            # four blocks of D = 128 at this random start have bias-like gradients of 1e7 ... 1e15 (rows of near-zero variance
+            # behind LayerNorms): which elements sit on an Adam sign boundary then changes from run to run with the order of
+            # the table's float atomics.  99 % of a tensor agree to 1e-4 (medians are ~1e-6), none moves more than the three steps allow; the
+            # sharp statement for these kernels is test_row_buffers_do_not_depend_on_the_sharding below (bitwise).
+            assert np.quantile(d, 0.99) <= 1e-4 and d.max() <= 3.5e-3, (k, float(np.quantile(d, 0.99)), float(d.max()))
+            continue
         assert d.max() <= 1e-4 and (d > 5e-6).sum() <= 1 + 1e-4 * d.size, (k, float(d.max()), int((d > 5e-6).sum()))
     loss_one = one.loss_auc()[0]
     st = res[0][2]
     assert st[0] / st[2] == pytest.approx(loss_one, rel=1e-5)  # bucket tail: loss_sum, auc_sum, n_target of the WHOLE batch
     assert st[2] == float((make_batch(STEPS - 1, items)[1] != 0).sum())
+
+
+@pytest.mark.parametrize("D_,H_", [(20, 1), (128, 4)])
+def test_row_buffers_do_not_depend_on_the_sharding(D_, H_):
+    """Every activation and gradient row of a step (every [M, D] / [3, M, D] buffer of the engine) holds the same BITS whether the
+    batch is one engine's or split over two replicas with batch_global / row_offset: dropout keyed by the global row, nothing
+    in a row's arithmetic depends on its neighbours in the batch.  What data parallelism changes is only the order of the sums
+    over rows (slabs, the bucket all-reduce)."""
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine as E
+    hp = lambda: E.Hyper(maxlen=T, hidden_units=D_, num_blocks=2, num_heads=H_, dropout_rate=0.2, max_bins=10, seed=4)
+    seq, pos, neg, time, z, _ = make_batch(0)
+    whole = E.Engine("cast_1", USERS, ITEMS, hp(), B, training=True, n_slabs=8)
+    parts = []
+    for r in range(2):
+        e = E.Engine("cast_1", USERS, ITEMS, hp(), B // 2, training=True, n_slabs=8, batch_global=B, row_offset=r * (B // 2) * T)
+        e.P.copy_(whole.P)
+        parts.append(e)
+    whole.set_batch(seq, pos, neg, time, z, z)
+    whole.launch_step(apply=False)
+    for r, e in enumerate(parts):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        e.set_batch(seq[sl], pos[sl], neg[sl], time[sl], z[sl], z[sl])
+        e.launch_step(apply=False)
+    torch.cuda.synchronize()
+    M, Mh, checked = B * T, B * T // 2, 0
+    for name, a in whole._bufs.items():
+        if a.dim() != 2 or a.shape[0] not in (M, 3 * M):
+            continue
+        for r, e in enumerate(parts):
+            b = e._bufs.get(name)
+            if b is None:
+                continue
+            for k in range(a.shape[0] // M):
+                assert torch.equal(a[k * M + r * Mh: k * M + (r + 1) * Mh], b[k * Mh: (k + 1) * Mh]), (name, r, k)
+                checked += 1
+    assert checked >= 20
 
 
 def _rccl_worker(rank, world, port, q):

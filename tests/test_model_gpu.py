@@ -424,11 +424,11 @@ def test_wide_dense_gradients_are_bitwise_reproducible(E, D, H):
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
 
 
-@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_DELTA", "CASTREC_WIDE_NO_TAILS"])
+@pytest.mark.parametrize("env", ["CASTREC_NO_WIDE", "CASTREC_WIDE_NO_WGRAD", "CASTREC_WIDE_NO_DELTA", "CASTREC_WIDE_NO_TAILS"])
 def test_wide_alternative_paths_stay_green(E, env, monkeypatch):
     """the unfused chain (cr_layernorm_* / cr_gemm_rows / cr_eltwise) and the wide kernels with cr_gemm_wgrad forming the
-    weight gradients: what the engine falls back to outside D = 128 / 192 / 256; the per-head delta from the FFN backward
-    with the attention backward as one launch"""
+    weight gradients: what the engine falls back to outside D = 128 / 192 / 256; the two-launch attention backward (no
+    per-head delta from the FFN backward)"""
     monkeypatch.setenv(env, "1")
     _other_shapes(E, "sasrec", 128, 4, 40, 2, prec="bf16x3")
 
