@@ -114,7 +114,7 @@ def algo_work(name, fnargs, eng):
         return 2.0 * M * D * 4 * D, None, "mfma"
     if name in ("cr_block_ln_qkv_bwd", "cr_block_ln_qkv_bwd_scatter", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter"):
         return 2.0 * M * D * 6 * D, None, "mfma"
-    if name in ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln"):
+    if name in ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads"):
         return 2.0 * M * D * 4 * D, None, "mfma"
     # hidden sizes 128 / 192 / 256 (cr_wide.hip): the activations do not fit the caches at these sizes (M x D x 4 = 13 MB per
     # tensor at config C4, ~20 tensors per block), so the row phases are priced against HBM: rows read + rows written
@@ -185,7 +185,7 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
               "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
-              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"],
+              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_heads": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"],
               "cr_wide_ln_qkv_fwd": ["k_wide_qkv_fwd"], "cr_wide_ln_ffn_fwd": ["k_wide_ffn_fwd"], "cr_wide_ln_ffn_bwd": ["k_wide_ffn_bwd"],
               "cr_wide_ln_qkv_bwd": ["k_wide_qkv_bwd"], "cr_gemm_rows": ["k_gemm_rows"], "cr_gemm_wgrad": ["k_gemm_wgrad"]}
 

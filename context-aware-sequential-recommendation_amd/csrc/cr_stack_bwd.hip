@@ -35,6 +35,7 @@ struct SbArgs {
     cr_block_bwd_desc bd;
     cr_embed_bwd_desc sc;         // qkv: optional scatter of dx into the embedding tables (see cr_block_ln_qkv_bwd_scatter)
     int B, T, nkt, scatter;
+    int heads;                    // ffn: attn_delta is [heads, M] (1, or 2 heads of 32 columns at D = 64)
     int has_ln;                   // ffn: bd.dy is not read; it is the backward of the stack's final LayerNorm (`ln`) applied to ln.dy
     cr_ln_bwd_desc ln;
     unsigned long long* ts;
@@ -432,13 +433,22 @@ __global__ __launch_bounds__(SB_NT) void k_stack_ffn_bwd(SbArgs a) {
                     // delta[m] = sum_c d_o[m][c] * (o[m][c] - q_in[m][c]) (the attention core's output is o - q_in, modules.py:262-269)
                     f32x4 qin[4];
                     r_finish(qin, rq, dcx);
-                    float acc = 0.0f;
+                    float acc = 0.0f, acc2 = 0.0f;        // (two heads: column tiles 0, 1 are head 0, tiles 2, 3 head 1)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc);
-                    acc = grp_sum(acc);
-                    if (lg == 0 && rok) bd.attn_delta[m] = acc;
+                        for (int r = 0; r < 4; ++r) {
+                            if (ct < 2) acc = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc);
+                            else acc2 = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc2);
+                        }
+                    if (a.heads == 2) {
+                        acc = grp_sum(acc);
+                        acc2 = grp_sum(acc2);
+                        if (lg == 0 && rok) { bd.attn_delta[m] = acc; bd.attn_delta[(size_t)d.M + m] = acc2; }
+                    } else {
+                        acc = grp_sum(acc + acc2);
+                        if (lg == 0 && rok) bd.attn_delta[m] = acc;
+                    }
                 }
             }
             if (PF && item + (int)gridDim.x < nitems) issue((item + (int)gridDim.x) / R, (item + (int)gridDim.x) % R);
@@ -691,11 +701,13 @@ static int sb_args(SbArgs* a, const cr_block_bwd_desc* bd, int B, int T, int pre
     return CR_OK;
 }
 
-static int stack_ffn_bwd_any(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream, const char* who) {
+static int stack_ffn_bwd_any(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int heads, int precision, void* stream, const char* who) {
     SbArgs a;
     int rc = sb_args(&a, bd, B, T, precision, who);
     if (rc) return rc;
     const cr_block_desc* d = &bd->f;
+    CR_REQUIRE(heads == 1 || (heads == 2 && d->D == 64), "%s: attn_delta per head is formed for one head, or two heads at D = 64", who);
+    a.heads = heads;
     CR_REQUIRE(bd->d_o && d->hid && d->f_in && d->o && d->mask_ids && d->w1 && d->w2 && d->ln2_g, "%s: NULL pointer", who);
     CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b, "%s: NULL gradient pointer", who);
     CR_REQUIRE(bd->attn_delta == nullptr || d->q_in != nullptr, "%s: attn_delta needs q_in", who);
@@ -717,11 +729,14 @@ static int stack_ffn_bwd_any(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* 
     return split ? launch_ffn_bwd<true, 0>(a, s) : launch_ffn_bwd<false, 0>(a, s);
 }
 extern "C" int cr_stack_ffn_bwd(const cr_block_bwd_desc* bd, int B, int T, int precision, void* stream) {
-    return stack_ffn_bwd_any(bd, nullptr, B, T, precision, stream, "cr_stack_ffn_bwd");
+    return stack_ffn_bwd_any(bd, nullptr, B, T, 1, precision, stream, "cr_stack_ffn_bwd");
 }
 extern "C" int cr_stack_ffn_bwd_ln(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream) {
     CR_REQUIRE(n != nullptr, "cr_stack_ffn_bwd_ln: NULL LayerNorm description");
-    return stack_ffn_bwd_any(bd, n, B, T, precision, stream, "cr_stack_ffn_bwd_ln");
+    return stack_ffn_bwd_any(bd, n, B, T, 1, precision, stream, "cr_stack_ffn_bwd_ln");
+}
+extern "C" int cr_stack_ffn_bwd_heads(const cr_block_bwd_desc* bd, const cr_ln_bwd_desc* n, int B, int T, int heads, int precision, void* stream) {
+    return stack_ffn_bwd_any(bd, n, B, T, heads, precision, stream, "cr_stack_ffn_bwd_heads");
 }
 
 static int stack_qkv_bwd_any(const cr_block_bwd_desc* bd, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream, const char* who) {

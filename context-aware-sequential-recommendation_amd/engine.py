@@ -714,7 +714,24 @@ class Engine:
             # bf16 arithmetic: the row phases run on the register-layout kernels (cr_stack_bwd.hip) where they take the shape
             prec = ATTN_PRECISIONS[self.attn_precision]
             rows_bf = bool(self.fuse_stack_bwd and bf and not one_pass and L.lib.cr_stack_bwd_supported(C.byref(bbd), B, T, prec))
-            if rows_bf and self._lnf_fused(y):
+            two_heads = (rows_bf and H == 2 and D == 64 and T <= 256 and os.environ.get("CASTREC_BF_TWO_KERNELS") is None
+                         and os.environ.get("CASTREC_NO_HEAD_DELTA") != "1")
+            if two_heads:
+                # config C3's shape: the register-layout FFN backward emits delta per head ([2, M]), so the attention backward is
+                # ONE launch here too
+                delta = self.vec("attn_delta_heads", H * M)
+                bbd.attn_delta = delta.data_ptr()
+                abd.delta = delta.data_ptr()
+                nd = None
+                if self._lnf_fused(y):
+                    _, pname, lo, lo_ld, lo_col = self._lnf_intent[y.data_ptr()]
+                    dlo = self._grad_of(lo)
+                    nd = L.LnBwdDesc(y.data_ptr(), D, self._pptr(pname + ".gamma"), dlo.data_ptr() + 4 * lo_col, lo_ld, None, D, 0,
+                                     self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+                    assert id(dy) not in self._grad_written, "the final LayerNorm must be the only consumer of the stack's output"
+                    self._keep.append(nd)
+                self._call(lst, "cr_stack_ffn_bwd_heads", C.byref(bbd), C.byref(nd) if nd is not None else None, B, T, H, prec)
+            elif rows_bf and self._lnf_fused(y):
                 _, pname, lo, lo_ld, lo_col = self._lnf_intent[y.data_ptr()]
                 dlo = self._grad_of(lo)
                 nd = L.LnBwdDesc(y.data_ptr(), D, self._pptr(pname + ".gamma"), dlo.data_ptr() + 4 * lo_col, lo_ld, None, D, 0,

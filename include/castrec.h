@@ -321,6 +321,9 @@ int cr_stack_ffn_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, vo
  * on the way in: `n` is the cr_layernorm_bwd call that would have produced d->dy (n->x == d->f.y; d->dy and n->dx are not
  * touched; n->accumulate == 0; same slabs as d) */
 int cr_stack_ffn_bwd_ln(const cr_block_bwd_desc* d, const cr_ln_bwd_desc* n, int B, int T, int precision, void* stream);
+/* ... either of the two (n may be NULL) with d->attn_delta per head, [heads, M]: one head, or two heads of 32 columns at D = 64
+ * (config C3) -- what cr_attn_bwd's one-launch form takes as cr_attn_bwd_desc.delta */
+int cr_stack_ffn_bwd_heads(const cr_block_bwd_desc* d, const cr_ln_bwd_desc* n, int B, int T, int heads, int precision, void* stream);
 int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
 /* ... with the embedding gather's backward applied instead of storing dx: arguments as cr_block_ln_qkv_bwd_scatter */
 int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);

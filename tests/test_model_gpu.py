@@ -246,11 +246,14 @@ def test_awkward_hidden_sizes_and_row_counts(E, model, D, H, T, L, B, prec):
 
 
 @pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD", "CASTREC_NO_EMBED_FUSION", "CASTREC_NO_HEAD_LN",
-                                 "CASTREC_NO_STACK_KERNEL", "CASTREC_NO_STACK_BWD", "CASTREC_NO_LNF_FUSION"])
+                                 "CASTREC_NO_STACK_KERNEL", "CASTREC_NO_STACK_BWD", "CASTREC_NO_LNF_FUSION", "CASTREC_NO_HEAD_DELTA"])
 def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     """The plain FFN forward entry (no tail), the two-pass attention backward at one head and the stand-alone
     embedding gather in front of a stack: the engine's default path no longer uses them, the C ABI still offers them."""
     monkeypatch.setenv(env, "1")
+    if env == "CASTREC_NO_HEAD_DELTA":                     # two heads at D = 64 with the two-launch attention backward
+        _other_shapes(E, "sasrec", 64, 2, 50, 2, prec="bf16x3")
+        return
     _other_shapes(E, "cast_1", 50, 1, 40, 2, prec="f32")
     _other_shapes(E, "cast_1", 50, 1, 40, 2, prec="bf16x3")
 
@@ -309,8 +312,8 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
     monkeypatch.delenv(env)
     names = lambda e: [n for n, _, _ in e.fwd + e.bwd]
-    new = "cr_stack_fwd" if env == "CASTREC_NO_STACK_KERNEL" else "cr_stack_ffn_bwd"
-    assert new in names(a) and new not in names(b)
+    new = ("cr_stack_fwd",) if env == "CASTREC_NO_STACK_KERNEL" else ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_heads")
+    assert any(n in names(a) for n in new) and not any(n in names(b) for n in new)
     a.P.add_(0.05 * torch.randn(a.P.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
     b.P.copy_(a.P)
     batch = make_batch(rs, B, T, itemnum, max_bins)
