@@ -256,13 +256,21 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_bf(WgradBatchBf batch) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = mma<SPLIT>(ah, al, gh[j], gl[j], acc[j]);
         }
-        if (d.db && k0 == 0 && threadIdx.x < 64) {            // column sums of G from the images (hi + lo = the fp32 value to 2^-17)
-            const int c = threadIdx.x;
-            for (int r = 0; r < 64; ++r) {
+        if (d.db && k0 == 0) {                                // column sums of G from the images (hi + lo = the fp32 value to 2^-17):
+            const int c = threadIdx.x & 63, r0 = 16 * wave;   // wave w takes rows 16 w .. 16 w + 15 (one wave doing all 64 was the
+#pragma unroll 4                                              // longest chain of its workgroup: 128 dependent LDS reads per chunk)
+            for (int r = r0; r < r0 + 16; ++r) {
                 const int o = img_off(r, c >> 3) + (c & 7);
                 bsum += (float)Gh[o] + (SPLIT ? (float)Gl[o] : 0.0f);
             }
         }
+    }
+    if (d.db && k0 == 0) {                                    // fold the four waves' partial column sums, wave order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 64) bsum = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
     }
     float* dW = d.dW + (size_t)s * batch.slab_stride;
 #pragma unroll
