@@ -897,14 +897,18 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
         }
     };
     auto stage_flags = [&]() {                                           // after a barrier: per query tile of the chunk
-        const int t = threadIdx.x;
-        if (t < g.ch_rows / 16) {
-            float f = 0.0f;
-            for (int i = 0; i < 16; ++i) {
-                if (sinv[16 * t + i] != 0.0f && f < 1.0f) f = 1.0f;
-                if (suni[16 * t + i] != 0.0f) f = 2.0f;
+        // one lane per ROW, the 16 rows of a tile folded by ballots (a thread per tile read its 32 values one after the other:
+        // 0.8 us between two barriers of the key-owner prologue)
+        const int t = threadIdx.x;                                       // ch_rows <= 256 < blockDim: whole waves take part
+        if ((t & ~63) < g.ch_rows) {
+            const bool live = t < g.ch_rows;
+            const unsigned long long bn = __ballot(live && sinv[live ? t : 0] != 0.0f);
+            const unsigned long long bu = __ballot(live && suni[live ? t : 0] != 0.0f);
+            if ((t & 15) == 0 && live) {
+                const int sh = t & 48;                                   // this tile's 16 bits of the wave's ballot
+                const bool anyu = ((bu >> sh) & 0xFFFFull) != 0, anyn = ((bn >> sh) & 0xFFFFull) != 0;
+                tile_flag[t >> 4] = anyu ? 2.0f : (anyn ? 1.0f : 0.0f);
             }
-            tile_flag[t] = f;
         }
     };
     const int rank = sched_rank(sch);
