@@ -126,9 +126,11 @@ extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
 // (sum over the batch) is reduced in registers + LDS (no atomics), the item rows are
 // scatter-added with one 4*D-byte contiguous float-atomic burst per row.
 #define EMB_MAXC 8   // columns per lane: D <= 512
-__global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
+#define EMB_BW 16    // waves per workgroup: a wave's rows are a serial chain of load -> atomics passes (4 waves x 8 passes at B = 128
+                     // made the 200 workgroups of config C4 take 29 us; 16 waves x 2 passes: the chip has the wave slots)
+__global__ __launch_bounds__(64 * EMB_BW) void k_embed_bwd(cr_embed_bwd_desc bd) {
     const cr_embed_desc& d = bd.f;
-    __shared__ float red[4][64 * EMB_MAXC];
+    __shared__ float red[EMB_BW][64 * EMB_MAXC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x;
     const int B = d.M / d.T;
@@ -139,12 +141,12 @@ __global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
     // U rows per pass: their ids, masks and gradient rows are requested together (one latency for U rows),
     // then scattered; the per-column accumulation order over b stays fixed
     constexpr int U = 4;
-    for (int b0 = wave; b0 < B; b0 += 4 * U) {
+    for (int b0 = wave; b0 < B; b0 += EMB_BW * U) {
         int mm[U], id[U];
         float keep[U], g[U][EMB_MAXC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int b = b0 + 4 * u;
+            const int b = b0 + EMB_BW * u;
             mm[u] = (b < B ? b : b0) * d.T + t;
             id[u] = d.ids[mm[u]];
             keep[u] = (b < B && !(d.mask_ids && d.mask_ids[mm[u]] == 0)) ? 1.0f : 0.0f;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (b0 + 4 * u >= B) break;
+            if (b0 + EMB_BW * u >= B) break;
             const int m = mm[u];
             const bool skip_table = (d.zero_pad && id[u] == 0) || bd.table_grad == nullptr;
 #pragma unroll
@@ -176,8 +178,12 @@ __global__ __launch_bounds__(256) void k_embed_bwd(cr_embed_bwd_desc bd) {
 #pragma unroll
         for (int i = 0; i < EMB_MAXC; ++i) red[wave][lane + 64 * i] = acc[i];
         __syncthreads();
-        for (int c = threadIdx.x; c < d.D; c += 256)
-            bd.pos_grad[(size_t)t * d.D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        for (int c = threadIdx.x; c < d.D; c += 64 * EMB_BW) {
+            float sum = 0.0f;                                 // wave order: fixed
+#pragma unroll
+            for (int w = 0; w < EMB_BW; ++w) sum += red[w][c];
+            bd.pos_grad[(size_t)t * d.D + c] = sum;
+        }
     }
 }
 
@@ -343,7 +349,7 @@ extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
                 if (grid > 2048) grid = 2048;
                 hipLaunchKernelGGL(k_embed_bwd_rows16, dim3(grid), dim3(256), 0, cr_stream(stream), big);
             } else {
-                hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(256), 0, cr_stream(stream), big);
+                hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(64 * EMB_BW), 0, cr_stream(stream), big);
             }
             return cr_check_launch("cr_embed_bwd(small table through the large-table kernels)");
         }
@@ -357,6 +363,6 @@ extern "C" int cr_embed_bwd(const cr_embed_bwd_desc* bd, void* stream) {
         hipLaunchKernelGGL(k_embed_bwd_rows16, dim3(grid), dim3(256), 0, cr_stream(stream), *bd);
         return cr_check_launch("cr_embed_bwd(rows)");
     }
-    hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(256), 0, cr_stream(stream), *bd);
+    hipLaunchKernelGGL(k_embed_bwd, dim3(d->T), dim3(64 * EMB_BW), 0, cr_stream(stream), *bd);
     return cr_check_launch("cr_embed_bwd");
 }
