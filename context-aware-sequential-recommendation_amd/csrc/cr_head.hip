@@ -11,6 +11,10 @@
 template <int LPR>
 __device__ __forceinline__ float head_row_sum(float v) {
     if (LPR == 16) return cr_row16_sum(v);
+    if (LPR == 32) {                                     // two DPP rows of 16 lanes: row sums, then the neighbouring row's
+        v = cr_row16_sum(v);
+        return v + __shfl_xor(v, 16, 64);
+    }
     return wave_sum(v);
 }
 
@@ -127,6 +131,10 @@ extern "C" int cr_head_fwd_bwd(const cr_head_desc* d, void* stream) {
         int grid = cr_ceil_div(d->M, 16);
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL((k_head<16, 4>), dim3(grid), dim3(256), 0, cr_stream(stream), *d);
+    } else if (d->D <= 128) {
+        int grid = cr_ceil_div(d->M, 8);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL((k_head<32, 4>), dim3(grid), dim3(256), 0, cr_stream(stream), *d);
     } else {
         int grid = cr_ceil_div(d->M, 4);
         if (grid > 2048) grid = 2048;
@@ -314,8 +322,12 @@ extern "C" int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n
                "cr_head_fwd_bwd_ln: the LayerNorm description must match the head's rows");
     CR_REQUIRE(!n->accumulate, "cr_head_fwd_bwd_ln: accumulate is not supported");
     if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd_ln: D=%d > 512", d->D);
+    // lanes per row: 16 (D <= 64), 32 (D <= 128: two rows per wave and DPP row sums -- with a whole wave per row the eight rows
+    // of a wave at config C4 were eight serial gather -> reduce -> atomics passes: 36 us), else 64
     if (d->D <= 64)
         hipLaunchKernelGGL((k_head_ln<16, 4>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
+    else if (d->D <= 128)
+        hipLaunchKernelGGL((k_head_ln<32, 4>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
     else
         hipLaunchKernelGGL((k_head_ln<64, 8>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
     return cr_check_launch("cr_head_fwd_bwd_ln");
