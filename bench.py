@@ -46,15 +46,26 @@ def launch_ranks(n, argv, env=None, timeout=None):
         e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL across processes on this driver)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all ranks: when one dies (or the deadline passes) the rest -- blocked in a collective the dead rank will never
+    # join -- are killed instead of being waited for until the process-group timeout
     rc = 0
-    deadline = None if timeout is None else time.time() + timeout
-    for p in procs:
-        try:
-            p.wait(None if deadline is None else max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.wait()
-        rc = max(rc, abs(p.returncode or 0))
+    deadline = time.time() + (timeout if timeout is not None else 3600.0)
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = max(rc, abs(r))
+        if live and (rc != 0 or time.time() > deadline):
+            for p in live:
+                p.kill()
+            for p in live:
+                p.wait()
+            rc = max(rc, 1)
+            break
+        if live:
+            time.sleep(0.05)
     return rc
 
 
@@ -190,15 +201,30 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_wide_ln_qkv_bwd": ["k_wide_qkv_bwd"], "cr_gemm_rows": ["k_gemm_rows"], "cr_gemm_wgrad": ["k_gemm_wgrad"]}
 
 
-def pmc_lookup(abi_name, precision):
-    """Counter evidence for the device kernels behind a C-ABI entry, from the committed rocprofv3 --pmc summary of
-    this same command (profiles/r*_<precision>_pmc_summary.json, written by tools/prof.sh + tools/pmc_summary.py):
-    HBM bytes per launch ((2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md section HBM) and the MFMA-busy fraction
-    (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)).  (None, None, "n/a") if absent."""
+HEADLINE = dict(model="cast_1", batch_size=128, maxlen=200, hidden_units=50, num_blocks=2, num_heads=1, corpus="ml-1m", lazy_adam=False)
+
+
+def config_tag(args):
+    """'' for the headline workload, else a tag naming the shape (profiles/r*_<tag>_<precision>_pmc_summary.json)."""
+    if all(getattr(args, k) == v for k, v in HEADLINE.items()):
+        return ""
+    return "%s_T%d_D%d_L%d_H%d_B%d_%s%s" % (args.model, args.maxlen, args.hidden_units, args.num_blocks, args.num_heads, args.batch_size,
+                                             args.corpus.replace("-", ""), "_lazy" if args.lazy_adam else "")
+
+
+def pmc_lookup(abi_name, precision, tag=""):
+    """Counter evidence for the device kernels behind a C-ABI entry.  NOT measured in this run: read from the committed
+    rocprofv3 --pmc summary of this same command AND workload (profiles/r*[_<tag>]_<precision>_pmc_summary.json, written by
+    tools/prof.sh + tools/pmc_summary.py; tag = config_tag(): empty for the headline workload): HBM bytes per launch
+    ((2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md section HBM) and the MFMA-busy fraction
+    (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)).  (None, None, reason) when no summary of this
+    workload is committed -- a summary of another workload is never substituted."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % precision)))
+    import re
+    pat = re.compile(r"^r\d+[a-z]?_%s%s_pmc_summary\.json$" % ((re.escape(tag) + "_") if tag else "", re.escape(precision)))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")) if pat.match(os.path.basename(f)))
     if not files:
-        return None, None, "n/a"
+        return None, None, "no committed PMC summary for this workload (%s)" % (tag or "headline")
     with open(files[-1]) as f:
         summ = json.load(f)
     want = KERNELS_OF.get(abi_name, ["k_" + abi_name[3:]])
@@ -208,7 +234,7 @@ def pmc_lookup(abi_name, precision):
             tot += e["hbm_traffic_bytes"]; hit += 1
             busy += e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); act += e.get("GRBM_GUI_ACTIVE", 0.0)
     if not hit:
-        return None, None, os.path.relpath(files[-1], ROOT)
+        return None, None, os.path.relpath(files[-1], ROOT) + " (kernel absent)"
     return tot, (round(busy / (act / 8.0 * 1024.0), 4) if act else None), os.path.relpath(files[-1], ROOT)
 
 
@@ -282,6 +308,18 @@ OTHER_CONFIGS = [
     ("C5 configs[4] shape on one GPU at batch 32: SASRec maxlen=512 hidden_units=256 num_blocks=2 num_heads=4, ml-1m-sized table "
      "(the 10 M-item table: --corpus c5 [--lazy_adam], profiles/r02d_c5_*_bench.json)",
      ["--model", "sasrec", "--maxlen", "512", "--hidden_units", "256", "--num_heads", "4", "--num_blocks", "2", "--batch_size", "32"]),
+    # the same two shapes at their full vocabularies: the tables no longer fit the caches and Adam sweeps them
+    ("C4 configs[3] at full size on one GPU: Books-sized corpus (600 000 users, 368 000 items, Zipf 1.0), SASRec maxlen=200 hidden_units=128 "
+     "num_blocks=4 num_heads=4, batch 128",
+     ["--model", "sasrec", "--maxlen", "200", "--hidden_units", "128", "--num_heads", "4", "--num_blocks", "4", "--corpus", "books", "--steps", "60"]),
+    ("C5 configs[4] at full size on one GPU: 10 M-item table (10.24 GB fp32 + two Adam moments + gradient = 41 GB resident), SASRec maxlen=512 "
+     "hidden_units=256 num_blocks=2 num_heads=4, batch 128, dense TF-Adam (the reference's optimiser); corpus cut: 4 000 of the 10^6 users "
+     "are materialised (the sampler draws users uniformly: a step's work does not depend on the user count)",
+     ["--model", "sasrec", "--maxlen", "512", "--hidden_units", "256", "--num_heads", "4", "--num_blocks", "2", "--corpus", "c5", "--steps", "12", "--warmup", "3"]),
+    ("C5 configs[4] at full size, row-sparse (lazy) Adam on the item table -- a DEVIATION from the reference's dense update (DESIGN.md "
+     "section 8); same corpus cut",
+     ["--model", "sasrec", "--maxlen", "512", "--hidden_units", "256", "--num_heads", "4", "--num_blocks", "2", "--corpus", "c5", "--lazy_adam",
+      "--steps", "30", "--warmup", "5"]),
 ]
 
 
@@ -292,9 +330,9 @@ def other_configs(steps=100, warmup=10):
     res = []
     for label, flags in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-gather", "--no-extra-precisions", "--no-other-configs",
-               "--steps", str(steps), "--warmup", str(warmup)] + flags
+               "--steps", str(steps), "--warmup", str(warmup)] + flags              # (a config's own --steps / --warmup come last and win)
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             res.append(dict(config=label, value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"],
                             launches_per_step=d["config"]["launches_per_step"], attn_precision=d["config"]["attn_precision"],
@@ -304,50 +342,55 @@ def other_configs(steps=100, warmup=10):
     return res
 
 
-def gather_block(reps=20):
+def gather_block(reps=24):
     """HBM roofline of the item-embedding gather at config C5's table (10 M x 256 fp32 = 10.24 GB, far beyond the 256 MiB
     Infinity Cache), uniformly random rows.  (a) cr_embed_fwd on one C5 step (65 536 rows: table row x sqrt(D) + positional
     row, masked, written as the fp32 activation -- as many bytes written as read); (b) the read-only form, cr_test_logits
-    (rows gathered and reduced against the sequence embedding, nothing but 4 bytes per row written)."""
+    (rows gathered and reduced against the sequence embedding, nothing but 4 bytes per row written).
+
+    EVERY launch gathers a fresh set of rows (its own id tensor): round 2 replayed one id tensor, so the 67 MB of table
+    rows of launch k were still in the Infinity Cache for launch k + 1 and the HIP-event time (73 us) was a cache number;
+    rocprofv3 of the interleaved kernels read 93-100 us.  With fresh rows both clocks agree."""
     import numpy as np
     import torch
     from castrec_amd import ops as O
     V, D, T = 10_000_000, 256, 512
     table = torch.empty(V, D, device="cuda", dtype=torch.float32).uniform_(-0.01, 0.01)
     rs = np.random.RandomState(0)
+    NW = 3
 
     def timed(f):
-        for _ in range(3):
-            f()
+        for k in range(NW):
+            f(k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            f()
+        for k in range(reps):
+            f(NW + k)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
     M = 128 * T
-    ids = torch.from_numpy(rs.randint(1, V, M).astype(np.int32)).cuda()
+    ids = torch.from_numpy(rs.randint(1, V, (NW + reps, M)).astype(np.int32)).cuda()
     out = torch.empty(M, D, device="cuda")
     pos = torch.randn(T, D, device="cuda")
-    us_a = timed(lambda: O.embed_fwd(ids, table, T, out, D, scale=float(D) ** 0.5, pos_table=pos, mask_ids=ids))
+    us_a = timed(lambda k: O.embed_fwd(ids[k], table, T, out, D, scale=float(D) ** 0.5, pos_table=pos, mask_ids=ids[k]))
     Bq, nc = 4096, 101
-    cand = torch.from_numpy(rs.randint(1, V, (Bq, nc)).astype(np.int32)).cuda()
+    cand = torch.from_numpy(rs.randint(1, V, (NW + reps, Bq, nc)).astype(np.int32)).cuda()
     semb = torch.randn(Bq, D, device="cuda")
     logits = torch.empty(Bq, nc, device="cuda")
-    us_b = timed(lambda: O.test_logits(semb, D, table, cand, Bq, 1, D, logits))
+    us_b = timed(lambda k: O.test_logits(semb, D, table, cand[k], Bq, 1, D, logits))
     rd_a, wr_a = M * (D * 4 + 4), M * D * 4
     rd_b = Bq * nc * (D * 4 + 4)
-    res = dict(table="10M x 256 fp32 (10.24 GB), uniform rows", peak_GBps=8000.0,
+    res = dict(table="10M x 256 fp32 (10.24 GB), uniform rows, a fresh row set per launch", peak_GBps=8000.0, launches_timed=reps,
                embed_fwd=dict(rows=M, us=round(us_a, 1), read_GBps=round(rd_a / us_a / 1e3, 1), read_write_GBps=round((rd_a + wr_a) / us_a / 1e3, 1),
                               read_frac=round(rd_a / us_a / 1e3 / 8000.0, 4), read_write_frac=round((rd_a + wr_a) / us_a / 1e3 / 8000.0, 4)),
                read_only=dict(kernel="cr_test_logits", rows=Bq * nc, us=round(us_b, 1), read_GBps=round(rd_b / us_b / 1e3, 1),
                               read_frac=round(rd_b / us_b / 1e3 / 8000.0, 4)),
                note="MI355X_MICROARCH.md: float4 copy ceiling 6.29 TB/s (79 % of the 8 TB/s spec); random whole-row gathers into "
-                    "registers 5.5-5.8 TB/s.  embed_fwd writes as many bytes as it reads, so its READ rate is bounded by half of what "
-                    "the memory system moves; the read-only form is the one to hold against the >= 70 % read target")
+                    "registers 5.5-5.8 TB/s.  embed_fwd (the training-path gather) writes as many bytes as it reads: read_write_frac is "
+                    "its number to hold against the roof; the read-only form is the one to hold against the >= 70 % READ target")
     del table, out
     torch.cuda.empty_cache()
     return res
@@ -488,7 +531,7 @@ def main():
             achieved = d["flops"] / (d["us"] * 1e-6) / 1e12
         else:
             achieved = d["bytes"] / (d["us"] * 1e-6) / 1e9
-        traffic, mfma_busy, src = pmc_lookup(name, prec)
+        traffic, mfma_busy, src = pmc_lookup(name, prec, config_tag(args))
         roofline = dict(kernel=name, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
                         frac=round(achieved / peak, 5), traffic=traffic, launches_per_step=d["launches"],
                         us_per_launch=round(d["us"] / d["launches"], 2),
@@ -496,8 +539,9 @@ def main():
                         mfma_busy_frac=mfma_busy,
                         note="achieved = algorithmic %s per launch / average HIP-event duration of its %d launches per step "
                              "(eager instrumented pass, 8 steps); peak = fp32-input MFMA (the arithmetic is fp32-grade: f32 MFMA, or bf16 "
-                             "MFMA on hi+lo split operands); traffic = HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB, and "
-                             "mfma_busy_frac = counter-measured matrix-pipe busy share, both from %s"
+                             "MFMA on hi+lo split operands); traffic (HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB) and "
+                             "mfma_busy_frac (matrix-pipe busy share) are NOT measured in this run: they are read from the committed "
+                             "rocprofv3 --pmc summary of this command and workload: %s"
                              % ("flops" if bound == "mfma" else "bytes", d["launches"], src))
         if name.startswith("cr_attn"):
             roofline["executed_flop_frac"] = executed_tile_fraction(host_batches, T)
@@ -507,7 +551,7 @@ def main():
             if n_ in by_name:
                 a = by_name[n_]
                 tf = a["flops"] / (a["us"] * 1e-6) / 1e12
-                tr, mb, _ = pmc_lookup(n_, prec)
+                tr, mb, _ = pmc_lookup(n_, prec, config_tag(args))
                 attn[n_] = dict(us_per_launch=round(a["us"] / a["launches"], 2), launches_per_step=a["launches"], achieved_TFLOPs=round(tf, 2),
                                 frac_of_f32_mfma_peak=round(tf / 157.3, 4), frac_of_bf16_mfma_peak=round(tf / PEAK_BF16_TF, 5),
                                 mfma_busy_frac=mb, traffic=tr)

@@ -47,6 +47,8 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
+            if torch.cuda.is_available():              # gloo over host memory (HostBounce): ranks may share a card
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
     return rank, local_rank, world
 
@@ -191,4 +193,12 @@ class HostBounce:
 
     def sparse_spec(self):
         return self.inner.sparse_spec()
+
+    @property
+    def lazy_adam(self):
+        return getattr(self.inner, "lazy_adam", False)
+
+    def set_lazy_ids(self, ids):
+        if hasattr(self.inner, "set_lazy_ids"):
+            self.inner.set_lazy_ids(ids)
 

@@ -192,6 +192,11 @@ class Engine:
         if attn_precision not in ATTN_PRECISIONS:
             raise ValueError("attn_precision must be one of %s" % sorted(ATTN_PRECISIONS))
         self.attn_precision = attn_precision
+        if attn_precision == "f32" and hp.hidden_units > 64:
+            import warnings
+            warnings.warn("attn_precision='f32' at hidden_units %d leaves the tuned path: the exact-fp32 row phases above 64 columns are "
+                          "the unfused kernels (2.6x slower at the C4 shape, 11x at C5; profiles/r02d_other_shapes.log); the "
+                          "fp32-grade default is 'bf16x3'" % hp.hidden_units, RuntimeWarning, stacklevel=2)
         # row-sparse Adam on the item table (DEVIATION from the reference's dense update, for tables like C5's 10 M rows;
         # castrec.h cr_adam_desc.lazy_ids): off unless asked for
         self.lazy_adam = bool(int(os.environ.get("CASTREC_LAZY_ADAM", "0"))) if lazy_adam is None else bool(lazy_adam)
@@ -1012,6 +1017,10 @@ class Engine:
         self.state[:4].zero_()
         self.state[8:].zero_()
         self.state[4:5].view(torch.int32)[0] = k
+        if getattr(self, "lazy_flags", None) is not None:
+            # row-sparse Adam claims a row with atomicExch(flag, step) != step: a flag left by an earlier run of the same
+            # step number (counter moved back, checkpoint loaded) would read as "already claimed" and skip the row
+            self.lazy_flags.zero_()
 
     def step_number(self):
         """Number of the step the next launch will run (1 + completed optimiser steps)."""

@@ -44,6 +44,13 @@ class _Model(object):
 
     def _train_engine(self, B):
         if self._train is None:
+            # the training engine shares the owner's parameter vector: both must live on the device this process runs on
+            # (under torch.distributed.run the process group -- which selects cuda:LOCAL_RANK -- comes before build_model)
+            cur = torch.device("cuda", torch.cuda.current_device())
+            if self._owner.P.device != cur:
+                raise RuntimeError("model parameters are on %s but the current device is %s: select the device "
+                                   "(castrec_amd.dist.init_from_env / torch.cuda.set_device) before building the model"
+                                   % (self._owner.P.device, cur))
             dp_cfg = getattr(self, "_dp_cfg", None)
             if dp_cfg is not None and dp_cfg[1] > 1:
                 from . import dist as D_
@@ -165,7 +172,11 @@ class _Model(object):
             if tuple(params[n].shape) != shp:
                 raise ValueError("checkpoint %s: %s has shape %s, model expects %s" % (prefix, n, params[n].shape, shp))
         self._owner.load_params(params)
-        if steps > 0 and set(slot_m) == set(want) and set(slot_v) == set(want):
+        have_m, have_v = set(slot_m) == set(want), set(slot_v) == set(want)
+        if (slot_m or slot_v) and not (have_m and have_v):
+            raise ValueError("checkpoint %s holds Adam slots for only part of model %s's variables (m: %d, v: %d of %d)"
+                             % (prefix, self.name, len(slot_m), len(slot_v), len(want)))
+        if have_m and have_v:
             lay = self._owner.layout
             M, V = torch.zeros(lay.n_total), torch.zeros(lay.n_total)
             for n in want:

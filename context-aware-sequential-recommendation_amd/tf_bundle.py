@@ -212,16 +212,23 @@ def load_logical(prefix):
 
 def load_logical_with_slots(prefix):
     """(params, adam_m, adam_v, completed_steps): the variables plus tf.train.AdamOptimizer's slots (`<var>/Adam` = m,
-    `<var>/Adam_1` = v) under the same logical names, and the number of optimiser steps taken, recovered from
-    beta1_power = 0.9 ** t (sasrec.py:120).  Slots missing from the bundle come back as empty dicts / 0."""
+    `<var>/Adam_1` = v) under the same logical names, and the number of optimiser steps taken.
+
+    The step count is the bundle's `global_step` (sasrec.py:119-121 hands it to minimize(), which increments it once per
+    step).  beta1_power is only the fallback: TF1's AdamOptimizer initialises it to beta1 and multiplies it AFTER each
+    step, so after t steps it holds 0.9 ** (t + 1) -- and in fp32 it underflows to exactly 0 after ~980 steps (every run
+    the reference ships ended at global_step 9400 with beta1_power == 0.0).  Slots missing from the bundle come back as
+    empty dicts; a bundle with neither counter gives steps = 0."""
     import math
     raw = load(prefix)
     params = to_logical({k: v for k, v in raw.items() if not _SKIP.search(k)})
     m = to_logical({k[:-len("/Adam")]: v for k, v in raw.items() if k.endswith("/Adam")})
     v = to_logical({k[:-len("/Adam_1")]: a for k, a in raw.items() if k.endswith("/Adam_1")})
     steps = 0
-    if "beta1_power" in raw:
+    if "global_step" in raw:
+        steps = int(np.asarray(raw["global_step"]).reshape(-1)[0])
+    elif "beta1_power" in raw:
         b1p = float(np.asarray(raw["beta1_power"]).reshape(-1)[0])
         if 0.0 < b1p < 1.0:
-            steps = int(round(math.log(b1p) / math.log(0.9)))
+            steps = max(0, int(round(math.log(b1p) / math.log(0.9))) - 1)
     return params, m, v, steps

@@ -79,15 +79,18 @@ def main(argv=None):
     if args.model.lower() not in MODELS:
         print("provide model from", MODELS)
         sys.exit(0)
-    model = build_model(args.model, usernum, itemnum, ratingnum, args)
     # Data parallelism (not in the reference): under `python -m torch.distributed.run --nproc-per-node N
     # main.py ...` every rank runs this same program -- same seed, same sampler stream, --batch_size is the GLOBAL batch --
     # and trains on its rows of each batch; gradients meet over RCCL (castrec_amd.dist).  Rank 0 evaluates, logs and saves.
+    # The process group comes FIRST: init_from_env selects this rank's GPU (torch.cuda.set_device(LOCAL_RANK)), and the
+    # model's parameter vector must be allocated on that device, not on cuda:0 of every rank.
     rank, world = 0, 1
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from castrec_amd import dist as cr_dist
         import torch.distributed as tdist
         rank, _, world = cr_dist.init_from_env(os.environ.get("CASTREC_DIST_BACKEND"))
+    model = build_model(args.model, usernum, itemnum, ratingnum, args)
+    if world > 1:
         model.data_parallel(rank, world)
     sampler = WarpSampler(args, train_corpus(train, usernum, itemnum), usernum, itemnum,
                           batch_size=args.batch_size, maxlen=args.maxlen, n_workers=1)
@@ -143,7 +146,7 @@ def main(argv=None):
                 t_valid = evaluate_valid(model, dataset, args)
                 logger.info('epoch:%d, time: %f(s), valid (NDCG@10: %.4f, HR@10: %.4f), test (NDCG@10: %.4f, HR@10: %.4f)' % (
                     epoch, T, t_valid[0], t_valid[1], t_test[0], t_test[1]))
-                f.write(str(t_valid) + ' ' + str(t_test) + '\n')
+                f.write(str(tuple(float(x) for x in t_valid)) + ' ' + str(tuple(float(x) for x in t_test)) + '\n')   # plain floats, as main.py:238 prints under numpy 1.16
                 f.flush()
                 if world > 1:
                     tdist.barrier()
@@ -151,6 +154,13 @@ def main(argv=None):
     except Exception as e:                                         # main.py:253-257
         logger.error(e)
         rc = 1
+        if world > 1:
+            # the other ranks sit in a barrier (or a collective) this rank will never reach: leave non-zero NOW so that the
+            # launcher tears the peers down instead of letting them wait for the process-group timeout
+            f.close()
+            sampler.close()
+            logging.shutdown()
+            os._exit(1)
     f.close()
     sampler.close()
     if rc == 0:

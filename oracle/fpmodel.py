@@ -189,12 +189,52 @@ def multihead_attention(queries, keys, P, pfx, num_heads, rate, drop, site):
 # as it hands over its dropout masks: the few units that sit within 1e-5 of the kink would otherwise flip on one side
 # only and change a row's gradient by a finite amount.  None (the default) = plain relu.
 RELU_GATES = None
+# Audit of a hand-over (set by handed_over_gates): per site (units compared, units whose handed-over gate differs from this
+# oracle's own `pre > 0`, largest |pre| among those, largest |pre| of the site).  RELU_CARE[site] marks the units whose gate
+# matters at all (a unit dropped by the dropout that follows, or a masked row, has no gradient whatever its gate).
+RELU_AUDIT = None
+RELU_CARE = None
 
 
 def _relu(x, site):
     if RELU_GATES is not None and site in RELU_GATES:
-        return x * RELU_GATES[site].reshape(x.shape).to(x.dtype)
+        g = RELU_GATES[site].reshape(x.shape)
+        if RELU_AUDIT is not None:
+            xd = x.detach()
+            care = RELU_CARE[site].reshape(x.shape) if (RELU_CARE is not None and site in RELU_CARE) else torch.ones_like(g)
+            mism = ((xd > 0) != g) & care
+            k = int(mism.sum())
+            RELU_AUDIT[site] = (int(care.sum()), k, float(xd.abs()[mism].max()) if k else 0.0, float(xd.abs().max()))
+        return x * g.to(x.dtype)
     return torch.relu(x)
+
+
+class handed_over_gates(object):
+    """with handed_over_gates(gates, care) as audit: ... -- the oracle runs with another implementation's ReLU gates; on
+    exit the hand-over is checked (unless check=False: plain-bf16 runs, whose activations differ by 1e-2): the gates may
+    differ from the oracle's own `pre > 0` only on a vanishing set of units that sit AT the kink -- fewer than `max_share`
+    of a site's units (at least `min_units` allowed) and each with |pre| < `near` * max |pre|.  Anything else means the
+    hand-over is hiding a real difference, and the parity claim of the test would be void."""
+
+    def __init__(self, gates, care=None, check=True, max_share=1e-3, min_units=2, near=1e-4):
+        self.gates, self.care, self.check = gates, care, check
+        self.max_share, self.min_units, self.near = max_share, min_units, near
+        self.audit = {}
+
+    def __enter__(self):
+        global RELU_GATES, RELU_AUDIT, RELU_CARE
+        RELU_GATES, RELU_AUDIT, RELU_CARE = self.gates, (self.audit if self.gates is not None else None), self.care
+        return self.audit
+
+    def __exit__(self, et, ev, tb):
+        global RELU_GATES, RELU_AUDIT, RELU_CARE
+        RELU_GATES, RELU_AUDIT, RELU_CARE = None, None, None
+        if et is None and self.check and self.gates is not None:
+            assert set(self.audit) == set(self.gates), "gates handed over for sites the graph does not have: %s" % sorted(set(self.gates) - set(self.audit))
+            for site, (n, k, worst, top) in self.audit.items():
+                assert k <= max(self.min_units, self.max_share * n), "%s: %d of %d handed-over ReLU gates differ from the oracle's own" % (site, k, n)
+                assert worst <= self.near * top, "%s: a differing gate sits at |pre| = %.3e, not at the kink (max |pre| %.3e)" % (site, worst, top)
+        return False
 
 
 def feedforward(x, P, pfx, rate, drop, site):

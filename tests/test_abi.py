@@ -42,12 +42,24 @@ def test_struct_sizes_match_c_layout(tmp_path):
     pairs = [("cr_rng", L.Rng), ("cr_embed_desc", L.EmbedDesc), ("cr_embed_bwd_desc", L.EmbedBwdDesc), ("cr_ln_desc", L.LnDesc),
              ("cr_ln_bwd_desc", L.LnBwdDesc), ("cr_gemm_desc", L.GemmDesc), ("cr_wgrad_desc", L.WgradDesc),
              ("cr_elt_desc", L.EltDesc), ("cr_attn_desc", L.AttnDesc), ("cr_attn_bwd_desc", L.AttnBwdDesc),
-             ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
+             ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_block_tail_desc", L.BlockTailDesc),
+             ("cr_stack_desc", L.StackDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
+    # every structure the header declares has a mirror in this list
+    hdr = open(os.path.join(ROOT, "include", "castrec.h")).read()
+    declared = set(re.findall(r"\}\s*(cr_[a-z_0-9]+)\s*;", hdr))
+    assert declared == {c for c, _ in pairs}, declared ^ {c for c, _ in pairs}
+    # sizeof AND the offset of every field (same field names on both sides)
+    probes = []
+    for cname, ct in pairs:
+        probes.append(("sizeof(%s)" % cname, ctypes.sizeof(ct), cname))
+        for fname, _ in ct._fields_:
+            probes.append(("offsetof(%s, %s)" % (cname, fname), getattr(ct, fname).offset, cname + "." + fname))
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "castrec.h"\nint main(void){' +
-                   "".join('printf("%%zu\\n", sizeof(%s));' % c for c, _ in pairs) + "return 0;}\n")
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "castrec.h"\nint main(void){' +
+                   "".join('printf("%%zu\\n", (size_t)%s);' % e for e, _, _ in probes) + "return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    for (cname, ct), n in zip(pairs, sizes):
-        assert ctypes.sizeof(ct) == n, (cname, ctypes.sizeof(ct), n)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert len(got) == len(probes)
+    for (_, want, what), n in zip(probes, got):
+        assert want == n, (what, want, n)

@@ -31,6 +31,17 @@ def hyper(E, D=D, H=1):
     return E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=10, seed=4)
 
 
+def perturb_start(eng):
+    """Moves the parameters off the TensorFlow initial point (seeded, the same on every engine of a test).  At gamma = 1,
+    beta = 0, zero biases, every row whose context embedding is the zero_pad row (time bin 0: cast_1.py:30-38) stays EXACTLY
+    zero through all blocks, each LayerNorm sees variance 0 and its backward multiplies by 1 / sqrt(1e-8) = 1e4: the fp64
+    oracle has d loss / d ctx_time.0.ln1.beta = 3e13 at that start (D = 20 and D = 128 alike), and Adam on such gradients
+    sits on sign boundaries that re-associated sums flip.  With beta off zero only the first LayerNorm of a zero row is
+    degenerate, and its input gradient goes to the discarded zero_pad row."""
+    g = torch.Generator().manual_seed(5)
+    eng.P.add_(0.05 * torch.randn(eng.P.numel(), generator=g).to(eng.P.device))
+
+
 def _worker(rank, world, port, q, items=ITEMS, sparse=False, D=D, H=1):
     import torch.distributed as dist
     import castrec_amd  # noqa: F401
@@ -42,6 +53,7 @@ def _worker(rank, world, port, q, items=ITEMS, sparse=False, D=D, H=1):
     hp = hyper(E, D, H)
     hp.seed = 4                                                # same dropout key on every rank ...
     eng = E.Engine("cast_1", USERS, items, hp, hi - lo, training=True, n_slabs=8, batch_global=B, row_offset=lo * T)
+    perturb_start(eng)
     if rank != 0:
         eng.P.mul_(1.5)                                        # ... but a different start: the wrapper must broadcast rank 0's
     rep = HostBounce(EngineReplica(eng, use_graph=True))
@@ -77,6 +89,7 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
         p.join(timeout=60)
         assert p.exitcode == 0
     one = E.Engine("cast_1", USERS, items, hyper(E, D, H), B, training=True, n_slabs=8)
+    perturb_start(one)
     for s in range(STEPS):
         one.train_step(*make_batch(s, items))
     torch.cuda.synchronize()
@@ -94,13 +107,6 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
         # element nearly cancel, m / (sqrt(v) + eps) turns the re-association-level ABSOLUTE gradient difference into a
         # relative one (seen: 2 elements of the 5001 x 20 item table at 3e-6 and 2e-5, each moved 4e-4 in 3 steps)
         d = np.abs(res[0][1][k] - ref[k])
-        if D == 128:
-            # four blocks of D = 128 at this random start have bias-like gradients of 1e7 ... 1e15 (rows of near-zero variance
-            # behind LayerNorms): which elements sit on an Adam sign boundary then changes from run to run with the order of
-            # the table's float atomics.  99 % of a tensor agree to 1e-4 (medians are ~1e-6), none moves more than the three steps allow; the
-            # sharp statement for these kernels is test_row_buffers_do_not_depend_on_the_sharding below (bitwise).
-            assert np.quantile(d, 0.99) <= 1e-4 and d.max() <= 3.5e-3, (k, float(np.quantile(d, 0.99)), float(d.max()))
-            continue
         assert d.max() <= 1e-4 and (d > 5e-6).sum() <= 1 + 1e-4 * d.size, (k, float(d.max()), int((d > 5e-6).sum()))
     loss_one = one.loss_auc()[0]
     st = res[0][2]

@@ -73,22 +73,37 @@ TOL = {"f32": dict(grad=2e-4, act=2e-5, loss=2e-5, auc=1e-6), "bf16x3": dict(gra
 
 
 def engine_relu_gates(eng, B, T, drop):
-    """The ReLU gates of an engine's last forward, by the oracle's site names (fpmodel.RELU_GATES): read from the stored
-    post-ReLU activations (FFN hidden: post-dropout, so a dropped unit's gate is unknown -- and irrelevant, its mask is 0)."""
-    gates = {}
+    """(gates, care): the ReLU gates of an engine's last forward, by the oracle's site names (fpmodel.RELU_GATES): read from
+    the stored post-ReLU activations (FFN hidden: post-dropout, so a dropped unit's gate is unknown -- and irrelevant, its
+    mask is 0: `care` is False there, and fpmodel.handed_over_gates audits the rest against the oracle's own pre > 0)."""
+    gates, care = {}, {}
     for name, buf in eng._bufs.items():
         if name.endswith(".hid"):
             site = name[:-4]                                    # "trunk.0"
             g = buf > 0
             if drop is not None:
-                g = g | ~drop(site + ".ffn1", (B * T, buf.shape[1])).reshape(B * T, -1).to(g.device)
+                kept = drop(site + ".ffn1", (B * T, buf.shape[1])).reshape(B * T, -1).to(g.device)
+                g = g | ~kept
+                care[site + ".relu"] = kept.reshape(B, T, -1).cpu()
             gates[site + ".relu"] = g.reshape(B, T, -1).cpu()
     if "mlp.h" in eng._bufs:
         gates["mlp.relu1"] = (eng._bufs["mlp.h"] > 0).reshape(B, T, -1).cpu()
         outb = eng._bufs["seq_emb"] if eng.model in ("cast_5", "cast_6") else eng._bufs["x0"]
         rowlive = (eng.ids["seq"] != 0).reshape(B * T, 1) if eng.model == "cast_9" else torch.ones(B * T, 1, dtype=torch.bool, device=outb.device)
         gates["mlp.relu2"] = ((outb > 0) | ~rowlive).reshape(B, T, -1).cpu()     # cast_9 masks the rows after the ReLU (their gradient is 0)
-    return gates
+        care["mlp.relu2"] = rowlive.expand(B * T, outb.shape[1]).reshape(B, T, -1).cpu()
+    return gates, care
+
+
+def oracle_with_engine_gates(eng, B, T, drop, prec, fn):
+    """fn() = the oracle run.  f32: the oracle's own gates.  Split precision: the engine's gates, audited (differences only
+    at the kink, on < 1e-3 of the units: fpmodel.handed_over_gates).  Plain bf16 (activations differ by 1e-2; the
+    throughput option, not a parity claim): handed over without the audit."""
+    if prec == "f32":
+        return fn()
+    gates, care = engine_relu_gates(eng, B, T, drop)
+    with fm.handed_over_gates(gates, care, check=(prec == "bf16x3")):
+        return fn()
 
 
 SEED_SHIFT = 0          # tools: shift to survey other draws
@@ -134,11 +149,7 @@ def test_model_grads_and_adam_match_oracle(E, model, rate, fused, prec):
         eng.set_batch(seq, pos, neg, time, hours, days)
         eng.launch_step(apply=False)
         torch.cuda.synchronize()
-        fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None     # see _other_shapes
-        try:
-            out, G = fm.loss_and_grads(model, P, ohp, batch, drop)
-        finally:
-            fm.RELU_GATES = None
+        out, G = oracle_with_engine_gates(eng, B, T, drop, prec, lambda: fm.loss_and_grads(model, P, ohp, batch, drop))   # see _other_shapes
         st = eng.state.cpu().numpy()
         n = st[2]
         assert n == float(out["istarget"].sum())
@@ -331,7 +342,10 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
         assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1) * gmax, k
 
 
-def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None):
+def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False):
+    """kink_free: the feed-forward pre-activations are pushed away from the ReLU kink (small W1, biases of +-1 alternating by
+    unit), the oracle runs with ITS OWN gates (no hand-over), and the test first proves that the engine's gates are the
+    same everywhere: gradient parity of the split-precision kernels with nothing taken from the engine but the dropout masks."""
     tol = TOL[prec]
     rs = np.random.RandomState(D + T)
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
@@ -342,6 +356,13 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9,
     assert eng.fused == (D <= 64)
     P = fm.init_params(model, 9, itemnum, ohp, seed=8)
     P = {k: v + 0.05 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
+    if kink_free:
+        assert not any(k.startswith("mlp.") for k in P)
+        for k in P:
+            if k.endswith(".w1"):
+                P[k] = 0.1 * P[k]
+            elif k.endswith(".b1"):
+                P[k] = torch.where(torch.arange(P[k].numel()) % 2 == 0, 1.0, -1.0).to(P[k].dtype).reshape(P[k].shape)
     eng.load_params(P)
     P = {k: v.double().cpu() for k, v in eng.get_params().items()}
     seq, pos, neg, time, hours, days = make_batch(rs, B, T, itemnum, max_bins)
@@ -357,11 +378,16 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9,
     drop = oracle_drop(E, 11, 1, 0.1, B, T, H)
     # split-precision attention perturbs activations by ~1e-5: the oracle takes the engine's ReLU gates like it takes its
     # dropout masks, so that units within 1e-5 of the kink do not flip on one side only (see fpmodel.RELU_GATES)
-    fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None
-    try:
-        out, G = fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), drop)
-    finally:
-        fm.RELU_GATES = None
+    run = lambda: fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), drop)
+    if kink_free:
+        gates, care = engine_relu_gates(eng, B, T, drop)
+        with fm.handed_over_gates(gates, care, max_share=0.0, min_units=0) as audit:      # premise: not ONE gate differs ...
+            run()
+        assert audit and all(a[0] > 0 for a in audit.values())
+        assert all(float(g.float().mean()) > 0.2 and float(g.float().mean()) < 0.8 for g in gates.values())   # ... on a real on / off mix
+        out, G = run()                                                                    # the oracle on its own gates
+    else:
+        out, G = oracle_with_engine_gates(eng, B, T, drop, prec, run)
     st = eng.state.cpu().numpy()
     assert st[0] / st[2] == pytest.approx(float(out["loss"]), rel=tol["loss"])
     got = eng.grads()
@@ -380,6 +406,22 @@ def test_config_c3_long_tail_vocabulary(E):
     """BASELINE configs[2]: Beauty, hidden 64, 2 heads, maxlen 50, the 57 289-item vocabulary with Zipf-distributed ids
     (hot rows: the float-atomic scatters of the embedding backward and of the head see heavy collisions)."""
     _other_shapes(E, "sasrec", 64, 2, 50, 2, B=128, prec="bf16x3", itemnum=57289, zipf=1.1)
+
+
+@pytest.mark.parametrize("model,D,H,T,B", [("cast_1", 50, 1, 200, 161),      # the headline kernels' non-PAIR forms (D = 50 constant, 13 tiles)
+                                            ("sasrec", 40, 1, 104, 170),      # generic hidden size, 7 tiles (NKT = 8 instantiation)
+                                            ("sasrec", 64, 2, 50, 163)])      # two heads of 32 columns
+def test_stack_forward_with_one_workgroup_per_sequence(E, model, D, H, T, B):
+    """More than 160 sequences: cr_stack_fwd gives a sequence ONE workgroup and runs all blocks in one launch (two tiles per
+    wave) -- the template family every other model test (B <= 130) never reaches (`python main.py --batch_size 256` does)."""
+    _other_shapes(E, model, D, H, T, 2, B=B, prec="bf16x3", itemnum=300)
+
+
+@pytest.mark.parametrize("D,H,T", [(50, 1, 200),      # register-layout kernels (cr_stack*.hip)
+                                   (128, 4, 40)])     # wide row kernels (cr_wide.hip)
+def test_split_precision_gradients_without_gate_handover(E, D, H, T):
+    """Gradient parity of the bf16x3 kernel families against the oracle's OWN ReLU gates."""
+    _other_shapes(E, "sasrec", D, H, T, 2, B=3, prec="bf16x3", kink_free=True)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
@@ -545,11 +587,8 @@ def test_trained_reference_weights_at_the_headline_shape(E, prec):
     eng.launch_step(apply=False)
     torch.cuda.synchronize()
     drop = oracle_drop(E, 5, 1, 0.2, B, T, H)
-    fm.RELU_GATES = engine_relu_gates(eng, B, T, drop) if prec != "f32" else None         # see _other_shapes
-    try:
-        o2, G = fm.loss_and_grads("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros), drop)
-    finally:
-        fm.RELU_GATES = None
+    o2, G = oracle_with_engine_gates(eng, B, T, drop, prec,
+                                     lambda: fm.loss_and_grads("cast_1", Pd, ohp, fm.to_batch(seq, pos, neg, time, zeros, zeros), drop))
     st = eng.state.cpu().numpy()
     assert st[0] / st[2] == pytest.approx(float(o2["loss"]), rel=tol["loss"])
     got = eng.grads()

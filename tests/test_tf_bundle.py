@@ -125,3 +125,39 @@ def test_variable_names_of_the_models_without_a_shipped_checkpoint(model):
     got = sorted(m for m in mapped if m is not None)
     assert got == sorted(lay.logical_names())
     assert len(set(got)) == len(got)
+
+
+def test_slots_and_step_count_of_a_shipped_run(tmp_path):
+    """The runs the reference ships ended at global_step 9400 with beta1_power underflowed to exactly 0.0 in fp32 (0.9 ** t
+    is below the smallest subnormal after ~980 steps): the step count must come from global_step (sasrec.py:119-121), and
+    the complete Adam slots must be returned with it -- saver.restore semantics (main.py:165-175)."""
+    src = os.path.join(HERE, "golden", "tf_index", "cast_5.index")
+    idx = tfb.read_index(src)
+    total = max(e["offset"] + e["size"] for e in idx.values())
+    raw = np.zeros(total, np.uint8)
+    f32 = raw.view("<f4")
+    for name, e in idx.items():
+        if e["dtype"] == 1 and name.endswith("/Adam"):
+            f32[e["offset"] // 4:(e["offset"] + e["size"]) // 4] = 0.25
+        elif e["dtype"] == 1 and name.endswith("/Adam_1"):
+            f32[e["offset"] // 4:(e["offset"] + e["size"]) // 4] = 0.5
+    gs = idx["global_step"]
+    raw[gs["offset"]:gs["offset"] + gs["size"]] = np.array([9400], "<i8" if gs["size"] == 8 else "<i4").view(np.uint8)
+    b1 = idx["beta1_power"]
+    f32[b1["offset"] // 4] = 0.0
+    prefix = str(tmp_path / "model.ckpt")
+    shutil.copyfile(src, prefix + ".index")
+    raw.tofile(prefix + ".data-00000-of-00001")
+    params, m, v, steps = tfb.load_logical_with_slots(prefix)
+    assert steps == 9400
+    assert set(m) == set(params) == set(v) and len(params) == 68
+    assert all(float(a.min()) == 0.25 for a in m.values()) and all(float(a.min()) == 0.5 for a in v.values())
+
+
+def test_step_count_falls_back_to_beta1_power(monkeypatch):
+    """Without global_step: TF1's AdamOptimizer starts beta1_power at beta1 and multiplies it after every step, so after t
+    steps it holds 0.9 ** (t + 1)."""
+    for t in (0, 1, 7, 300):
+        fake = {"SASRec/ln/Variable": np.zeros(4, np.float32), "beta1_power": np.float32(0.9) ** np.float32(t + 1)}
+        monkeypatch.setattr(tfb, "load", lambda prefix, fake=fake: fake)
+        assert tfb.load_logical_with_slots("x")[3] == t

@@ -40,6 +40,13 @@ fe = agg(os.path.join(src, "p_fetch", "*", "*_counter_collection.csv"), "FETCH_S
 wr = agg(os.path.join(src, "p_write", "*", "*_counter_collection.csv"), "WRITE_SIZE")
 mf = {c: agg(os.path.join(src, "p_mfma", "*", "*_counter_collection.csv"), c)
       for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES")}
+SQ_PASSES = {"p_inst": ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                        "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES"),
+             "p_stall": ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                         "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
+             "p_misc": ("SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_IFETCH", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_ACTIVE_INST_SCA",
+                        "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC", "SQ_BUSY_CU_CYCLES")}
+sq = {c: agg(os.path.join(src, d, "*", "*_counter_collection.csv"), c) for d, cs in SQ_PASSES.items() for c in cs}
 dur = {}
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -58,8 +65,30 @@ for k in fe:
     if "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"]:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over all 1024 SIMDs
         e["mfma_busy_frac"] = round(e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+    # instruction mix and stall shares (tools/prof.sh sq): per-launch sums over all waves.  SQ_WAVE_CYCLES / SQ_WAIT_* /
+    # SQ_ACTIVE_INST_* count quad-cycles of wave lifetime (MI355X_MICROARCH.md cycle-constants table): shares of the
+    # wave-cycles are what a wave spends parked (s_waitcnt / barrier), stalled at issue, or issuing
+    for c in sq:
+        if k in sq[c]:
+            e[c] = round(sq[c][k][0])
+    if e.get("SQ_INSTS_MFMA"):
+        e["valu_per_mfma"] = round((e.get("SQ_INSTS_VALU", 0) - e["SQ_INSTS_MFMA"]) / e["SQ_INSTS_MFMA"], 2)   # SQ_INSTS_VALU counts MFMAs too
+        e["lds_per_mfma"] = round(e.get("SQ_INSTS_LDS", 0) / e["SQ_INSTS_MFMA"], 2)
+        e["salu_per_mfma"] = round(e.get("SQ_INSTS_SALU", 0) / e["SQ_INSTS_MFMA"], 2)
+    wc = e.get("SQ_WAVE_CYCLES")
+    if wc and "SQ_WAIT_ANY" in e:
+        e["share_wait_any"] = round(e["SQ_WAIT_ANY"] / wc, 4)
+        e["share_wait_inst_any"] = round(e["SQ_WAIT_INST_ANY"] / wc, 4)
+        e["share_wait_inst_lds"] = round(e["SQ_WAIT_INST_LDS"] / wc, 4)
+        e["share_active_inst_any"] = round(e["SQ_ACTIVE_INST_ANY"] / wc, 4)
+        e["share_active_inst_valu"] = round(e["SQ_ACTIVE_INST_VALU"] / wc, 4)
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_bank_conflict_share"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0) / e["SQ_LDS_IDX_ACTIVE"], 4)
     summary[k] = e
 with open(os.path.join(out, tag + "_pmc_summary.json"), "w") as fjson:
     json.dump(summary, fjson, indent=1, sort_keys=True)
 for k, e in sorted(summary.items(), key=lambda kv: -kv[1].get("avg_ns", 0) * kv[1].get("calls", 0)):
-    print("%-34s avg %8.1f us  traffic %7.2f MB  mfma_busy %s" % (k[:34], e.get("avg_ns", 0) / 1e3, e["hbm_traffic_bytes"] / 1e6, e.get("mfma_busy_frac")))
+    print("%-34s avg %8.1f us  traffic %7.2f MB  mfma_busy %s  valu/mfma %s  lds/mfma %s  wait_any %s  wait_inst %s (lds %s)  issuing %s  lds_conflict %s"
+          % (k[:34], e.get("avg_ns", 0) / 1e3, e["hbm_traffic_bytes"] / 1e6, e.get("mfma_busy_frac"), e.get("valu_per_mfma"), e.get("lds_per_mfma"),
+             e.get("share_wait_any"), e.get("share_wait_inst_any"), e.get("share_wait_inst_lds"), e.get("share_active_inst_any"),
+             e.get("lds_bank_conflict_share")))
