@@ -40,7 +40,7 @@ def build(force=False, verbose=False, timeline=False):
     lib = LIB_TL if timeline else LIB
     flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else []) + os.environ.get("CASTREC_EXTRA_FLAGS", "").split()
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
-    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"),
+    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"), os.path.join(CSRC, "cr_rbwd.hpp"),
                os.path.join(ROOT, "include", "castrec.h")]
     objs, jobs = [], []
     for s in SOURCES:

@@ -58,46 +58,6 @@ struct BfGeom {
 #define BT_TS(slot) do { } while (0)
 #endif
 
-// Register fragment of the wave's own 16-row tile straight from global memory (operand with k = head dim):
-// lane (li, lg) holds row grow0 + li, columns 32 ks + 8 lg + j.  Issue early, finish (mask, split) at first use.
-template <int NKS>
-struct GFrag { float v[NKS][8]; };
-template <int NKS>
-__device__ __forceinline__ void gfrag_issue(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const bool rok = li < nvalid;
-    const int grow = grow0 + (rok ? li : 0);
-    const float* p = src + (size_t)grow * ld + hoff;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) item_issue(f.v[ks], p, 32 * ks + 8 * lg, d, item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d));
-}
-template <int NKS>
-__device__ __forceinline__ void gfrag_mask(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const bool rok = li < nvalid;
-    const int grow = grow0 + (rok ? li : 0);
-    bool any_fix = false;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const bool fix = item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d);
-        item_mask(f.v[ks], 32 * ks + 8 * lg, d, rok, fix);
-        any_fix |= fix;
-    }
-    if (__builtin_expect(grow0 + 16 >= M && __any(any_fix ? 1 : 0), 0)) {        // wave-uniform, true for one tile of the grid
-        const float* p = src + (size_t)grow * ld + hoff;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            if (item_fix(rok, grow == M - 1, 32 * ks + 8 * lg, d)) item_refill(f.v[ks], p, 32 * ks + 8 * lg, d);
-    }
-}
-template <bool SPLIT, int NKS>
-__device__ __forceinline__ void gfrag_finish(GFrag<NKS>& f, const float* src, int ld, int grow0, int hoff, int nvalid, int d, int M,
-                                             bf8 (&hi)[NKS], bf8 (&lo)[NKS]) {
-    gfrag_mask<NKS>(f, src, ld, grow0, hoff, nvalid, d, M);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) split8<SPLIT>(f.v[ks], hi[ks], lo[ks]);
-}
-
 // Stage rows [crow0, crow0 + nrows) of two [T, d] head blocks into their LDS images (chunk-relative rows).
 // An item is (row, 16-byte chunk); the 4 x U loads of a batch are issued before the first conversion
 // (U = 4: the 208 x 8 items of the headline shape are ONE batch for 512 threads, one memory latency).

@@ -77,14 +77,17 @@ def engine_relu_gates(eng, B, T, drop):
     the stored post-ReLU activations (FFN hidden: post-dropout, so a dropped unit's gate is unknown -- and irrelevant, its
     mask is 0: `care` is False there, and fpmodel.handed_over_gates audits the rest against the oracle's own pre > 0)."""
     gates, care = {}, {}
+    live = (eng.ids["seq"] != 0).reshape(B * T, 1)              # every block ends with `*= mask` (sasrec.py:83): a padded row has no gradient
     for name, buf in eng._bufs.items():
         if name.endswith(".hid"):
             site = name[:-4]                                    # "trunk.0"
             g = buf > 0
+            c = live.expand(B * T, buf.shape[1])
             if drop is not None:
                 kept = drop(site + ".ffn1", (B * T, buf.shape[1])).reshape(B * T, -1).to(g.device)
                 g = g | ~kept
-                care[site + ".relu"] = kept.reshape(B, T, -1).cpu()
+                c = c & kept
+            care[site + ".relu"] = c.reshape(B, T, -1).cpu()
             gates[site + ".relu"] = g.reshape(B, T, -1).cpu()
     if "mlp.h" in eng._bufs:
         gates["mlp.relu1"] = (eng._bufs["mlp.h"] > 0).reshape(B, T, -1).cpu()
