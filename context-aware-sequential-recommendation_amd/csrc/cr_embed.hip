@@ -128,6 +128,13 @@ extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
 #define EMB_MAXC 8   // columns per lane: D <= 512
 #define EMB_BW 16    // waves per workgroup: a wave's rows are a serial chain of load -> atomics passes (4 waves x 8 passes at B = 128
                      // made the 200 workgroups of config C4 take 29 us; 16 waves x 2 passes: the chip has the wave slots)
+
+// gradient of the forward's output at element idx: f.out (+ out2: a gradient that arrives as two partials)
+__device__ __forceinline__ float dout_at(const cr_embed_bwd_desc& bd, size_t idx) {
+    const float v = bd.f.out[idx];
+    return bd.out2 ? v + bd.out2[idx] : v;
+}
+
 __global__ __launch_bounds__(64 * EMB_BW) void k_embed_bwd(cr_embed_bwd_desc bd) {
     const cr_embed_desc& d = bd.f;
     __shared__ float red[EMB_BW][64 * EMB_MAXC];
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(64 * EMB_BW) void k_embed_bwd(cr_embed_bwd_desc bd)
 #pragma unroll
             for (int i = 0; i < EMB_MAXC; ++i) {
                 const int c = lane + 64 * i;
-                g[u][i] = (c < d.D) ? d.out[(size_t)mm[u] * d.ld_out + d.col_off + c] : 0.0f;
+                g[u][i] = (c < d.D) ? dout_at(bd, (size_t)mm[u] * d.ld_out + d.col_off + c) : 0.0f;
             }
         }
 #pragma unroll
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
                 for (int i = 0; i < 4; ++i) {
                     const int c = l + 16 * i;
                     if (c < d.D) {
-                        const float gv = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep;
+                        const float gv = dout_at(bd, (size_t)m * d.ld_out + d.col_off + c) * keep;
                         bd.d_addend[(size_t)m * d.ld_add + c] =
                             drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, gv);
                     }
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
                         const int r = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         rr[k] = r;
-                        g[k] = col ? d.out[(size_t)(h0 + r) * d.ld_out + d.col_off + lane] : 0.0f;
+                        g[k] = col ? dout_at(bd, (size_t)(h0 + r) * d.ld_out + d.col_off + lane) : 0.0f;
                         cnt = k + 1;
                     } else {
                         rr[k] = 0;
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_small(cr_embed_bwd_desc bd) {
         const float keep_row = (d.mask_ids && d.mask_ids[m] == 0) ? 0.0f : 1.0f;
         const bool skip_table = (d.zero_pad && id == 0);
         for (int c = lane; c < d.D; c += 64) {
-            float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
+            float g = dout_at(bd, (size_t)m * d.ld_out + d.col_off + c) * keep_row;
             g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
             if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
             if (!skip_table) atomicAdd(&tab[id * d.D + c], g * d.scale);
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_rows16(cr_embed_bwd_desc bd) 
         for (int i = 0; i < 4; ++i) {
             const int c = l + 16 * i;
             if (c < d.D) {
-                float g = d.out[(size_t)m * d.ld_out + d.col_off + c] * keep_row;
+                float g = dout_at(bd, (size_t)m * d.ld_out + d.col_off + c) * keep_row;
                 g = drop_apply(dc, (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c, g);
                 if (bd.d_addend) bd.d_addend[(size_t)m * d.ld_add + c] = g;
                 if (!skip_table && g != 0.0f) atomicAdd(bd.table_grad + (size_t)id * d.D + c, g * d.scale);

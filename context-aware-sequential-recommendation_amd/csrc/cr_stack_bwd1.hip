@@ -323,3 +323,747 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     }
     (void)MD;
 }
+
+// ---- the embedding backward of a partial of dx, phase-2 half: g = partial * mask * keep / (1 - rate) in the registers ----
+// (cr_embed_bwd's recipe; the rows then wait in `buf` -- d_addend where the graph has one, else the dx buffer -- for phase 3)
+__device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4], int m, bool rok, int D) {
+    const cr_embed_desc& e = a.sc.f;
+    const DropCtx dce = drop_ctx(e.drop);
+    const int lg = lane_now() >> 4;
+    const int mk = e.mask_ids ? e.mask_ids[m] : 1;
+    const float kf = (rok && mk != 0) ? 1.0f : 0.0f;
+    const uint32_t eb = ((e.drop.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + dce.key;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = dxl[ct][r] * kf;
+            if (dce.on) v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
+            dxl[ct][r] = v;
+        }
+}
+// phase-3 half: the waiting rows of sequence n, one row per step, lane = column: one contiguous float-atomic burst per table row
+__device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* buf, int n, int D) {
+    if (!a.sc.table_grad && !a.sc.pos_grad) return;
+    const cr_embed_desc& e = a.sc.f;
+    const int wave = threadIdx.x >> 6, col = threadIdx.x & 63, T = a.T;
+    for (int t0 = 16 * wave; t0 < T; t0 += 16 * SB_WAVES) {
+        const int nr = min(16, T - t0);
+#pragma unroll 4
+        for (int r = 0; r < nr; ++r) {
+            const int m = n * T + t0 + r;
+            const int id = e.ids[m];
+            if (col < D) {
+                const float g = buf[(size_t)m * D + col];
+                if (a.sc.table_grad && !(e.zero_pad && id == 0)) atomicAdd(a.sc.table_grad + (size_t)id * D + col, g * e.scale);
+                if (a.sc.pos_grad) atomicAdd(a.sc.pos_grad + (size_t)(m % e.T) * D + col, g);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// Q side, phases 2 and 3: query-owner pass (dQ), LN1 + Q projection backward, dWq
+// =====================================================================================================
+// K rows natural, V rows in the k order of layout R (w_put_perm's column map), hi (+ lo) images; the additive key bias
+template <bool SPLIT>
+__device__ __forceinline__ void b1_stage_kv(unsigned char* smem, float* kb, const B1Args& a, int base_row, int T16, int D, int M) {
+    typedef B1Lds<SPLIT> L;
+    const cr_attn_desc& d = a.ad;
+    __bf16* Kh = reinterpret_cast<__bf16*>(smem);
+    __bf16* Vh = reinterpret_cast<__bf16*>(smem + L::MATB);
+    const int T = a.T, total = T16 * 8;
+    constexpr int U = 4;
+    const bool wg_has_last = base_row + T == M;          // only the last sequence can meet the matrix's last row
+    const int t0 = threadIdx.x;
+    const float kv0 = d.k_valid[base_row + min(t0, T - 1)];
+    for (int i0 = threadIdx.x; i0 < total; i0 += SB_NT * U) {
+        float va[U][8], vb[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int item = min(i0 + u * SB_NT, total - 1);
+            const int r = item >> 3, ch = item & 7;
+            const bool rok = r < T;
+            const int grow = base_row + (rok ? r : 0);
+            const bool fix = item_fix(rok, grow == M - 1, 8 * ch, D);
+            item_issue(va[u], d.K + (size_t)grow * d.ld, 8 * ch, D, fix);
+            item_issue(vb[u], d.V + (size_t)grow * d.ld, 8 * ch, D, fix);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * SB_NT < total) {
+                const int item = i0 + u * SB_NT;
+                const int r = item >> 3, ch = item & 7;
+                const bool rok = r < T;
+                const bool fix = wg_has_last && item_fix(rok, r == T - 1, 8 * ch, D);
+                item_mask(va[u], 8 * ch, D, rok, fix);
+                item_mask(vb[u], 8 * ch, D, rok, fix);
+                if (__builtin_expect(wg_has_last && fix, 0)) {           // one thread of the grid
+                    item_refill(va[u], d.K + (size_t)(M - 1) * d.ld, 8 * ch, D);
+                    item_refill(vb[u], d.V + (size_t)(M - 1) * d.ld, 8 * ch, D);
+                }
+                bf8 h, l;
+                split8<SPLIT>(va[u], h, l);
+                const int o = img_off<2>(r, ch);
+                *reinterpret_cast<bf8*>(Kh + o) = h;
+                if (SPLIT) *reinterpret_cast<bf8*>(Kh + B1_FSTR + o) = l;
+                split8<SPLIT>(vb[u], h, l);
+                const int ks = ch >> 2, c4 = ch & 3, hh = c4 >> 1, lga = 2 * (c4 & 1);
+                const int oa = img_off<2>(r, 4 * ks + lga) + 4 * hh, ob = img_off<2>(r, 4 * ks + lga + 1) + 4 * hh;
+                *reinterpret_cast<bf4*>(Vh + oa) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
+                *reinterpret_cast<bf4*>(Vh + ob) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
+                if (SPLIT) {
+                    *reinterpret_cast<bf4*>(Vh + B1_FSTR + oa) = __builtin_shufflevector(l, l, 0, 1, 2, 3);
+                    *reinterpret_cast<bf4*>(Vh + B1_FSTR + ob) = __builtin_shufflevector(l, l, 4, 5, 6, 7);
+                }
+            }
+        }
+    }
+    if (t0 < T16) kb[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;
+    if (a.nkt & 1) {                                     // the absent second tile of the last pair: finite (zero) rows, masked keys
+        const int im = t0 >> 7, o16 = t0 & 127;
+        if (im < L::NIMG) *reinterpret_cast<float4*>(smem + (size_t)im * L::LOB + (size_t)T16 * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 < 16) kb[T16 + t0] = -INFINITY;
+    }
+}
+
+template <bool SPLIT, int DS>
+__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add) {
+    typedef B1Lds<SPLIT> L;
+    const cr_block_bwd_desc& bd = a.bd;
+    const cr_block_desc& bk = bd.f;
+    const cr_attn_desc& d = a.ad;
+    __bf16* Im = reinterpret_cast<__bf16*>(smem);
+    __bf16* Wi = Im + L::W_OFF;                           // slot 0: Wq (permuted)
+    float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
+    float* gam = fl + L::GAM; float* part = fl + L::PART; float* sdel = fl + L::SDEL; float* kb = fl + L::KB;
+    constexpr int IST = L::IST;
+    const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
+    const DCtx dcx = d_ctx(D);
+    const int base_row = n * T, M = bk.M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const size_t MD = (size_t)M * D;
+    float* dQg = const_cast<float*>(bd.dqkv);
+    // ---- phase 2 staging: the image slots of phase 1 are dead behind its last barrier; so are W1 / W2 ----
+    {
+        WRegs<1, SB_NT> w;
+        w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
+        const float gv = (threadIdx.x < D) ? bk.ln1_g[threadIdx.x] : 0.0f;
+        __syncthreads();                                  // the LayerNorm flush of phase 1 has read `part`; gam (gamma2) is dead
+        b1_stage_kv<SPLIT>(smem, kb, a, base_row, T16, D, M);
+        w_put_perm<1, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
+        if (threadIdx.x < 64) gam[threadIdx.x] = gv;
+        for (int i = threadIdx.x; i < 2 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;
+    }
+    __syncthreads();
+    B1_TS(3);
+    const int kt_first = first_valid_key_lds(kb, T16, T) >> 4;
+    const DropCtx dc = drop_ctx(d.drop);
+    // per-lane byte offsets of the operand reads at tile 0 of an image (img_off: the swizzle term (row & 6) does not depend on
+    // the tile, so a tile adds 2048 bytes)
+    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    int ftr[4];
+    {
+        const int q_ = li >> 2, p_ = li & 3;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
+    }
+    const unsigned tpk = a.qpk[wave];
+    typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll 1
+    for (int ti = 0; ti < 2; ++ti) {
+        const int qt = (int)((tpk >> (5 * ti)) & 31u);
+        if (qt >= a.nkt) break;                           // 31 = none (wave-uniform)
+        const int q0 = 16 * qt, q = q0 + li;
+        const bool rok = q < T;
+        const int m = base_row + min(q, T - 1);
+        const u32 mo = (u32)m * (u32)(4 * D);
+        GFrag<2> qn;
+        RRaw rdo;
+        gfrag_issue<2>(qn, d.Q, d.ld, base_row + q0, 0, T - q0, D, M);
+        r_issue(rdo, bd.d_o, mo, dcx, rok);
+        const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + min(q, T - 1)) * 4);
+        const float qvq = rok ? d.q_valid[m] : 0.0f;
+        const float delta = sdel[min(q, T16 - 1)];
+        const bool normal = rok && st.z == 0.0f;
+        const float mrow = normal ? st.x : 1e30f, inv = normal ? st.y : 0.0f;
+        bf8 qh[2], ql[2], oh[2], ol[2];
+        gfrag_finish<SPLIT, 2>(qn, d.Q, d.ld, base_row + q0, 0, T - q0, D, M, qh, ql);
+        {
+            f32x4 dO[4];
+            r_finish(dO, rdo, dcx);
+            r_split<SPLIT>(dO, oh, ol);
+        }
+        const bool tile_live = __any(normal ? 1 : 0) != 0;              // uniform and dead rows carry no score gradient
+        const uint32_t ridx = attn_row_idx(d, 0, n, q);
+        const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
+        f32x4 dq[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dq[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tile_live) {
+            const int lo = kt_first, hi = qt;
+            for (int kp = lo >> 1; 2 * kp <= hi; ++kp) {                 // pairs of key tiles 2 kp, 2 kp + 1
+                const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                const int po = 4096 * kp;
+                auto rfF = [&](int base, int ks, int second, int lo_) {
+                    return *reinterpret_cast<const bf8*>(smem + (base + po + (ks ? frk1 : frk0)) + 2048 * second + L::LOB * lo_);
+                };
+                auto trF = [&](int base, int jt, int lo_) {
+                    const unsigned char* pa = smem + (base + po + ftr[jt]) + L::LOB * lo_;
+                    const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
+                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                {
+                    bf8 a0h[2], a0l[2], a1h[2], a1l[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                        a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        s0 = mma<SPLIT>(a0h[ks], a0l[ks], qh[ks], ql[ks], s0);      // S^T[key][q] = K Q^T
+                        s1 = mma<SPLIT>(a1h[ks], a1l[ks], qh[ks], ql[ks], s1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
+                }
+                {
+                    bf8 v0h[2], v0l[2], v1h[2], v1l[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        v0h[ks] = rfF(L::MATB, ks, 0, 0); v1h[ks] = rfF(L::MATB, ks, 1, 0);
+                        v0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : v0h[ks]; v1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : v1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        p0 = mma<SPLIT>(v0h[ks], v0l[ks], oh[ks], ol[ks], p0);      // dA^T[key][q] = V dO^T (V permuted, dO in layout R)
+                        p1 = mma<SPLIT>(v1h[ks], v1l[ks], oh[ks], ol[ks], p1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
+                }
+                // the dQ product's K operand (transposed reads): first batch requested before the element-wise phase that hides it
+                constexpr int JB = SPLIT ? 2 : 4;
+                bf8 bh[JB], bl[JB];
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    bh[jt] = trF(0, jt, 0);
+                    bl[jt] = SPLIT ? trF(0, jt, 1) : bh[jt];
+                }
+                float x[8];
+                auto finish = [&](int kt, const f32x4& s, const f32x4& p, bool on_, int xo) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * kt + 4 * lg + r;
+                        const bool valid = on_ && key <= q && bb[r] == 0.0f;             // causal + key mask
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mrow)) * inv;
+                        const float pn = valid ? e : 0.0f;
+                        float w = qvq;
+                        if (dc.on) w *= drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                        x[xo + r] = pn * (p[r] * w - delta) * a.isd;                     // dS / sqrt(d)
+                    }
+                };
+                finish(k0, s0, p0, k0 >= lo, 0);
+                finish(k1, s1, p1, k1 <= hi, 4);
+                bf8 ah, al;
+                split8<SPLIT>(x, ah, al);
+                // dQ^T += K^T dS^T: the transposed-read fragment as A, dS as B -> D[feature 16 jt + 4 lg + r][query li] = layout R
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) dq[jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[jt]);
+#pragma unroll
+                for (int j0 = JB; j0 < 4; j0 += JB) {
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        bh[jt] = trF(0, j0 + jt, 0);
+                        bl[jt] = SPLIT ? trF(0, j0 + jt, 1) : bh[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                }
+            }
+        }
+        // ---- the tile goes on through registers: dq_in = dQ Wq^T + d_o, LN1 backward -> this side's partial of dx ----
+        RRaw rx, rdx;
+        r_issue(rdo, bd.d_o, mo, dcx, rok);
+        r_issue(rx, bk.x, mo, dcx);
+        if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
+        r_store(dQg, mo, dq, rok, dcx);                                   // for the weight-gradient images of phase 3
+        f32x4 dqin[4];
+        {
+            bf8 gh[2], gl[2];
+            r_split<SPLIT>(dq, gh, gl);
+            r_gemm_t<SPLIT, false>(dqin, Wi, Wi + ST_WIMG, gh, gl);
+            f32x4 dob[4];
+            r_finish(dob, rdo, dcx);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) dqin[ct] += dob[ct];
+        }
+        f32x4 x[4], dxl[4], ag[4], ab[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
+        r_finish(x, rx, dcx);
+        r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
+        b1_ln_fold(part, ag, ab);
+        if (bd.dx_accumulate) {
+            f32x4 old[4];
+            r_finish(old, rdx, dcx);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) dxl[ct] += old[ct];
+        }
+        if (a.scatter) {
+            b1_scatter_prep(a, dxl, m, rok, D);
+            r_store(a.sbuf, mo, dxl, rok, dcx);
+        } else {
+            r_store(bd.dx, mo, dxl, rok, dcx);
+        }
+    }
+    B1_TS(4);
+    __syncthreads();                                      // every pass is done: the K / V images are dead, dQ rows are visible
+    // ---- phase 3: scatter of this side's partial, dWq dbq from images of q_in and dQ, dgamma1 dbeta1 ----
+    if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
+    f32x4 awq[2], nob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; nob[j] = awq[j]; }
+    const int it = wave >> 1, jt0 = 2 * (wave & 1);
+    const int R = a.nkt > SB_TPR ? 2 : 1;
+#pragma unroll 1
+    for (int rd = 0; rd < R; ++rd) {
+        const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
+        if (wave < ntr) {
+            const int qq = 16 * (rd * SB_TPR + wave) + li;
+            const bool rok = qq < T;
+            const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
+            RRaw r1, r2;
+            r_issue(r1, bk.q_in, mo, dcx);
+            r_issue(r2, dQg, mo, dcx, rok);
+            f32x4 qin[4], dQ[4];
+            r_finish(qin, r1, dcx);
+            plant_one(qin, D);
+            img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, qin);
+            r_finish(dQ, r2, dcx);
+            img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, dQ);
+        }
+        __syncthreads();
+        wgrad_accum<SPLIT, false>(awq, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
+        __syncthreads();
+    }
+    const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+    b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
+    b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
+    B1_TS(5);
+    (void)MD;
+}
+
+// =====================================================================================================
+// K side, phases 2 and 3: key-owner pass (dK, dV), K / V projections backward, dWk dWv
+// =====================================================================================================
+template <bool SPLIT, int DS>
+__device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add) {
+    typedef B1Lds<SPLIT> L;
+    const cr_block_bwd_desc& bd = a.bd;
+    const cr_block_desc& bk = bd.f;
+    const cr_attn_desc& d = a.ad;
+    __bf16* Im = reinterpret_cast<__bf16*>(smem);
+    __bf16* Wi = Im + L::W_OFF;                           // slot 0: Wk, slot 1: Wv (permuted)
+    float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
+    float* sdel = fl + L::SDEL; float* smx = fl + L::SMX; float* sinv = fl + L::SINV; float* suni = fl + L::SUNI; float* sqv = fl + L::SQV;
+    float* tile_flag = fl + L::TFLAG;
+    constexpr int WST = L::WST, IST = L::IST;
+    const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
+    const DCtx dcx = d_ctx(D);
+    const int base_row = n * T, M = bk.M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const size_t MD = (size_t)M * D;
+    float* dKg = const_cast<float*>(bd.dqkv) + MD;
+    float* dVg = const_cast<float*>(bd.dqkv) + 2 * MD;
+    typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+    // ---- phase 2 staging: row statistics of every query row; Wk, Wv over W1, W2 ----
+    {
+        WRegs<2, SB_NT> w;
+        w_issue<2, SB_NT>(w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
+        const int t = threadIdx.x, tc = min(t, T - 1);
+        const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + tc) * 4);
+        const float qv = d.q_valid[base_row + tc];
+        __syncthreads();                                  // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete
+        w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
+        // stored so that the inner loop is branch-free: A[q][key] = valid * exp2(s c - smx) * sinv + (key < T ? suni : 0);
+        // normal row: suni = 0; uniform row: sinv = 0, suni = 1/T; dead row: both 0 (smx = 1e30 wherever sinv = 0)
+        if (t < T16 + ((a.nkt & 1) ? 16 : 0)) {             // (an odd tile count: the absent tile of the last pair reads as dead rows)
+            const float flag = t < T ? st.z : 2.0f;
+            const bool normal = flag == 0.0f;
+            smx[t] = normal ? st.x : 1e30f;
+            sinv[t] = normal ? st.y : 0.0f;
+            if (!normal || t >= T16) sdel[t] = 0.0f;
+            suni[t] = (flag == 1.0f) ? a.invT : 0.0f;
+            sqv[t] = t < T ? qv : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        // per query tile: 0 nothing flows, 1 normal rows only, 2 has a uniform row (one lane per row, folded by ballots)
+        const int t = threadIdx.x;
+        if ((t & ~63) < T16) {
+            const bool live = t < T16;
+            const unsigned long long bn = __ballot(live && sinv[live ? t : 0] != 0.0f);
+            const unsigned long long bu = __ballot(live && suni[live ? t : 0] != 0.0f);
+            if ((t & 15) == 0 && live) {
+                const int sh = t & 48;
+                const bool anyu = ((bu >> sh) & 0xFFFFull) != 0, anyn = ((bn >> sh) & 0xFFFFull) != 0;
+                tile_flag[t >> 4] = anyu ? 2.0f : (anyn ? 1.0f : 0.0f);
+            }
+        }
+        if (t == 0 && (a.nkt & 1)) tile_flag[a.nkt] = 0.0f;
+    }
+    __syncthreads();
+    B1_TS(3);
+    const DropCtx dc = drop_ctx(d.drop);
+    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    int ftr[4];
+    {
+        const int q_ = li >> 2, p_ = li & 3;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
+    }
+    const unsigned tpk = a.kpk[wave];
+#pragma unroll 1
+    for (int ti = 0; ti < 2; ++ti) {
+        const int kt = (int)((tpk >> (5 * ti)) & 31u);
+        if (kt >= a.nkt) break;
+        const int key0 = 16 * kt, key = key0 + li;
+        const bool rok = key < T;
+        const int m = base_row + min(key, T - 1);
+        const u32 mo = (u32)m * (u32)(4 * D);
+        const float key_in_T = rok ? 1.0f : 0.0f;
+        const uint32_t drop_base = attn_row_idx(d, 0, n, 0) + (uint32_t)key;
+        GFrag<2> kn, vn;
+        gfrag_issue<2>(kn, d.K, d.ld, base_row + key0, 0, T - key0, D, M);
+        gfrag_issue<2>(vn, d.V, d.ld, base_row + key0, 0, T - key0, D, M);
+        const float kvn = d.k_valid[m];
+        bf8 kh[2], kl[2], vh[2], vl[2];
+        gfrag_finish<SPLIT, 2>(kn, d.K, d.ld, base_row + key0, 0, T - key0, D, M, kh, kl);
+        gfrag_finish<SPLIT, 2>(vn, d.V, d.ld, base_row + key0, 0, T - key0, D, M, vh, vl);
+        const bool kvk = rok && kvn != 0.0f;
+        const bool tile_has_key = __any(kvk ? 1 : 0) != 0;              // all-padding key tile: only uniform rows reach it
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            dk[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int ntile = a.nkt;
+        for (int qp = 0; 2 * qp < ntile; ++qp) {                         // pairs of query tiles 2 qp, 2 qp + 1
+            const int l0 = 2 * qp, l1 = 2 * qp + 1;
+            const bool two = l1 < ntile;
+            auto wanted = [&](int lt) {
+                const float f = tile_flag[lt];
+                if (f == 0.0f) return false;                                     // nothing flows through dead query tiles
+                if (f == 2.0f) return true;                                      // uniform rows see every key
+                return (lt >= kt) && tile_has_key;                               // causal / padding skip
+            };
+            const bool w0 = wanted(l0), w1 = two && wanted(l1);
+            if (!w0 && !w1) continue;
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            const int po = 4096 * qp;
+            auto rfF = [&](int base, int ks, int second, int lo) {
+                return *reinterpret_cast<const bf8*>(smem + (base + po + (ks ? frk1 : frk0)) + 2048 * second + L::LOB * lo);
+            };
+            auto trF = [&](int base, int jt, int lo) {
+                const unsigned char* pa = smem + (base + po + ftr[jt]) + L::LOB * lo;
+                const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
+                const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            {
+                bf8 a0h[2], a0l[2], a1h[2], a1l[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                    a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s0 = mma<SPLIT>(a0h[ks], a0l[ks], kh[ks], kl[ks], s0);      // S[q][key]
+                    s1 = mma<SPLIT>(a1h[ks], a1l[ks], kh[ks], kl[ks], s1);
+                }
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
+                BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
+            }
+            {
+                bf8 o0h[2], o0l[2], o1h[2], o1l[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    o0h[ks] = rfF(L::MATB, ks, 0, 0); o1h[ks] = rfF(L::MATB, ks, 1, 0);
+                    o0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : o0h[ks]; o1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : o1h[ks];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    p0 = mma<SPLIT>(o0h[ks], o0l[ks], vh[ks], vl[ks], p0);      // dA[q][key] = dO V^T
+                    p1 = mma<SPLIT>(o1h[ks], o1l[ks], vh[ks], vl[ks], p1);
+                }
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
+                BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
+            }
+            // dOut columns for the dV product: first batch requested before the element-wise phase that hides it
+            constexpr int JB = SPLIT ? 2 : 4;
+            bf8 oth[JB], otl[JB];
+#pragma unroll
+            for (int jt = 0; jt < JB; ++jt) {
+                oth[jt] = trF(L::MATB, jt, 0);
+                otl[jt] = SPLIT ? trF(L::MATB, jt, 1) : oth[jt];
+            }
+            float xa[8], xd[8];
+            auto finish = [&](int lt, const f32x4& s, const f32x4& p, bool on_, int xo) {
+                const int q4 = 16 * lt + 4 * lg;                             // this lane's 4 query rows
+                const float4 m4 = *reinterpret_cast<const float4*>(smx + q4), i4 = *reinterpret_cast<const float4*>(sinv + q4);
+                const float4 d4 = *reinterpret_cast<const float4*>(sdel + q4), u4 = *reinterpret_cast<const float4*>(suni + q4);
+                const float4 w4 = *reinterpret_cast<const float4*>(sqv + q4);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+                const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, uu[4] = {u4.x, u4.y, u4.z, u4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                const uint32_t x0 = (drop_base + (uint32_t)q4 * (uint32_t)T) * CR_PHI + dc.key;   // counter of attention_weights[n, q4, key]
+                const uint32_t xT = (uint32_t)T * CR_PHI;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = on_ && (key <= q4 + r) && kvk;         // causal + key mask
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mm[r])) * ii[r];
+                    const float pn = valid ? e : 0.0f;
+                    float w = ww[r];
+                    if (dc.on) w *= drop_factor_x(dc, x0 + (uint32_t)r * xT);
+                    xa[xo + r] = on_ ? (pn + key_in_T * uu[r]) * w : 0.0f;   // A after mask + dropout
+                    xd[xo + r] = pn * (p[r] * w - dd[r]) * a.isd;            // dS / sqrt(d)
+                }
+            };
+            finish(l0, s0, p0, true, 0);
+            finish(l1, s1, p1, two, 4);
+            bf8 ah, al, dh, dl;
+            split8<SPLIT>(xa, ah, al);
+            split8<SPLIT>(xd, dh, dl);
+            // dV^T += dO^T A, dK^T += Q^T dS: the transposed-read fragment as A, the coefficients as B -> layout R
+#pragma unroll
+            for (int jt = 0; jt < JB; ++jt) dv[jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[jt]);
+#pragma unroll
+            for (int j0 = JB; j0 < 4; j0 += JB) {
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    oth[jt] = trF(L::MATB, j0 + jt, 0);
+                    otl[jt] = SPLIT ? trF(L::MATB, j0 + jt, 1) : oth[jt];
+                }
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[j0 + jt]);
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+            }
+#pragma unroll
+            for (int j0 = 0; j0 < 4; j0 += JB) {
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    oth[jt] = trF(0, j0 + jt, 0);
+                    otl[jt] = SPLIT ? trF(0, j0 + jt, 1) : oth[jt];
+                }
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], dh, dl, dk[j0 + jt]);
+                BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+            }
+        }
+        // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
+        r_store(dKg, mo, dk, rok, dcx);                                   // for the weight-gradient images of phase 3
+        r_store(dVg, mo, dv, rok, dcx);
+        f32x4 dxp[4];
+        {
+            bf8 gh[2], gl[2];
+            r_split<SPLIT>(dk, gh, gl);
+            r_gemm_t<SPLIT, false>(dxp, Wi, Wi + ST_WIMG, gh, gl);
+            r_split<SPLIT>(dv, gh, gl);
+            r_gemm_t<SPLIT, true>(dxp, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
+        }
+        if (a.scatter) {
+            b1_scatter_prep(a, dxp, m, rok, D);
+            r_store(a.sbuf2, mo, dxp, rok, dcx);
+        } else {
+            r_store(a.dx2, mo, dxp, rok, dcx);
+        }
+    }
+    B1_TS(4);
+    __syncthreads();                                      // every pass is done: the Q / dOut images are dead, dK / dV rows are visible
+    // ---- phase 3: scatter of this side's partial, dWk dbk dWv dbv from images of x, dK, dV ----
+    if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
+    f32x4 awk[2], awv[2], nob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; nob[j] = awk[j]; }
+    const int it = wave >> 1, jt0 = 2 * (wave & 1);
+    const int R = a.nkt > SB_TPR ? 2 : 1;
+#pragma unroll 1
+    for (int rd = 0; rd < R; ++rd) {
+        const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
+        if (wave < ntr) {
+            const int qq = 16 * (rd * SB_TPR + wave) + li;
+            const bool rok = qq < T;
+            const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
+            RRaw r1, r2, r3;
+            r_issue(r1, bk.x, mo, dcx);
+            r_issue(r2, dKg, mo, dcx, rok);
+            r_issue(r3, dVg, mo, dcx, rok);
+            f32x4 x[4], g[4];
+            r_finish(x, r1, dcx);
+            plant_one(x, D);
+            img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, x);
+            r_finish(g, r2, dcx);
+            img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, g);
+            r_finish(g, r3, dcx);
+            img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, g);
+        }
+        __syncthreads();
+        wgrad_accum<SPLIT, false>(awk, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
+        wgrad_accum<SPLIT, false>(awv, nob, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
+        __syncthreads();
+    }
+    const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+    b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
+    b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
+    B1_TS(5);
+}
+
+template <bool SPLIT, int DS>
+__global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    B1_TS(0);
+    // sequences blockIdx.x, + gridDim.x, ...: the slab of the workgroup pair is written by its first sequence and added to by the rest
+    if (blockIdx.y == 0) {
+#pragma unroll 1
+        for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
+            b1_phase1<SPLIT, DS, false>(a, smem_raw, n, n != (int)blockIdx.x);
+            b1_k_side<SPLIT, DS>(a, smem_raw, n, n != (int)blockIdx.x);
+        }
+    } else {
+#pragma unroll 1
+        for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
+            b1_phase1<SPLIT, DS, true>(a, smem_raw, n, n != (int)blockIdx.x);
+            b1_q_side<SPLIT, DS>(a, smem_raw, n, n != (int)blockIdx.x);
+        }
+    }
+    B1_TS(31);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+// Tiles of the attention passes' waves: at most two per wave (what a wave carries through registers), heaviest first to the
+// SIMD (waves w and w + 4 share one) with the fewest pair iterations so far, there to the wave with the fewer.  A query tile
+// qt meets key tiles 0..qt, a key tile kt query tiles kt..nkt-1, two per loop iteration.
+static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
+    int cost[16], order[16], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 8; ++w) pk[w] = 0x3FFu;                           // two "none" entries
+    for (int t = 0; t < nkt; ++t) {
+        cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2;
+        order[t] = t;
+    }
+    for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
+        for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
+    for (int i = 0; i < nkt; ++i) {
+        const int t = order[i];
+        int best = -1;
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (cnt[s4] >= 2 && cnt[s4 + 4] >= 2) continue;
+            if (best < 0 || load[s4] + load[s4 + 4] < load[best] + load[best + 4]) best = s4;
+        }
+        int w = best;
+        if (cnt[w] >= 2 || (cnt[w + 4] < 2 && load[w + 4] < load[w])) w = best + 4;
+        pk[w] = (pk[w] & ~(31u << (5 * cnt[w]))) | ((unsigned)t << (5 * cnt[w]));
+        ++cnt[w];
+        load[w] += cost[t];
+    }
+}
+
+static const char* b1_unsupported(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, int B, int T, int precision) {
+    if (!bd || !ad) return "NULL description";
+    const cr_block_desc& d = bd->f;
+    if (d.D < 8 || d.D >= 64) return "hidden size 8..63";
+    if (precision != CR_PREC_BF16X3 && precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
+    if (B < 1 || T < 1 || d.M != B * T) return "M = B T";
+    if ((T + 15) / 16 > 2 * SB_TPR) return "T <= 224 (two rounds of 7 row tiles)";
+    if ((size_t)d.M * d.D * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
+    if (bd->n_slabs < 1) return "n_slabs";
+    if (ad->H != 1 || ad->d != d.D || ad->B != B || ad->T != T) return "one head of d = D, the block's B and T";
+    if (ad->ld != d.D || ad->Q != d.qkv || ad->K != d.qkv + (size_t)d.M * d.D || ad->V != d.qkv + 2 * (size_t)d.M * d.D) return "Q / K / V = the parts of the block's qkv";
+    if (ad->residual != d.q_in || ad->out != d.o || ad->k_valid != d.k_valid || ad->q_valid != d.q_valid) return "the attention call of this block (residual = q_in, out = o, masks)";
+    if (!ad->row_stats) return "row_stats (saved by the forward)";
+    if (ad->attn_weights) return "attention weights are not taken";
+    return nullptr;
+}
+extern "C" int cr_stack_block_bwd_supported(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, int B, int T, int precision) {
+    return b1_unsupported(bd, ad, B, T, precision) == nullptr;
+}
+
+template <bool SPLIT, int DS>
+static int launch_b1(const B1Args& a, int nwg, hipStream_t s) {
+    static cr_devmask attr = 0;
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_block_bwd<SPLIT, DS>), &attr);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stack_block_bwd<SPLIT, DS>), dim3(nwg, 2), dim3(SB_NT), B1Lds<SPLIT>::BYTES, s, a);
+    return cr_check_launch("cr_stack_block_bwd");
+}
+
+extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, const cr_block_bwd1_ext* x, const cr_ln_bwd_desc* lnf,
+                                  const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream) {
+    const char* why = b1_unsupported(bd, ad, B, T, precision);
+    CR_REQUIRE(why == nullptr, "cr_stack_block_bwd: unsupported (%s)", why ? why : "");
+    CR_REQUIRE(x != nullptr, "cr_stack_block_bwd: NULL extension");
+    B1Args a;
+    memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.bd = *bd; a.ad = *ad;
+    a.B = B; a.T = T; a.nkt = (T + 15) / 16;
+    const cr_block_desc* d = &bd->f;
+    CR_REQUIRE(bd->d_o && bd->dqkv && d->hid && d->f_in && d->o && d->q_in && d->x && d->mask_ids && d->w1 && d->w2 && d->wqkv && d->ln1_g && d->ln2_g,
+               "cr_stack_block_bwd: NULL pointer");
+    CR_REQUIRE(bd->g_w1 && bd->g_b1 && bd->g_w2 && bd->g_b2 && bd->g_ln2_g && bd->g_ln2_b && bd->g_wqkv && bd->g_bqkv && bd->g_ln1_g && bd->g_ln1_b,
+               "cr_stack_block_bwd: NULL gradient pointer");
+    CR_REQUIRE(bd->dq_part == nullptr, "cr_stack_block_bwd: dq_part is not taken");
+    a.dy2 = x->dy2; a.dx2 = x->dx2; a.ln_dy2 = x->lnf_dy2; a.d_addend2 = x->d_addend2;
+    if (lnf) {
+        CR_REQUIRE(lnf->x == d->y && lnf->ldx == d->D && lnf->M == d->M && lnf->D == d->D, "cr_stack_block_bwd: the LayerNorm's input must be this block's y");
+        CR_REQUIRE(lnf->gamma && lnf->dy && lnf->dgamma && lnf->dbeta && lnf->accumulate == 0, "cr_stack_block_bwd: LayerNorm backward arguments");
+        CR_REQUIRE(lnf->slab_stride == bd->slab_stride && lnf->n_slabs == bd->n_slabs, "cr_stack_block_bwd: the LayerNorm's slabs must be the block's");
+        CR_REQUIRE((size_t)lnf->M * lnf->lddy * 4 < ((size_t)1 << 32), "cr_stack_block_bwd: dy of 4 GiB or more");
+        a.ln = *lnf;
+        a.has_ln = 1;
+    } else {
+        CR_REQUIRE(bd->dy, "cr_stack_block_bwd: dy is NULL");
+        CR_REQUIRE(x->lnf_dy2 == nullptr, "cr_stack_block_bwd: lnf_dy2 without a LayerNorm");
+    }
+    if (sc) {
+        const cr_embed_desc* e = &sc->f;
+        CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
+                   "cr_stack_block_bwd: the embedding recipe must describe the block's dense input x");
+        CR_REQUIRE(sc->n_slabs == 0, "cr_stack_block_bwd: small-table mode is not fused");
+        CR_REQUIRE(!bd->dx_accumulate, "cr_stack_block_bwd: dx_accumulate with a scatter (this kernel must be the only producer of dx)");
+        CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "cr_stack_block_bwd: nothing to scatter into");
+        CR_REQUIRE(sc->d_addend == nullptr || (e->ld_add == d->D && x->d_addend2 != nullptr), "cr_stack_block_bwd: d_addend must be dense [M, D] and come with d_addend2");
+        a.sc = *sc;
+        a.scatter = 1;
+        // the masked partial rows wait for phase 3 in d_addend / d_addend2 where the graph has an addend, else in dx / dx2
+        a.sbuf = sc->d_addend ? sc->d_addend : bd->dx;
+        a.sbuf2 = sc->d_addend ? x->d_addend2 : x->dx2;
+        CR_REQUIRE(a.sbuf && a.sbuf2 && a.sbuf != a.sbuf2, "cr_stack_block_bwd: the scatter needs two [M, D] row buffers (d_addend + d_addend2, or dx + dx2)");
+    } else {
+        CR_REQUIRE(bd->dx && x->dx2 && bd->dx != x->dx2, "cr_stack_block_bwd: dx / dx2");
+    }
+    a.isd = 1.0f / sqrtf((float)ad->d);
+    a.isd_log2e = a.isd * 1.4426950408889634f;
+    a.invT = 1.0f / (float)T;
+    b1_deal_tiles(a.nkt, true, a.qpk);
+    b1_deal_tiles(a.nkt, false, a.kpk);
+    a.ts = g_attn_ts_which == 9 ? g_attn_ts : nullptr;
+    const int nwg = B < bd->n_slabs ? B : bd->n_slabs;
+    const bool split = precision == CR_PREC_BF16X3;
+    hipStream_t s = cr_stream(stream);
+    if (d->D == 50) return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
+    return split ? launch_b1<true, 0>(a, nwg, s) : launch_b1<false, 0>(a, nwg, s);
+}

@@ -214,6 +214,12 @@ class Engine:
         self._scatter_recipe, self._scatter_claimed = {}, set()
         self._ln_recipe, self._ln_claimed = {}, set()
         self._lnf_intent = {}                         # y buffer of a stack's last block -> (LN output pointer, param prefix, out, ld, col)
+        # one launch per block backward (cr_stack_block_bwd): the gradient of a block input then exists as TWO partials;
+        # _grad2 maps an activation buffer to the second addend of its gradient until a consumer takes it (see _second_grad)
+        self.fuse_block_bwd = os.environ.get("CASTREC_NO_BLOCK_BWD") != "1"
+        self._grad2 = {}
+        self._grad2_bufs = {}                         # data_ptr -> (activation buffer, second-addend buffer)
+        self._block_bwd_ranges = []                   # slab-0 float ranges written by cr_stack_block_bwd (one slab per sequence)
         self.fuse_head_ln = os.environ.get("CASTREC_NO_HEAD_LN") != "1"
         self._check_ids = os.environ.get("CASTREC_NO_ID_CHECK") != "1"
         self.fused = (4 <= hp.hidden_units <= 64) if fused is None else bool(fused)
@@ -355,15 +361,16 @@ class Engine:
             if addend:
                 assert self._acc(id(addend[1])) == 0, "addend gradient must be first-written here"
                 dadd = addend[1].data_ptr()
+            g2 = self._second_grad(out) if (ld_out == D and col_off == 0) else None   # a gradient in two partials: the kernels add them
             return L.EmbedBwdDesc(f, self._gptr(table), self._gptr("pos_emb") if pos == "learned" else None, dadd,
-                                  self.Gs.shape[1] if small else 0, self.n_slabs if small else 0)
+                                  self.Gs.shape[1] if small else 0, self.n_slabs if small else 0, g2.data_ptr() if g2 is not None else None)
 
         # the first block's QKV backward can apply this scatter itself (cr_block_ln_qkv_bwd_scatter): large-table
         # mode only (a learned positional table's gradient is then accumulated with atomics: its slot in the table
         # section is zero at that point); the block's factory (it runs before this one) claims it
         if (out.data_ptr() in self._pending_embed and not small
                 and (addend is None or addend[0].shape[1] == D)):
-            self._scatter_recipe[out.data_ptr()] = make_bwd_desc
+            self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None)
 
         def factory():
             if out.data_ptr() in self._scatter_claimed:
@@ -371,6 +378,7 @@ class Engine:
             lst = []
             self._call(lst, "cr_embed_bwd", C.byref(make_bwd_desc()))
             return lst
+        factory.pair_aware = ld_out == D and col_off == 0
         self._bwd_factories.append(factory)
 
     def _grad_of(self, t):
@@ -379,6 +387,23 @@ class Engine:
         if key not in self._bufs:
             self._bufs[key] = torch.zeros_like(t)
         return self._bufs[key]
+
+    def _second_grad(self, t):
+        """Second addend of the gradient of activation buffer t (or None), handed to a consumer that adds it itself."""
+        return self._grad2.pop(t.data_ptr(), None)
+
+    def _fold_pairs(self):
+        """cr_eltwise launches that add every pending second addend into its gradient buffer: for consumers that read
+        one gradient pointer."""
+        lst = []
+        for ptr, (t, g2) in list(self._grad2_bufs.items()):
+            if ptr in self._grad2:
+                g = self._grad_of(t)
+                e = L.EltDesc(L.ELT_ADD, g.data_ptr(), g.shape[1], g2.data_ptr(), g2.shape[1], g.data_ptr(), g.shape[1], g.shape[0], g.shape[1],
+                              O.NO_DROP, None, 0)
+                self._call(lst, "cr_eltwise", C.byref(e))
+                del self._grad2[ptr]
+        return lst
 
     def op_layernorm(self, x, y, y_ld, y_col, pname, flags=None, skip_fwd=False):
         """modules.py:53-80.  y may be a column block of a wider (concat) buffer.  skip_fwd: the forward ran as the
@@ -719,6 +744,46 @@ class Engine:
             # bf16 arithmetic: the row phases run on the register-layout kernels (cr_stack_bwd.hip) where they take the shape
             prec = ATTN_PRECISIONS[self.attn_precision]
             rows_bf = bool(self.fuse_stack_bwd and bf and not one_pass and L.lib.cr_stack_bwd_supported(C.byref(bbd), B, T, prec))
+            # ... and where the whole block fits one launch (cr_stack_bwd1.hip: one head, D < 64): ffn_bwd -> attn_bwd -> qkv_bwd per
+            # sequence on a pair of workgroups; the input gradient leaves as two partials (dx, dx2)
+            if (rows_bf and self.fuse_block_bwd and H == 1
+                    and L.lib.cr_stack_block_bwd_supported(C.byref(bbd), C.byref(abd.f), B, T, prec)):
+                dx2 = self.buf(pfx + "dx2", D)
+                dy2 = self._second_grad(y)
+                ext = L.BlockBwd1Ext(dy2.data_ptr() if dy2 is not None else None, dx2.data_ptr(), None, None)
+                nd = None
+                if self._lnf_fused(y):
+                    _, pname, lo, lo_ld, lo_col = self._lnf_intent[y.data_ptr()]
+                    dlo = self._grad_of(lo)
+                    nd = L.LnBwdDesc(y.data_ptr(), D, self._pptr(pname + ".gamma"), dlo.data_ptr() + 4 * lo_col, lo_ld, None, D, 0,
+                                     self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+                    assert id(dy) not in self._grad_written and dy2 is None, "the final LayerNorm must be the only consumer of the stack's output"
+                    dlo2 = self._second_grad(lo)
+                    if dlo2 is not None:
+                        assert dlo2.shape == dlo.shape
+                        ext.lnf_dy2 = dlo2.data_ptr() + 4 * lo_col
+                    self._keep.append(nd)
+                    self._block_slab_range(pname + ".gamma", pname + ".beta")
+                sc = None
+                rec = self._scatter_recipe.get(x.data_ptr())
+                if rec is not None and not bbd.dx_accumulate:
+                    self._scatter_claimed.add(x.data_ptr())
+                    sc = rec[0]()
+                    if sc.d_addend:
+                        dadd2 = self.buf(pfx + "dadd2", D)
+                        ext.d_addend2 = dadd2.data_ptr()
+                        self._grad2[rec[1].data_ptr()] = dadd2            # the addend's gradient is d_addend + d_addend2
+                        self._grad2_bufs[rec[1].data_ptr()] = (rec[1], dadd2)
+                    self._keep.append(sc)
+                else:
+                    self._grad2[x.data_ptr()] = dx2                       # the block input's gradient is dx + dx2
+                    self._grad2_bufs[x.data_ptr()] = (x, dx2)
+                self._keep.append(ext)
+                self._block_slab_range(pfx + "ln1.gamma", pfx + "b2")
+                self._call(lst, "cr_stack_block_bwd", C.byref(bbd), C.byref(abd.f), C.byref(ext), C.byref(nd) if nd is not None else None,
+                           C.byref(sc) if sc is not None else None, B, T, prec)
+                return lst
+            lst += self._fold_pairs()                              # the kernels below read one gradient pointer
             two_heads = (rows_bf and H == 2 and D == 64 and T <= 256 and os.environ.get("CASTREC_BF_TWO_KERNELS") is None
                          and os.environ.get("CASTREC_NO_HEAD_DELTA") != "1")
             if two_heads:
@@ -753,15 +818,23 @@ class Engine:
             if recipe is not None and not bbd.dx_accumulate:
                 self._scatter_claimed.add(x.data_ptr())
                 if rows_bf:
-                    self._call(lst, "cr_stack_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()), B, T, prec)
+                    self._call(lst, "cr_stack_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe[0]()), B, T, prec)
                 else:
-                    self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe()))
+                    self._call(lst, "cr_block_ln_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe[0]()))
             elif rows_bf:
                 self._call(lst, "cr_stack_qkv_bwd", C.byref(bbd), B, T, prec)
             else:
                 self._call(lst, "cr_block_ln_qkv_bwd", C.byref(bbd))
             return lst
+        factory.pair_aware = True                      # (takes dy2 where it can; any other pending pair is not its input)
         self._bwd_factories.append(factory)
+
+    def _block_slab_range(self, first, last):
+        """Parameters first..last (contiguous in the layout) get their gradient from cr_stack_block_bwd: one slab per sequence
+        pair, min(B, n_slabs) slabs in use (cr_adam_desc.slab_counts)."""
+        a = self.layout.entries[first][0] - self.layout.n_table
+        off, shape, _, _ = self.layout.entries[last]
+        self._block_bwd_ranges.append((a, off + int(np.prod(shape)) - self.layout.n_table, min(self.B, self.n_slabs)))
 
     def _stack_kernel_fits(self, nblocks, want_attn):
         """Shapes cr_stack_fwd takes (castrec.h): one head (or two of 32 columns), D 8..64, bf16 arithmetic, K / V images +
@@ -948,7 +1021,11 @@ class Engine:
     def _finalize(self):
         if self.training:
             for fac in reversed(self._bwd_factories):
-                self.bwd += fac()
+                lst = fac()
+                if lst and self._grad2 and not getattr(fac, "pair_aware", False):
+                    self.bwd += self._fold_pairs()            # a consumer with one gradient pointer: fold the pending pairs first
+                self.bwd += lst
+            assert not self._grad2, "a gradient partial was left without a consumer"
             lay = self.layout
             # the step ends inside Adam (castrec.h, state block): sums and step number are read from the snapshot the
             # head kernel took, and the kernel zeroes the sums and advances the counter -- no cr_step_begin launch
@@ -965,15 +1042,17 @@ class Engine:
                 lazy = (self.lazy_ids.data_ptr(), self.lazy_ids.numel(), self.itemnum + 1, self.D, self.lazy_flags.data_ptr())
             # slabs in use per 256-parameter block: n_wslabs where cr_gemm_wgrad is the only writer, n_slabs elsewhere
             counts = None
-            if self.n_wslabs < self.n_slabs and self._wgrad_ranges:
-                cov = np.zeros(lay.n_dense + 1, np.int32)
+            per = np.full(lay.n_dense, self.n_slabs, np.int32)       # slabs that hold gradient, per dense parameter
+            if self.n_wslabs < self.n_slabs:
                 for a, b in self._wgrad_ranges:
-                    cov[a] += 1; cov[b] -= 1
-                only_w = np.cumsum(cov[:-1]) > 0
+                    per[a:b] = self.n_wslabs
+            for a, b, c in self._block_bwd_ranges:                    # cr_stack_block_bwd: one slab per sequence pair
+                per[a:b] = c
+            if lay.n_dense and int(per.min()) < self.n_slabs:
                 nb = (lay.n_dense + 255) // 256
-                pad = np.ones(nb * 256, bool)
-                pad[:lay.n_dense] = only_w
-                cnt = np.where(pad.reshape(nb, 256).all(1), self.n_wslabs, self.n_slabs).astype(np.int32)
+                pad = np.zeros(nb * 256, np.int32)
+                pad[:lay.n_dense] = per
+                cnt = pad.reshape(nb, 256).max(1).astype(np.int32)   # a block shared with a parameter of more slabs reads them all (zeros)
                 self.slab_counts = torch.from_numpy(cnt).to(self.dev)
                 counts = self.slab_counts.data_ptr()
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),

@@ -42,7 +42,7 @@ class EmbedDesc(C.Structure):
 
 class EmbedBwdDesc(C.Structure):
     _fields_ = [("f", EmbedDesc), ("table_grad", c_p), ("pos_grad", c_p), ("d_addend", c_p),
-                ("slab_stride", c_i), ("n_slabs", c_i)]
+                ("slab_stride", c_i), ("n_slabs", c_i), ("out2", c_p)]
 
 
 class LnDesc(C.Structure):
@@ -96,6 +96,10 @@ class BlockBwdDesc(C.Structure):
                 ("g_ln1_g", c_p), ("g_ln1_b", c_p), ("g_wqkv", c_p), ("g_bqkv", c_p), ("g_ln2_g", c_p), ("g_ln2_b", c_p),
                 ("g_w1", c_p), ("g_b1", c_p), ("g_w2", c_p), ("g_b2", c_p), ("slab_stride", c_i), ("n_slabs", c_i),
                 ("attn_delta", c_p), ("dq_part", c_p)]
+
+
+class BlockBwd1Ext(C.Structure):
+    _fields_ = [("dy2", c_p), ("dx2", c_p), ("lnf_dy2", c_p), ("d_addend2", c_p)]
 
 
 class BlockTailDesc(C.Structure):
@@ -155,6 +159,9 @@ _sig("cr_stack_ffn_bwd_ln", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(LnBwdDesc),
 _sig("cr_stack_ffn_bwd_heads", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(LnBwdDesc), c_i, c_i, c_i, c_i, c_p])
 _sig("cr_stack_qkv_bwd", c_i, [C.POINTER(BlockBwdDesc), c_i, c_i, c_i, c_p])
 _sig("cr_stack_qkv_bwd_scatter", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(EmbedBwdDesc), c_i, c_i, c_i, c_p])
+_sig("cr_stack_block_bwd_supported", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(AttnDesc), c_i, c_i, c_i])
+_sig("cr_stack_block_bwd", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(AttnDesc), C.POINTER(BlockBwd1Ext), C.POINTER(LnBwdDesc), C.POINTER(EmbedBwdDesc),
+                                 c_i, c_i, c_i, c_p])
 _sig("cr_block_ln_qkv_bwd_scatter", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(EmbedBwdDesc), c_p])
 _sig("cr_wide_supported", c_i, [C.POINTER(BlockDesc), c_i])
 _sig("cr_wide_ln_qkv_fwd", c_i, [C.POINTER(BlockDesc), c_i, c_p])
@@ -178,7 +185,7 @@ _sig("cr_sampler_destroy", None, [c_p])
 
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
-           "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_block_ln_qkv_bwd_scatter",
+           "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_block_ln_qkv_bwd_scatter",
            "cr_wide_supported", "cr_wide_ln_qkv_fwd", "cr_wide_ln_ffn_fwd", "cr_wide_ln_ffn_fwd_tail", "cr_wide_ln_ffn_bwd", "cr_wide_ln_qkv_bwd",
            "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]

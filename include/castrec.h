@@ -96,6 +96,8 @@ typedef struct {
     int slab_stride, n_slabs; /* n_slabs > 0: small-table mode (V*D*4 <= 48 KiB, context tables with
                                8..201 rows): each of n_slabs workgroups reduces its rows in LDS and
                                WRITES slab s (no hot-row global atomics) */
+    const float* out2;      /* optional: second addend of dout, laid out like f.out (the gradient then is f.out + out2:
+                               cr_stack_block_bwd returns a block input's gradient as two partials) */
 } cr_embed_bwd_desc;
 int cr_embed_bwd(const cr_embed_bwd_desc* d, void* stream);
 
@@ -327,6 +329,30 @@ int cr_stack_ffn_bwd_heads(const cr_block_bwd_desc* d, const cr_ln_bwd_desc* n, 
 int cr_stack_qkv_bwd(const cr_block_bwd_desc* d, int B, int T, int precision, void* stream);
 /* ... with the embedding gather's backward applied instead of storing dx: arguments as cr_block_ln_qkv_bwd_scatter */
 int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);
+
+/* ---- a whole block backward in ONE launch (round 3; csrc/cr_stack_bwd1.hip) --------------------------------------
+ * = cr_stack_ffn_bwd[_ln] -> cr_attn_bwd -> cr_stack_qkv_bwd[_scatter] of one block (sasrec.py:65-83 and its autodiff), per
+ * sequence, on a PAIR of workgroups (query side / key side) that never wait for each other.  Same inputs and slab layout as
+ * those calls, with these differences:
+ *   - the gradient of the block input leaves as TWO partials, d->dx (query side: LayerNorm-1 branch) and x->dx2 (key side:
+ *     K / V projections); the caller's gradient is their SUM.  Likewise the input gradient may arrive as a sum: d->dy + x->dy2
+ *     (or, with the final LayerNorm `lnf` as in cr_stack_ffn_bwd_ln: lnf->dy + x->lnf_dy2);
+ *   - with `sc` (the embedding backward of the block input, as cr_stack_qkv_bwd_scatter): each side applies it to its partial:
+ *     table / positional gradients by float atomics, the addend's gradient as sc->d_addend + x->d_addend2 (their sum);
+ *   - d->d_o, d->dqkv ([3, M, D]) are workspaces here; d->attn_delta is not used (delta stays on chip);
+ *   - ONE slab per sequence pair: workgroup pair p writes slab p (p < min(B, n_slabs)) and adds its later sequences to it;
+ *     slabs >= min(B, n_slabs) are not written by this call.
+ * `ad` is the block's attention call exactly as given to cr_attn_fwd / cr_stack_fwd (row_stats required).
+ * Shapes (cr_stack_block_bwd_supported): one head, 8 <= D < 64, T <= 224, CR_PREC_BF16X3 or CR_PREC_BF16. */
+typedef struct {
+    const float* dy2;                          /* optional [M,D] */
+    float* dx2;                                /* [M,D] (may be NULL with `sc` when sc->d_addend is set) */
+    const float* lnf_dy2;                      /* optional, with lnf: second addend of lnf->dy (same leading dimension) */
+    float* d_addend2;                          /* with sc->d_addend: [M,D] */
+} cr_block_bwd1_ext;
+int cr_stack_block_bwd_supported(const cr_block_bwd_desc* d, const cr_attn_desc* ad, int B, int T, int precision);   /* 1 / 0 */
+int cr_stack_block_bwd(const cr_block_bwd_desc* d, const cr_attn_desc* ad, const cr_block_bwd1_ext* x, const cr_ln_bwd_desc* lnf,
+                       const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);
 
 /* ---- the same four row phases for hidden sizes 128 / 192 / 256 (configs C4, C5) on the bf16 matrix pipe (cr_wide.hip):
  * one launch each where the unfused path runs cr_layernorm_* + cr_gemm_rows (+ cr_eltwise) chains -- modules.py:53-80

@@ -42,7 +42,7 @@ def test_struct_sizes_match_c_layout(tmp_path):
     pairs = [("cr_rng", L.Rng), ("cr_embed_desc", L.EmbedDesc), ("cr_embed_bwd_desc", L.EmbedBwdDesc), ("cr_ln_desc", L.LnDesc),
              ("cr_ln_bwd_desc", L.LnBwdDesc), ("cr_gemm_desc", L.GemmDesc), ("cr_wgrad_desc", L.WgradDesc),
              ("cr_elt_desc", L.EltDesc), ("cr_attn_desc", L.AttnDesc), ("cr_attn_bwd_desc", L.AttnBwdDesc),
-             ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_block_tail_desc", L.BlockTailDesc),
+             ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_block_bwd1_ext", L.BlockBwd1Ext), ("cr_block_tail_desc", L.BlockTailDesc),
              ("cr_stack_desc", L.StackDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
     # every structure the header declares has a mirror in this list
     hdr = open(os.path.join(ROOT, "include", "castrec.h")).read()

@@ -260,7 +260,8 @@ def test_awkward_hidden_sizes_and_row_counts(E, model, D, H, T, L, B, prec):
 
 
 @pytest.mark.parametrize("env", ["CASTREC_NO_TAILS", "CASTREC_TWO_PASS_ATTN_BWD", "CASTREC_NO_EMBED_FUSION", "CASTREC_NO_HEAD_LN",
-                                 "CASTREC_NO_STACK_KERNEL", "CASTREC_NO_STACK_BWD", "CASTREC_NO_LNF_FUSION", "CASTREC_NO_HEAD_DELTA"])
+                                 "CASTREC_NO_STACK_KERNEL", "CASTREC_NO_STACK_BWD", "CASTREC_NO_LNF_FUSION", "CASTREC_NO_HEAD_DELTA",
+                                 "CASTREC_NO_BLOCK_BWD"])
 def test_alternative_kernel_paths_stay_green(E, env, monkeypatch):
     """The plain FFN forward entry (no tail), the two-pass attention backward at one head and the stand-alone
     embedding gather in front of a stack: the engine's default path no longer uses them, the C ABI still offers them."""
@@ -308,6 +309,9 @@ def test_fused_entries_give_the_results_of_their_separate_calls(E, env, model, m
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("env,T,D,B,H", [("CASTREC_NO_STACK_BWD", 40, 50, 6, 1), ("CASTREC_NO_STACK_BWD", 200, 50, 3, 1), ("CASTREC_NO_STACK_BWD", 33, 24, 5, 1),
+                                         # the one-launch block backward (cr_stack_bwd1.hip) against the three launches it replaces
+                                         ("CASTREC_NO_BLOCK_BWD", 40, 50, 6, 1), ("CASTREC_NO_BLOCK_BWD", 200, 50, 3, 1), ("CASTREC_NO_BLOCK_BWD", 33, 24, 5, 1),
+                                         ("CASTREC_NO_BLOCK_BWD", 224, 50, 2, 1), ("CASTREC_NO_BLOCK_BWD", 100, 63, 9, 1),
                                          ("CASTREC_NO_STACK_KERNEL", 40, 50, 6, 1), ("CASTREC_NO_STACK_KERNEL", 200, 50, 3, 1), ("CASTREC_NO_STACK_KERNEL", 33, 24, 5, 1),
                                          ("CASTREC_NO_STACK_BWD", 50, 64, 5, 2), ("CASTREC_NO_STACK_KERNEL", 50, 64, 5, 2),     # config C3's shape: two heads
                                          ("CASTREC_NO_STACK_BWD", 100, 64, 3, 1), ("CASTREC_NO_STACK_KERNEL", 100, 64, 3, 1)])
@@ -326,8 +330,11 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=4 if B > 4 else 7, attn_precision=prec)
     monkeypatch.delenv(env)
     names = lambda e: [n for n, _, _ in e.fwd + e.bwd]
-    new = ("cr_stack_fwd",) if env == "CASTREC_NO_STACK_KERNEL" else ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_heads")
+    new = {"CASTREC_NO_STACK_KERNEL": ("cr_stack_fwd",), "CASTREC_NO_BLOCK_BWD": ("cr_stack_block_bwd",),
+           "CASTREC_NO_STACK_BWD": ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_heads", "cr_stack_block_bwd")}[env]
     assert any(n in names(a) for n in new) and not any(n in names(b) for n in new)
+    if env == "CASTREC_NO_BLOCK_BWD":
+        assert "cr_stack_ffn_bwd" in names(b) or "cr_stack_ffn_bwd_ln" in names(b)      # ... and b runs the three-launch form
     a.P.add_(0.05 * torch.randn(a.P.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
     b.P.copy_(a.P)
     batch = make_batch(rs, B, T, itemnum, max_bins)
@@ -343,6 +350,28 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     gmax = max(float(v.abs().max()) for v in gb.values())
     for k in gb:
         assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1) * gmax, k
+
+
+@pytest.mark.parametrize("B,n_slabs", [(6, 16), (9, 4)])
+def test_block_backward_is_bitwise_reproducible(E, B, n_slabs):
+    """cr_stack_block_bwd: slabs written in a fixed order by one workgroup pair per sequence (and added to, sequence after
+    sequence, when there are fewer slabs than sequences), no atomics in the dense path: the same bits on every run."""
+    rs = np.random.RandomState(3)
+    T, D, itemnum = 100, 50, 41
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=9, num_context_blocks=1, lr=1e-3, seed=11)
+    eng = E.Engine("cast_1", 9, itemnum, hp, B, training=True, n_slabs=n_slabs)
+    assert "cr_stack_block_bwd" in [n for n, _, _ in eng.bwd]
+    batch = make_batch(rs, B, T, itemnum, 9)
+    got = []
+    for _ in range(3):
+        eng.set_batch(*batch)
+        eng.set_step(1)
+        eng.Gflat.zero_()
+        eng.launch_step(apply=False)
+        torch.cuda.synchronize()
+        got.append(eng.Gs.clone())
+    assert float(got[0].abs().max()) > 0
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
 
 
 def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False):
