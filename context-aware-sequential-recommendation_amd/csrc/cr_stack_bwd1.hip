@@ -50,6 +50,7 @@ struct B1Args {
     float* d_addend2;                     // scatter: K side's partial of d_addend
     float* sbuf; float* sbuf2;            // scatter: where the masked partial rows wait for phase 3 ([M, D] each)
     int B, T, nkt, scatter, has_ln;
+    int n0, add;                          // this launch: sequences n0 .. n0 + gridDim.x - 1; add: the slabs already hold earlier sequences' sums
     float isd, isd_log2e, invT;
     unsigned qpk[8], kpk[8];              // tiles of wave w in the attention passes: two 5-bit tile numbers, 31 = none
     unsigned long long* ts;
@@ -444,6 +445,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const size_t MD = (size_t)M * D;
     float* dQg = const_cast<float*>(bd.dqkv);
+    B1_TS(9);
     // ---- phase 2 staging: the image slots of phase 1 are dead behind its last barrier; so are W1 / W2 ----
     {
         WRegs<1, SB_NT> w;
@@ -474,6 +476,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     for (int ti = 0; ti < 2; ++ti) {
         const int qt = (int)((tpk >> (5 * ti)) & 31u);
         if (qt >= a.nkt) break;                           // 31 = none (wave-uniform)
+        if (ti == 1) B1_TS(8);
         const int q0 = 16 * qt, q = q0 + li;
         const bool rok = q < T;
         const int m = base_row + min(q, T - 1);
@@ -589,6 +592,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
                 }
             }
         }
+        if (ti == 0) B1_TS(6);
         // ---- the tile goes on through registers: dq_in = dQ Wq^T + d_o, LN1 backward -> this side's partial of dx ----
         RRaw rx, rdx;
         r_issue(rdo, bd.d_o, mo, dcx, rok);
@@ -626,6 +630,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     }
     B1_TS(4);
     __syncthreads();                                      // every pass is done: the K / V images are dead, dQ rows are visible
+    B1_TS(7);
     // ---- phase 3: scatter of this side's partial, dWq dbq from images of q_in and dQ, dgamma1 dbeta1 ----
     if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     f32x4 awq[2], nob[2];
@@ -736,6 +741,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     for (int ti = 0; ti < 2; ++ti) {
         const int kt = (int)((tpk >> (5 * ti)) & 31u);
         if (kt >= a.nkt) break;
+        if (ti == 1) B1_TS(8);
         const int key0 = 16 * kt, key = key0 + li;
         const bool rok = key < T;
         const int m = base_row + min(key, T - 1);
@@ -873,6 +879,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
                 BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
             }
         }
+        if (ti == 0) B1_TS(6);
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
         r_store(dKg, mo, dk, rok, dcx);                                   // for the weight-gradient images of phase 3
         r_store(dVg, mo, dv, rok, dcx);
@@ -893,6 +900,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     }
     B1_TS(4);
     __syncthreads();                                      // every pass is done: the Q / dOut images are dead, dK / dV rows are visible
+    B1_TS(7);
     // ---- phase 3: scatter of this side's partial, dWk dbk dWv dbv from images of x, dK, dV ----
     if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     f32x4 awk[2], awv[2], nob[2];
@@ -935,19 +943,16 @@ template <bool SPLIT, int DS>
 __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     B1_TS(0);
-    // sequences blockIdx.x, + gridDim.x, ...: the slab of the workgroup pair is written by its first sequence and added to by the rest
+    // ONE sequence per workgroup pair and launch: sequence a.n0 + blockIdx.x, slab blockIdx.x.  (A loop over sequences in here
+    // made every per-lane address and mask of both sides loop-invariant: hoisted to the top of the kernel and spilled, 269
+    // registers.  More sequences than slabs are further launches that ADD to the slabs -- the host's loop.)
+    const int n = a.n0 + (int)blockIdx.x;
     if (blockIdx.y == 0) {
-#pragma unroll 1
-        for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
-            b1_phase1<SPLIT, DS, false>(a, smem_raw, n, n != (int)blockIdx.x);
-            b1_k_side<SPLIT, DS>(a, smem_raw, n, n != (int)blockIdx.x);
-        }
+        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, a.add != 0);
+        b1_k_side<SPLIT, DS>(a, smem_raw, n, a.add != 0);
     } else {
-#pragma unroll 1
-        for (int n = blockIdx.x; n < a.B; n += gridDim.x) {
-            b1_phase1<SPLIT, DS, true>(a, smem_raw, n, n != (int)blockIdx.x);
-            b1_q_side<SPLIT, DS>(a, smem_raw, n, n != (int)blockIdx.x);
-        }
+        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, a.add != 0);
+        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0);
     }
     B1_TS(31);
 }
@@ -1003,11 +1008,15 @@ extern "C" int cr_stack_block_bwd_supported(const cr_block_bwd_desc* bd, const c
 }
 
 template <bool SPLIT, int DS>
-static int launch_b1(const B1Args& a, int nwg, hipStream_t s) {
+static int launch_b1(B1Args& a, int nwg, hipStream_t s) {
     static cr_devmask attr = 0;
     int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_block_bwd<SPLIT, DS>), &attr);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_block_bwd<SPLIT, DS>), dim3(nwg, 2), dim3(SB_NT), B1Lds<SPLIT>::BYTES, s, a);
+    for (int n0 = 0; n0 < a.B; n0 += nwg) {               // more sequences than slabs: further launches add to the slabs
+        a.n0 = n0;
+        a.add = n0 > 0;
+        hipLaunchKernelGGL((k_stack_block_bwd<SPLIT, DS>), dim3(a.B - n0 < nwg ? a.B - n0 : nwg, 2), dim3(SB_NT), B1Lds<SPLIT>::BYTES, s, a);
+    }
     return cr_check_launch("cr_stack_block_bwd");
 }
 
