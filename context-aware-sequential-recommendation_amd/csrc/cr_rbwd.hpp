@@ -101,13 +101,13 @@ __device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane
 // acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1).
 // BIAS (D == 64: no spare column for the ones trick): the waves with it == 0 also form accb[j] += 1^T g, the column sums
 // of g (an all-ones A operand: every row of the result is the bias gradient).
-template <bool SPLIT, bool BIAS>
+template <bool SPLIT, bool BIAS, int TMAX = SB_TPR>
 __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
                                             int ntr, int it, int jt0) {
     const int lane = lane_now();
     const bf4 ones = (bf4){(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-    for (int t = 0; t < SB_TPR; ++t) {                   // unrolled, wave-uniform guard: several tiles' reads in flight
+    for (int t = 0; t < TMAX; ++t) {                     // unrolled, wave-uniform guard: several tiles' reads in flight
         if (t < ntr) {
             const bf4 ah = tr4(Ah, 16 * t, it, lane);
             const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;

@@ -130,8 +130,10 @@ __device__ __forceinline__ void b1_ln_flush(const float* part, float* dg, float*
 // =====================================================================================================
 // phase 1: LN2 + feed-forward backward of every tile of sequence n (both sides)
 // =====================================================================================================
+struct B1Acc { f32x4 aw1[2], aw2[2], ag[4], ab[4], agF[4], abF[4]; };   // Q side: what phase 1 leaves in registers
+
 template <bool SPLIT, int DS, bool QSIDE>
-__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, bool add) {
+__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A) {
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -145,7 +147,8 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     const int wave = threadIdx.x >> 6;
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-    f32x4 aw1[2], aw2[2], nob[2], ag[4], ab[4], agF[4], abF[4];
+    f32x4 (&aw1)[2] = A.aw1; f32x4 (&aw2)[2] = A.aw2; f32x4 (&ag)[4] = A.ag; f32x4 (&ab)[4] = A.ab; f32x4 (&agF)[4] = A.agF; f32x4 (&abF)[4] = A.abF;
+    f32x4 nob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; nob[j] = aw1[j]; }
 #pragma unroll
@@ -309,20 +312,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(2);
-    if (QSIDE) {
-        const size_t so = (size_t)blockIdx.x * bd.slab_stride;      // one slab per workgroup PAIR: the sides write disjoint ranges
-        b1_wstore(bd.g_w1 + so, D, bd.g_b1 + so, aw1, D, it, jt0, add);
-        b1_wstore(bd.g_w2 + so, D, bd.g_b2 + so, aw2, D, it, jt0, add);
-        // LayerNorm column sums: zero the slots, fold, flush
-        for (int i = threadIdx.x; i < 4 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;       // part and partF are adjacent
-        __syncthreads();
-        b1_ln_fold(part, ag, ab);
-        if (a.has_ln) b1_ln_fold(partF, agF, abF);
-        __syncthreads();
-        b1_ln_flush(part, bd.g_ln2_g + so, bd.g_ln2_b + so, D, add);
-        if (a.has_ln) b1_ln_flush(partF, a.ln.dgamma + so, a.ln.dbeta + so, D, add);
-    }
-    (void)MD;
+    (void)MD; (void)part; (void)partF;
 }
 
 // ---- the embedding backward of a partial of dx, phase-2 half: g = partial * mask * keep / (1 - rate) in the registers ----
@@ -366,61 +356,63 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
 // =====================================================================================================
 // Q side, phases 2 and 3: query-owner pass (dQ), LN1 + Q projection backward, dWq
 // =====================================================================================================
-// K rows natural, V rows in the k order of layout R (w_put_perm's column map), hi (+ lo) images; the additive key bias
+// K rows natural, V rows in the k order of layout R (w_put_perm's column map), hi (+ lo) images; the additive key bias.
+// Issue and put are apart: the loads fly under the stores and the LayerNorm fold that end phase 1.
+struct B1Stage { float va[4][8], vb[4][8]; float kv0; };
+__device__ __forceinline__ void b1_stage_kv_issue(B1Stage& r, const B1Args& a, int base_row, int T16, int D, int M) {
+    const cr_attn_desc& d = a.ad;
+    const int T = a.T, total = T16 * 8;
+    r.kv0 = d.k_valid[base_row + min((int)threadIdx.x, T - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int item = min(tid_now() + u * SB_NT, total - 1);
+        const int row = item >> 3, ch = item & 7;
+        const bool rok = row < T;
+        const int grow = base_row + (rok ? row : 0);
+        const bool fix = item_fix(rok, grow == M - 1, 8 * ch, D);
+        item_issue(r.va[u], d.K + (size_t)grow * d.ld, 8 * ch, D, fix);
+        item_issue(r.vb[u], d.V + (size_t)grow * d.ld, 8 * ch, D, fix);
+    }
+}
 template <bool SPLIT>
-__device__ __forceinline__ void b1_stage_kv(unsigned char* smem, float* kb, const B1Args& a, int base_row, int T16, int D, int M) {
+__device__ __forceinline__ void b1_stage_kv_put(B1Stage& r, unsigned char* smem, float* kb, const B1Args& a, int base_row, int T16, int D, int M) {
     typedef B1Lds<SPLIT> L;
     const cr_attn_desc& d = a.ad;
     __bf16* Kh = reinterpret_cast<__bf16*>(smem);
     __bf16* Vh = reinterpret_cast<__bf16*>(smem + L::MATB);
-    const int T = a.T, total = T16 * 8;
-    constexpr int U = 4;
+    const int T = a.T, total = T16 * 8;                  // T16 <= 224 rows: 1792 items, four per thread
     const bool wg_has_last = base_row + T == M;          // only the last sequence can meet the matrix's last row
-    const int t0 = threadIdx.x;
-    const float kv0 = d.k_valid[base_row + min(t0, T - 1)];
-    for (int i0 = threadIdx.x; i0 < total; i0 += SB_NT * U) {
-        float va[U][8], vb[U][8];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int item = min(i0 + u * SB_NT, total - 1);
-            const int r = item >> 3, ch = item & 7;
-            const bool rok = r < T;
-            const int grow = base_row + (rok ? r : 0);
-            const bool fix = item_fix(rok, grow == M - 1, 8 * ch, D);
-            item_issue(va[u], d.K + (size_t)grow * d.ld, 8 * ch, D, fix);
-            item_issue(vb[u], d.V + (size_t)grow * d.ld, 8 * ch, D, fix);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u * SB_NT < total) {
-                const int item = i0 + u * SB_NT;
-                const int r = item >> 3, ch = item & 7;
-                const bool rok = r < T;
-                const bool fix = wg_has_last && item_fix(rok, r == T - 1, 8 * ch, D);
-                item_mask(va[u], 8 * ch, D, rok, fix);
-                item_mask(vb[u], 8 * ch, D, rok, fix);
-                if (__builtin_expect(wg_has_last && fix, 0)) {           // one thread of the grid
-                    item_refill(va[u], d.K + (size_t)(M - 1) * d.ld, 8 * ch, D);
-                    item_refill(vb[u], d.V + (size_t)(M - 1) * d.ld, 8 * ch, D);
-                }
-                bf8 h, l;
-                split8<SPLIT>(va[u], h, l);
-                const int o = img_off<2>(r, ch);
-                *reinterpret_cast<bf8*>(Kh + o) = h;
-                if (SPLIT) *reinterpret_cast<bf8*>(Kh + B1_FSTR + o) = l;
-                split8<SPLIT>(vb[u], h, l);
-                const int ks = ch >> 2, c4 = ch & 3, hh = c4 >> 1, lga = 2 * (c4 & 1);
-                const int oa = img_off<2>(r, 4 * ks + lga) + 4 * hh, ob = img_off<2>(r, 4 * ks + lga + 1) + 4 * hh;
-                *reinterpret_cast<bf4*>(Vh + oa) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
-                *reinterpret_cast<bf4*>(Vh + ob) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
-                if (SPLIT) {
-                    *reinterpret_cast<bf4*>(Vh + B1_FSTR + oa) = __builtin_shufflevector(l, l, 0, 1, 2, 3);
-                    *reinterpret_cast<bf4*>(Vh + B1_FSTR + ob) = __builtin_shufflevector(l, l, 4, 5, 6, 7);
-                }
+    for (int u = 0; u < 4; ++u) {
+        const int item = tid_now() + u * SB_NT;
+        if (item < total) {
+            const int row = item >> 3, ch = item & 7;
+            const bool rok = row < T;
+            const bool fix = wg_has_last && item_fix(rok, row == T - 1, 8 * ch, D);
+            item_mask(r.va[u], 8 * ch, D, rok, fix);
+            item_mask(r.vb[u], 8 * ch, D, rok, fix);
+            if (__builtin_expect(wg_has_last && fix, 0)) {           // one thread of the grid
+                item_refill(r.va[u], d.K + (size_t)(M - 1) * d.ld, 8 * ch, D);
+                item_refill(r.vb[u], d.V + (size_t)(M - 1) * d.ld, 8 * ch, D);
+            }
+            bf8 h, l;
+            split8<SPLIT>(r.va[u], h, l);
+            const int o = img_off<2>(row, ch);
+            *reinterpret_cast<bf8*>(Kh + o) = h;
+            if (SPLIT) *reinterpret_cast<bf8*>(Kh + B1_FSTR + o) = l;
+            split8<SPLIT>(r.vb[u], h, l);
+            const int ks = ch >> 2, c4 = ch & 3, hh = c4 >> 1, lga = 2 * (c4 & 1);
+            const int oa = img_off<2>(row, 4 * ks + lga) + 4 * hh, ob = img_off<2>(row, 4 * ks + lga + 1) + 4 * hh;
+            *reinterpret_cast<bf4*>(Vh + oa) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
+            *reinterpret_cast<bf4*>(Vh + ob) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
+            if (SPLIT) {
+                *reinterpret_cast<bf4*>(Vh + B1_FSTR + oa) = __builtin_shufflevector(l, l, 0, 1, 2, 3);
+                *reinterpret_cast<bf4*>(Vh + B1_FSTR + ob) = __builtin_shufflevector(l, l, 4, 5, 6, 7);
             }
         }
     }
-    if (t0 < T16) kb[t0] = (t0 < T && kv0 != 0.0f) ? 0.0f : -INFINITY;
+    const int t0 = threadIdx.x;
+    if (t0 < T16) kb[t0] = (t0 < T && r.kv0 != 0.0f) ? 0.0f : -INFINITY;
     if (a.nkt & 1) {                                     // the absent second tile of the last pair: finite (zero) rows, masked keys
         const int im = t0 >> 7, o16 = t0 & 127;
         if (im < L::NIMG) *reinterpret_cast<float4*>(smem + (size_t)im * L::LOB + (size_t)T16 * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -429,7 +421,7 @@ __device__ __forceinline__ void b1_stage_kv(unsigned char* smem, float* kb, cons
 }
 
 template <bool SPLIT, int DS>
-__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add) {
+__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A) {
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -446,16 +438,26 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const size_t MD = (size_t)M * D;
     float* dQg = const_cast<float*>(bd.dqkv);
     B1_TS(9);
-    // ---- phase 2 staging: the image slots of phase 1 are dead behind its last barrier; so are W1 / W2 ----
+    // ---- end of phase 1 + phase 2 staging: the image slots of phase 1 are dead behind its last barrier, so are W1 / W2.
+    // K, V and Wq are requested first; the slab stores and the LayerNorm fold of phase 1 run under those loads.
     {
+        float* partF = fl + L::PARTF; float* gamF = fl + L::GAMF;
+        (void)gamF;
         WRegs<1, SB_NT> w;
+        B1Stage st;
         w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
+        b1_stage_kv_issue(st, a, base_row, T16, D, M);
         const float gv = (threadIdx.x < D) ? bk.ln1_g[threadIdx.x] : 0.0f;
-        __syncthreads();                                  // the LayerNorm flush of phase 1 has read `part`; gam (gamma2) is dead
-        b1_stage_kv<SPLIT>(smem, kb, a, base_row, T16, D, M);
+        const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+        const int it = wave >> 1, jt0 = 2 * (wave & 1);
+        b1_wstore(bd.g_w1 + so, D, bd.g_b1 + so, A.aw1, D, it, jt0, add);
+        b1_wstore(bd.g_w2 + so, D, bd.g_b2 + so, A.aw2, D, it, jt0, add);
+        // (dgamma2 dbeta2 and the final LayerNorm's sums leave on the K side: it runs the same chain and is the shorter side)
+        b1_stage_kv_put<SPLIT>(st, smem, kb, a, base_row, T16, D, M);
         w_put_perm<1, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
-        if (threadIdx.x < 64) gam[threadIdx.x] = gv;
+        if (threadIdx.x < 64) gam[threadIdx.x] = gv;      // (gamma2 is dead behind phase 1's last barrier)
         for (int i = threadIdx.x; i < 2 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;
+        (void)partF;
     }
     __syncthreads();
     B1_TS(3);
@@ -472,6 +474,21 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     }
     const unsigned tpk = a.qpk[wave];
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+    // a tile's inputs (Q fragment in operand layout, d_o in layout R, the forward's row statistics); the NEXT tile's are
+    // requested behind the current tile's loop, under its row chain
+    GFrag<2> qn;
+    RRaw rdo;
+    f4s st = (f4s){0.f, 0.f, 2.0f, 0.f};
+    float qv_n = 0.0f;
+    auto issue_tile = [&](int qt_) {
+        const int q0_ = 16 * qt_, q_ = q0_ + (lane_now() & 15);
+        const int m_ = base_row + min(q_, T - 1);
+        gfrag_issue<2>(qn, d.Q, d.ld, base_row + q0_, 0, T - q0_, D, M);
+        r_issue(rdo, bd.d_o, (u32)m_ * (u32)(4 * D), dcx, q_ < T);
+        st = *reinterpret_cast<const f4s*>(d.row_stats + (size_t)m_ * 4);
+        qv_n = d.q_valid[m_];
+    };
+    if ((int)(tpk & 31u) < a.nkt) issue_tile((int)(tpk & 31u));
 #pragma unroll 1
     for (int ti = 0; ti < 2; ++ti) {
         const int qt = (int)((tpk >> (5 * ti)) & 31u);
@@ -481,12 +498,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const bool rok = q < T;
         const int m = base_row + min(q, T - 1);
         const u32 mo = (u32)m * (u32)(4 * D);
-        GFrag<2> qn;
-        RRaw rdo;
-        gfrag_issue<2>(qn, d.Q, d.ld, base_row + q0, 0, T - q0, D, M);
-        r_issue(rdo, bd.d_o, mo, dcx, rok);
-        const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + min(q, T - 1)) * 4);
-        const float qvq = rok ? d.q_valid[m] : 0.0f;
+        const float qvq = rok ? qv_n : 0.0f;
         const float delta = sdel[min(q, T16 - 1)];
         const bool normal = rok && st.z == 0.0f;
         const float mrow = normal ? st.x : 1e30f, inv = normal ? st.y : 0.0f;
@@ -594,9 +606,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         }
         if (ti == 0) B1_TS(6);
         // ---- the tile goes on through registers: dq_in = dQ Wq^T + d_o, LN1 backward -> this side's partial of dx ----
-        RRaw rx, rdx;
-        r_issue(rdo, bd.d_o, mo, dcx, rok);
+        RRaw rx, rdx, rdo2;
+        r_issue(rdo2, bd.d_o, mo, dcx, rok);
         r_issue(rx, bk.x, mo, dcx);
+        issue_tile(min((int)((tpk >> 5) & 31u), a.nkt - 1));              // the next tile's inputs (unconditional: the load count stays static)
         if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
         r_store(dQg, mo, dq, rok, dcx);                                   // for the weight-gradient images of phase 3
         f32x4 dqin[4];
@@ -605,7 +618,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
             r_split<SPLIT>(dq, gh, gl);
             r_gemm_t<SPLIT, false>(dqin, Wi, Wi + ST_WIMG, gh, gl);
             f32x4 dob[4];
-            r_finish(dob, rdo, dcx);
+            r_finish(dob, rdo2, dcx);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) dqin[ct] += dob[ct];
         }
@@ -637,28 +650,26 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; nob[j] = awq[j]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
-    const int R = a.nkt > SB_TPR ? 2 : 1;
+    // ONE round: the images of q_in and dQ over all tiles (2 x 14 tiles x hi, lo) are exactly the image area; wave w writes
+    // tiles w and w + 8
+    __bf16* Gm = reinterpret_cast<__bf16*>(smem + L::MATB);
 #pragma unroll 1
-    for (int rd = 0; rd < R; ++rd) {
-        const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
-        if (wave < ntr) {
-            const int qq = 16 * (rd * SB_TPR + wave) + li;
-            const bool rok = qq < T;
-            const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
-            RRaw r1, r2;
-            r_issue(r1, bk.q_in, mo, dcx);
-            r_issue(r2, dQg, mo, dcx, rok);
-            f32x4 qin[4], dQ[4];
-            r_finish(qin, r1, dcx);
-            plant_one(qin, D);
-            img_put<SPLIT>(Im, Im + SB_IMG, 16 * wave, qin);
-            r_finish(dQ, r2, dcx);
-            img_put<SPLIT>(Im + IST, Im + IST + SB_IMG, 16 * wave, dQ);
-        }
-        __syncthreads();
-        wgrad_accum<SPLIT, false>(awq, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);       // dWq (+ dbq) += q_in^T dQ
-        __syncthreads();
+    for (int tt = wave; tt < a.nkt; tt += SB_WAVES) {
+        const int qq = 16 * tt + li;
+        const bool rok = qq < T;
+        const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
+        RRaw r1, r2;
+        r_issue(r1, bk.q_in, mo, dcx);
+        r_issue(r2, dQg, mo, dcx, rok);
+        f32x4 qin[4], dQ[4];
+        r_finish(qin, r1, dcx);
+        plant_one(qin, D);
+        img_put<SPLIT>(Im, Im + B1_FSTR, 16 * tt, qin);
+        r_finish(dQ, r2, dcx);
+        img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt, dQ);
     }
+    __syncthreads();
+    wgrad_accum<SPLIT, false, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);      // dWq (+ dbq) += q_in^T dQ
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
@@ -670,7 +681,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 // K side, phases 2 and 3: key-owner pass (dK, dV), K / V projections backward, dWk dWv
 // =====================================================================================================
 template <bool SPLIT, int DS>
-__device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add) {
+__device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A) {
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -696,7 +707,18 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         const int t = threadIdx.x, tc = min(t, T - 1);
         const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + tc) * 4);
         const float qv = d.q_valid[base_row + tc];
-        __syncthreads();                                  // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete
+        {
+            // dgamma2 dbeta2 (+ the final LayerNorm's sums) of this side's phase 1: slots zeroed, folded, flushed
+            float* part = fl + L::PART; float* partF = fl + L::PARTF;
+            for (int i = threadIdx.x; i < 4 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;       // part and partF are adjacent
+            __syncthreads();                              // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete
+            b1_ln_fold(part, A.ag, A.ab);
+            if (a.has_ln) b1_ln_fold(partF, A.agF, A.abF);
+            __syncthreads();
+            const size_t so = (size_t)blockIdx.x * bd.slab_stride;
+            b1_ln_flush(part, bd.g_ln2_g + so, bd.g_ln2_b + so, D, add);
+            if (a.has_ln) b1_ln_flush(partF, a.ln.dgamma + so, a.ln.dbeta + so, D, add);
+        }
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
         // stored so that the inner loop is branch-free: A[q][key] = valid * exp2(s c - smx) * sinv + (key < T ? suni : 0);
         // normal row: suni = 0; uniform row: sinv = 0, suni = 1/T; dead row: both 0 (smx = 1e30 wherever sinv = 0)
@@ -737,6 +759,15 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
     }
     const unsigned tpk = a.kpk[wave];
+    // a tile's own K / V rows (operand layout, from memory); the NEXT tile's are requested behind the current tile's loop
+    GFrag<2> kn, vn;
+    float kvn = 0.0f;
+    auto issue_tile = [&](int kt_) {
+        gfrag_issue<2>(kn, d.K, d.ld, base_row + 16 * kt_, 0, T - 16 * kt_, D, M);
+        gfrag_issue<2>(vn, d.V, d.ld, base_row + 16 * kt_, 0, T - 16 * kt_, D, M);
+        kvn = d.k_valid[base_row + min(16 * kt_ + (lane_now() & 15), T - 1)];
+    };
+    if ((int)(tpk & 31u) < a.nkt) issue_tile((int)(tpk & 31u));
 #pragma unroll 1
     for (int ti = 0; ti < 2; ++ti) {
         const int kt = (int)((tpk >> (5 * ti)) & 31u);
@@ -748,10 +779,6 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         const u32 mo = (u32)m * (u32)(4 * D);
         const float key_in_T = rok ? 1.0f : 0.0f;
         const uint32_t drop_base = attn_row_idx(d, 0, n, 0) + (uint32_t)key;
-        GFrag<2> kn, vn;
-        gfrag_issue<2>(kn, d.K, d.ld, base_row + key0, 0, T - key0, D, M);
-        gfrag_issue<2>(vn, d.V, d.ld, base_row + key0, 0, T - key0, D, M);
-        const float kvn = d.k_valid[m];
         bf8 kh[2], kl[2], vh[2], vl[2];
         gfrag_finish<SPLIT, 2>(kn, d.K, d.ld, base_row + key0, 0, T - key0, D, M, kh, kl);
         gfrag_finish<SPLIT, 2>(vn, d.V, d.ld, base_row + key0, 0, T - key0, D, M, vh, vl);
@@ -880,6 +907,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             }
         }
         if (ti == 0) B1_TS(6);
+        issue_tile(min((int)((tpk >> 5) & 31u), a.nkt - 1));              // the next tile's inputs (unconditional: the load count stays static)
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
         r_store(dKg, mo, dk, rok, dcx);                                   // for the weight-gradient images of phase 3
         r_store(dVg, mo, dv, rok, dcx);
@@ -948,11 +976,13 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     // registers.  More sequences than slabs are further launches that ADD to the slabs -- the host's loop.)
     const int n = a.n0 + (int)blockIdx.x;
     if (blockIdx.y == 0) {
-        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, a.add != 0);
-        b1_k_side<SPLIT, DS>(a, smem_raw, n, a.add != 0);
+        B1Acc acc;
+        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, acc);
+        b1_k_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc);
     } else {
-        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, a.add != 0);
-        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0);
+        B1Acc acc;
+        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, acc);
+        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc);
     }
     B1_TS(31);
 }
@@ -967,7 +997,9 @@ static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
     int cost[16], order[16], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < 8; ++w) pk[w] = 0x3FFu;                           // two "none" entries
     for (int t = 0; t < nkt; ++t) {
-        cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2;
+        // pair iterations + what a tile costs whatever its length (fragments from memory, the row chain behind the loop,
+        // stores: about two iterations' worth on the timeline, tools/b1_ts.py)
+        cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2 + 2;
         order[t] = t;
     }
     for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
