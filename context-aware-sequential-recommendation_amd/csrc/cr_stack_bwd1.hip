@@ -36,6 +36,10 @@
 
 #include "cr_rbwd.hpp"
 
+// Global rows written by one wave and read by another wave of the workgroup later on (d_o, dQ / dK / dV, the scatter rows) cross a
+// workgroup barrier; __syncthreads() itself only drains the LDS counter on this target (s_waitcnt lgkmcnt(0); s_barrier), so the
+// writing wave drains its vector-memory counter explicitly first
+#define B1_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define B1_ROWS 224                       // rows of an attention image (14 tiles of 16)
 #define B1_FSTR (B1_ROWS * 64)            // bf16 elements of one image half
 
@@ -312,6 +316,11 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(2);
+    if (QSIDE) {
+        // d_o rows are read back in phase 2 by OTHER waves (the tiles are dealt differently there): this wave's stores are drained
+        // here and a barrier follows (the Q side's staging block ends with one) before any of those reads
+        B1_DRAIN();
+    }
     (void)MD; (void)part; (void)partF;
 }
 
@@ -333,21 +342,27 @@ __device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4]
             dxl[ct][r] = v;
         }
 }
-// phase-3 half: the waiting rows of sequence n, one row per step, lane = column: one contiguous float-atomic burst per table row
+// last thing a side does: the waiting rows of sequence n, lane = column: one contiguous float-atomic burst per table row.
+// A wave takes 16 rows at a time: their ids and gradient rows are requested together, then the atomics go out back to back
+// and the wave ends with them in flight (nothing in the kernel waits behind them: placed in front of phase 3 they held its
+// loads back for the ~3000 clocks an atomic stays in the memory queue: +17 us on the block that scatters).
 __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* buf, int n, int D) {
     if (!a.sc.table_grad && !a.sc.pos_grad) return;
     const cr_embed_desc& e = a.sc.f;
     const int wave = threadIdx.x >> 6, col = threadIdx.x & 63, T = a.T;
     for (int t0 = 16 * wave; t0 < T; t0 += 16 * SB_WAVES) {
         const int nr = min(16, T - t0);
-#pragma unroll 4
-        for (int r = 0; r < nr; ++r) {
-            const int m = n * T + t0 + r;
-            const int id = e.ids[m];
-            if (col < D) {
-                const float g = buf[(size_t)m * D + col];
-                if (a.sc.table_grad && !(e.zero_pad && id == 0)) atomicAdd(a.sc.table_grad + (size_t)id * D + col, g * e.scale);
-                if (a.sc.pos_grad) atomicAdd(a.sc.pos_grad + (size_t)(m % e.T) * D + col, g);
+        const int m0 = n * T + t0;
+        const int my_id = e.ids[m0 + min(col & 15, nr - 1)];             // lanes 0..15: the id of row t0 + lane
+        float g[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = (r < nr && col < D) ? buf[(size_t)(m0 + r) * D + col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int id = __shfl(my_id, r, 64);
+            if (r < nr && col < D) {
+                if (a.sc.table_grad && !(e.zero_pad && id == 0)) atomicAdd(a.sc.table_grad + (size_t)id * D + col, g[r] * e.scale);
+                if (a.sc.pos_grad) atomicAdd(a.sc.pos_grad + (size_t)((m0 + r) % e.T) * D + col, g[r]);
             }
         }
     }
@@ -609,7 +624,6 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         RRaw rx, rdx, rdo2;
         r_issue(rdo2, bd.d_o, mo, dcx, rok);
         r_issue(rx, bk.x, mo, dcx);
-        issue_tile(min((int)((tpk >> 5) & 31u), a.nkt - 1));              // the next tile's inputs (unconditional: the load count stays static)
         if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
         r_store(dQg, mo, dq, rok, dcx);                                   // for the weight-gradient images of phase 3
         f32x4 dqin[4];
@@ -626,6 +640,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; }
         r_finish(x, rx, dcx);
+        // the NEXT tile's inputs, under the LayerNorm backward and the stores.  Behind the chain's own loads, and only where a next
+        // tile exists: an unconditional request in front of them (static load counts, no full drain at the first use) made single
+        // columns of dx differ between runs of the same step (tools/diag_repro.py) -- not understood, not kept
+        if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));
         r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
         b1_ln_fold(part, ag, ab);
         if (bd.dx_accumulate) {
@@ -642,10 +660,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(4);
+    B1_DRAIN();
     __syncthreads();                                      // every pass is done: the K / V images are dead, dQ rows are visible
     B1_TS(7);
-    // ---- phase 3: scatter of this side's partial, dWq dbq from images of q_in and dQ, dgamma1 dbeta1 ----
-    if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
+    // ---- phase 3: dWq dbq from images of q_in and dQ, dgamma1 dbeta1; then the scatter of this side's partial ----
     f32x4 awq[2], nob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; nob[j] = awq[j]; }
@@ -673,6 +691,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
+    if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
 }
@@ -907,7 +926,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             }
         }
         if (ti == 0) B1_TS(6);
-        issue_tile(min((int)((tpk >> 5) & 31u), a.nkt - 1));              // the next tile's inputs (unconditional: the load count stays static)
+        if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));   // the next tile's K / V rows, under this tile's row chain
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
         r_store(dKg, mo, dk, rok, dcx);                                   // for the weight-gradient images of phase 3
         r_store(dVg, mo, dv, rok, dcx);
@@ -927,10 +946,10 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(4);
+    B1_DRAIN();
     __syncthreads();                                      // every pass is done: the Q / dOut images are dead, dK / dV rows are visible
     B1_TS(7);
-    // ---- phase 3: scatter of this side's partial, dWk dbk dWv dbv from images of x, dK, dV ----
-    if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
+    // ---- phase 3: dWk dbk dWv dbv from images of x, dK, dV; then the scatter of this side's partial ----
     f32x4 awk[2], awv[2], nob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; nob[j] = awk[j]; }
@@ -964,6 +983,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
     b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
+    if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
 

@@ -352,6 +352,35 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
         assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1) * gmax, k
 
 
+@pytest.mark.parametrize("model", ["cast_1", "cast_3"])
+def test_block_backward_rows_are_reproducible_at_the_headline_length(E, model):
+    """Every activation-gradient buffer of a step (d_o, dQ / dK / dV, both partials of every block input, what the consumers
+    make of them) and the dense slabs hold the same bits on ten runs of the same step at T = 200: the rows that cross from one
+    wave to another inside cr_stack_block_bwd (through memory, behind workgroup barriers) included.  (A variant of the kernel
+    that requested the next tile's inputs unconditionally differed in single columns of dx in about one run in four.)"""
+    rs = np.random.RandomState(250)
+    B, T, D, itemnum = 3, 200, 50, 300
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.1, max_bins=200, num_context_blocks=1, lr=1e-3, seed=11)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=5)
+    assert "cr_stack_block_bwd" in [n for n, _, _ in eng.bwd]
+    eng.P.add_(0.05 * torch.randn(eng.P.numel(), generator=torch.Generator().manual_seed(5)).to(eng.P.device))
+    batch = make_batch(rs, B, T, itemnum, 200)
+    ref = None
+    for _ in range(10):
+        eng.set_batch(*batch)
+        eng.set_step(1)
+        eng.Gflat.zero_()
+        eng.launch_step(apply=False)
+        torch.cuda.synchronize()
+        cur = {k: v.clone() for k, v in eng._bufs.items() if v.dtype == torch.float32}
+        cur["Gs"] = eng.Gs.clone()
+        if ref is None:
+            ref = cur
+        else:
+            bad = [k for k in cur if not torch.equal(cur[k], ref[k]) and not torch.isnan(cur[k]).any()]
+            assert not bad, bad
+
+
 @pytest.mark.parametrize("B,n_slabs", [(6, 16), (9, 4)])
 def test_block_backward_is_bitwise_reproducible(E, B, n_slabs):
     """cr_stack_block_bwd: slabs written in a fixed order by one workgroup pair per sequence (and added to, sequence after
