@@ -127,6 +127,11 @@ def algo_work(name, fnargs, eng):
         return 2.0 * M * D * 6 * D, None, "mfma"
     if name in ("cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads"):
         return 2.0 * M * D * 4 * D, None, "mfma"
+    if name == "cr_stack_block_bwd":
+        # one launch per block: feed-forward backward (2 data + 2 weight gradients) + attention backward (2 x forward: SURVEY 8d)
+        # + Q / K / V projections backward (3 data + 3 weight gradients).  ALGORITHMIC work: the chain both workgroups of a
+        # sequence run (the feed-forward data gradients, twice) is counted once
+        return 2.0 * M * D * 4 * D + 2.0 * 2.0 * D * T * (T + 1) * B + 2.0 * M * D * 6 * D, None, "mfma"
     # hidden sizes 128 / 192 / 256 (cr_wide.hip): the activations do not fit the caches at these sizes (M x D x 4 = 13 MB per
     # tensor at config C4, ~20 tensors per block), so the row phases are priced against HBM: rows read + rows written
     if name == "cr_wide_ln_qkv_fwd":
@@ -196,7 +201,7 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
               "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
-              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_heads": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"],
+              "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_heads": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"], "cr_stack_block_bwd": ["k_stack_block_bwd"],
               "cr_wide_ln_qkv_fwd": ["k_wide_qkv_fwd"], "cr_wide_ln_ffn_fwd": ["k_wide_ffn_fwd"], "cr_wide_ln_ffn_bwd": ["k_wide_ffn_bwd"],
               "cr_wide_ln_qkv_bwd": ["k_wide_qkv_bwd"], "cr_gemm_rows": ["k_gemm_rows"], "cr_gemm_wgrad": ["k_gemm_wgrad"]}
 
@@ -543,11 +548,11 @@ def main():
                              "mfma_busy_frac (matrix-pipe busy share) are NOT measured in this run: they are read from the committed "
                              "rocprofv3 --pmc summary of this command and workload: %s"
                              % ("flops" if bound == "mfma" else "bytes", d["launches"], src))
-        if name.startswith("cr_attn"):
+        if name.startswith("cr_attn") or name in ("cr_stack_fwd", "cr_stack_block_bwd"):
             roofline["executed_flop_frac"] = executed_tile_fraction(host_batches, T)
         # the attention entries on their own (the kernels the north-star target is stated on), whichever entry dominates
         attn = {}
-        for n_ in ("cr_attn_fwd", "cr_attn_bwd"):
+        for n_ in ("cr_attn_fwd", "cr_attn_bwd", "cr_stack_fwd", "cr_stack_block_bwd"):    # (the last two hold the attention core since rounds 2 / 3)
             if n_ in by_name:
                 a = by_name[n_]
                 tf = a["flops"] / (a["us"] * 1e-6) / 1e12

@@ -54,6 +54,7 @@ struct B1Args {
     float* d_addend2;                     // scatter: K side's partial of d_addend
     float* sbuf; float* sbuf2;            // scatter: where the masked partial rows wait for phase 3 ([M, D] each)
     int B, T, nkt, scatter, has_ln;
+    int small;                            // scatter: small-table mode: each side reduces its partial into an LDS image of the table and writes slab (side * gridDim.x + blockIdx.x)
     int n0, add;                          // this launch: sequences n0 .. n0 + gridDim.x - 1; add: the slabs already hold earlier sequences' sums
     float isd, isd_log2e, invT;
     unsigned qpk[8], kpk[8];              // tiles of wave w in the attention passes: two 5-bit tile numbers, 31 = none
@@ -366,6 +367,58 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
             }
         }
     }
+}
+
+// Small-table form of the scatter (context tables of 8 .. 201 rows: cr_embed_bwd's small-table mode, its contract): thousands of
+// rows land in a handful of table rows, so float atomics would serialise on hot rows.  Each side reduces the waiting rows of
+// its partial into an LDS image of the table -- every table row has ONE owner wave (id mod 8): a wave scans the ids of 64
+// rows at a time, requests up to 16 of the rows it owns together (lane = column) and adds them with plain read-add-write --
+// and writes the image as its slab: slab blockIdx.x (Q side) or gridDim.x + blockIdx.x (K side).  Runs last: the image area is free.
+__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, const float* buf, int n, int D, bool add) {
+    const cr_embed_desc& e = a.sc.f;
+    float* tab = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, T = a.T;
+    const int nt = e.V * D;
+    __syncthreads();                                      // the weight-gradient images are dead
+    for (int i = threadIdx.x; i < (nt + 3) >> 2; i += SB_NT) *reinterpret_cast<float4*>(tab + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    constexpr int U = 16;
+    const bool col = lane < D;
+    for (int h0 = 0; h0 < T; h0 += 64) {
+        const int t = h0 + lane;
+        const bool act = t < T;
+        const int id = act ? e.ids[n * T + t] : 0;
+        const bool mine = act && !(e.zero_pad && id == 0) && ((id & (SB_WAVES - 1)) == wave);
+        unsigned long long todo = __ballot(mine ? 1 : 0);
+        while (todo) {
+            float g[U];
+            int rr[U];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (todo) {
+                    const int r = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    rr[k] = r;
+                    g[k] = col ? buf[(size_t)(n * T + h0 + r) * D + lane] : 0.0f;
+                    cnt = k + 1;
+                } else {
+                    rr[k] = 0;
+                    g[k] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (k < cnt) {
+                    const int rid = __shfl(id, rr[k], 64);
+                    if (col) tab[rid * D + lane] += g[k] * e.scale;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = a.sc.table_grad + (size_t)((blockIdx.y == 0 ? gridDim.x : 0) + blockIdx.x) * a.sc.slab_stride;
+    for (int i = threadIdx.x; i < nt; i += SB_NT) slab[i] = add ? slab[i] + tab[i] : tab[i];
 }
 
 // =====================================================================================================
@@ -691,7 +744,8 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
-    if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
+    if (a.scatter && a.small) b1_small_table(a, smem, a.sbuf, n, D, add);
+    else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
 }
@@ -983,7 +1037,8 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
     b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
-    if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
+    if (a.scatter && a.small) b1_small_table(a, smem, a.sbuf2, n, D, add);
+    else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
 
@@ -1103,9 +1158,15 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
         const cr_embed_desc* e = &sc->f;
         CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
                    "cr_stack_block_bwd: the embedding recipe must describe the block's dense input x");
-        CR_REQUIRE(sc->n_slabs == 0, "cr_stack_block_bwd: small-table mode is not fused");
         CR_REQUIRE(!bd->dx_accumulate, "cr_stack_block_bwd: dx_accumulate with a scatter (this kernel must be the only producer of dx)");
         CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "cr_stack_block_bwd: nothing to scatter into");
+        if (sc->n_slabs > 0) {
+            // small-table mode (cr_embed_bwd's contract: every slab in use written, their sum is the gradient): two slabs per pair
+            const int nw = B < bd->n_slabs ? B : bd->n_slabs;
+            CR_REQUIRE(sc->table_grad && !sc->pos_grad && (long long)e->V * d->D <= 12288 && sc->n_slabs >= 2 * nw,
+                       "cr_stack_block_bwd: small-table scatter needs table_grad, no pos_grad, V * D <= 12288 and n_slabs >= 2 * min(B, n_slabs of the block)");
+            a.small = 1;
+        }
         CR_REQUIRE(sc->d_addend == nullptr || (e->ld_add == d->D && x->d_addend2 != nullptr), "cr_stack_block_bwd: d_addend must be dense [M, D] and come with d_addend2");
         a.sc = *sc;
         a.scatter = 1;

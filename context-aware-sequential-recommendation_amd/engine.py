@@ -368,9 +368,11 @@ class Engine:
         # the first block's QKV backward can apply this scatter itself (cr_block_ln_qkv_bwd_scatter): large-table
         # mode only (a learned positional table's gradient is then accumulated with atomics: its slot in the table
         # section is zero at that point); the block's factory (it runs before this one) claims it
-        if (out.data_ptr() in self._pending_embed and not small
-                and (addend is None or addend[0].shape[1] == D)):
-            self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None)
+        # (a small context table: only cr_stack_block_bwd takes it -- reduced in LDS, written as slabs -- and only with two slabs
+        #  per sequence pair to write to)
+        if (out.data_ptr() in self._pending_embed and (addend is None or addend[0].shape[1] == D)
+                and (not small or (V * D <= 12288 and D <= 64 and pos is None and self.n_slabs >= 2 * min(self.B, self.n_slabs)))):
+            self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None, small, table)
 
         def factory():
             if out.data_ptr() in self._scatter_claimed:
@@ -769,6 +771,8 @@ class Engine:
                 if rec is not None and not bbd.dx_accumulate:
                     self._scatter_claimed.add(x.data_ptr())
                     sc = rec[0]()
+                    if rec[2]:                                             # small table: two slabs per sequence pair
+                        self._block_slab_range(rec[3], rec[3], 2 * min(self.B, self.n_slabs))
                     if sc.d_addend:
                         dadd2 = self.buf(pfx + "dadd2", D)
                         ext.d_addend2 = dadd2.data_ptr()
@@ -815,7 +819,7 @@ class Engine:
                 self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             recipe = self._scatter_recipe.get(x.data_ptr())
-            if recipe is not None and not bbd.dx_accumulate:
+            if recipe is not None and not recipe[2] and not bbd.dx_accumulate:
                 self._scatter_claimed.add(x.data_ptr())
                 if rows_bf:
                     self._call(lst, "cr_stack_qkv_bwd_scatter", C.byref(bbd), C.byref(recipe[0]()), B, T, prec)
@@ -829,12 +833,12 @@ class Engine:
         factory.pair_aware = True                      # (takes dy2 where it can; any other pending pair is not its input)
         self._bwd_factories.append(factory)
 
-    def _block_slab_range(self, first, last):
+    def _block_slab_range(self, first, last, count=None):
         """Parameters first..last (contiguous in the layout) get their gradient from cr_stack_block_bwd: one slab per sequence
-        pair, min(B, n_slabs) slabs in use (cr_adam_desc.slab_counts)."""
+        pair, min(B, n_slabs) slabs in use (cr_adam_desc.slab_counts); `count`: another number of slabs."""
         a = self.layout.entries[first][0] - self.layout.n_table
         off, shape, _, _ = self.layout.entries[last]
-        self._block_bwd_ranges.append((a, off + int(np.prod(shape)) - self.layout.n_table, min(self.B, self.n_slabs)))
+        self._block_bwd_ranges.append((a, off + int(np.prod(shape)) - self.layout.n_table, min(self.B, self.n_slabs) if count is None else count))
 
     def _stack_kernel_fits(self, nblocks, want_attn):
         """Shapes cr_stack_fwd takes (castrec.h): one head (or two of 32 columns), D 8..64, bf16 arithmetic, K / V images +

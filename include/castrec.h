@@ -338,7 +338,9 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
  *     K / V projections); the caller's gradient is their SUM.  Likewise the input gradient may arrive as a sum: d->dy + x->dy2
  *     (or, with the final LayerNorm `lnf` as in cr_stack_ffn_bwd_ln: lnf->dy + x->lnf_dy2);
  *   - with `sc` (the embedding backward of the block input, as cr_stack_qkv_bwd_scatter): each side applies it to its partial:
- *     table / positional gradients by float atomics, the addend's gradient as sc->d_addend + x->d_addend2 (their sum);
+ *     table / positional gradients by float atomics, the addend's gradient as sc->d_addend + x->d_addend2 (their sum); a
+ *     small-table recipe (sc->n_slabs > 0, cr_embed_bwd's small-table mode) is reduced in LDS instead and leaves as slabs:
+ *     pair p writes slabs p and min(B, n_slabs) + p of sc->table_grad (sc->n_slabs >= 2 min(B, n_slabs) required);
  *   - d->d_o, d->dqkv ([3, M, D]) are workspaces here; d->attn_delta is not used (delta stays on chip);
  *   - ONE slab per sequence pair: workgroup pair p writes slab p (p < min(B, n_slabs)) and adds its later sequences to it;
  *     slabs >= min(B, n_slabs) are not written by this call.
