@@ -15,7 +15,13 @@ LIB_TL = os.path.join(PKG, "libcastrec_tl.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
            "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         # no SLP vectorisation: it packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  (a) Beside MFMAs those cost more
+         # than the two scalar ops (MI355X_MICROARCH.md, cycle constants).  (b) Round 3: in cr_stack_bwd1.hip a compiler-made
+         # v_pk_mul_f32 whose source pair was overwritten by the very next instruction returned a wrong LOW half in lanes 48..63,
+         # about once in 350 steps (single columns of a gradient tile; 7 of 2400 runs against 0 of 2400 without the packing, same
+         # box, tools/diag_repro.py).  Not understood further; the hand-written f32x2 arithmetic (cr_bf16.hpp split8) is unaffected.
+         "-fno-slp-vectorize"]
 
 
 def _hipcc():

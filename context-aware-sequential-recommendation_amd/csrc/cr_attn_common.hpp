@@ -67,10 +67,15 @@ __device__ __forceinline__ float grp_max(float v) {
     return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 __device__ __forceinline__ float grp_sum(float v) {
+#ifdef CR_NO_PERMLANE_SWAP
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+#else
     cr_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r.x) + __uint_as_float(r.y);
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
+#endif
 }
 
 __device__ __forceinline__ int wave_min_i(int v) {

@@ -374,47 +374,42 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
 // its partial into an LDS image of the table -- every table row has ONE owner wave (id mod 8): a wave scans the ids of 64
 // rows at a time, requests up to 16 of the rows it owns together (lane = column) and adds them with plain read-add-write --
 // and writes the image as its slab: slab blockIdx.x (Q side) or gridDim.x + blockIdx.x (K side).  Runs last: the image area is free.
-__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, const float* buf, int n, int D, bool add) {
+__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* lst, const float* buf, int n, int D, bool add) {
     const cr_embed_desc& e = a.sc.f;
     float* tab = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, T = a.T;
     const int nt = e.V * D;
+    // ids of all rows of the sequence (T <= 224: four per lane), requested before the image is zeroed
+    int id4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) id4[j] = (lane + 64 * j < T) ? e.ids[n * T + lane + 64 * j] : 0;
     __syncthreads();                                      // the weight-gradient images are dead
     for (int i = threadIdx.x; i < (nt + 3) >> 2; i += SB_NT) *reinterpret_cast<float4*>(tab + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    // the rows this wave owns (table row id mod 8 == wave), compacted into the wave's list: entry = row | id << 8
+    int* mine_lst = lst + wave * B1_ROWS;
+    int count = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = lane + 64 * j, id = id4[j];
+        const bool mine = row < T && !(e.zero_pad && id == 0) && ((id & (SB_WAVES - 1)) == wave);
+        const unsigned long long mk = __ballot(mine ? 1 : 0);
+        if (mine) mine_lst[count + __popcll(mk & ((1ull << lane) - 1ull))] = row | (id << 8);
+        count += __popcll(mk);
+    }
+    __syncthreads();                                      // the image is zero everywhere
     constexpr int U = 16;
     const bool col = lane < D;
-    for (int h0 = 0; h0 < T; h0 += 64) {
-        const int t = h0 + lane;
-        const bool act = t < T;
-        const int id = act ? e.ids[n * T + t] : 0;
-        const bool mine = act && !(e.zero_pad && id == 0) && ((id & (SB_WAVES - 1)) == wave);
-        unsigned long long todo = __ballot(mine ? 1 : 0);
-        while (todo) {
-            float g[U];
-            int rr[U];
-            int cnt = 0;
+    for (int k0 = 0; k0 < count; k0 += U) {               // (wave-uniform) up to 16 rows in flight: one memory round trip per batch
+        float g[U];
+        int ent[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (todo) {
-                    const int r = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    rr[k] = r;
-                    g[k] = col ? buf[(size_t)(n * T + h0 + r) * D + lane] : 0.0f;
-                    cnt = k + 1;
-                } else {
-                    rr[k] = 0;
-                    g[k] = 0.0f;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (k < cnt) {
-                    const int rid = __shfl(id, rr[k], 64);
-                    if (col) tab[rid * D + lane] += g[k] * e.scale;
-                }
-            }
+        for (int k = 0; k < U; ++k) {
+            ent[k] = (k0 + k < count) ? mine_lst[k0 + k] : 0;
+            g[k] = (k0 + k < count && col) ? buf[(size_t)(n * T + (ent[k] & 255)) * D + lane] : 0.0f;
         }
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (k0 + k < count && col) tab[(ent[k] >> 8) * D + lane] += g[k] * e.scale;
     }
     __syncthreads();
     float* slab = a.sc.table_grad + (size_t)((blockIdx.y == 0 ? gridDim.x : 0) + blockIdx.x) * a.sc.slab_stride;
@@ -744,7 +739,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
-    if (a.scatter && a.small) b1_small_table(a, smem, a.sbuf, n, D, add);
+    if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part + partF: 8 x 224 list entries)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
@@ -1037,7 +1032,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
     b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
-    if (a.scatter && a.small) b1_small_table(a, smem, a.sbuf2, n, D, add);
+    if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
