@@ -37,7 +37,10 @@ __device__ __forceinline__ void rot4(f4e v, int shift, float (&e)[4]) {
 }
 template <int LPR>
 __global__ __launch_bounds__(256) void k_embed_fwd_vec(cr_embed_desc d) {
-    constexpr int RPW = 64 / LPR, R = 4;
+    // R row groups in flight per wave.  Two batches of independent loads: first every group's id (+ row mask), then every
+    // group's table row and positional row, unconditionally (the zero-pad row 0 is read like any other and zeroed by a select:
+    // a branch per group put each group's id -> row chain behind the previous one); then the arithmetic and the stores.
+    constexpr int RPW = 64 / LPR, R = LPR >= 32 ? 8 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, l = lane % LPR;          // row within the group, 4-column chunk within the row
     const int nchunk = (d.D + 3) >> 2;
@@ -46,29 +49,32 @@ __global__ __launch_bounds__(256) void k_embed_fwd_vec(cr_embed_desc d) {
     const int rows_per_iter = RPW * R;
     for (int mb = (blockIdx.x * 4 + wave) * rows_per_iter; mb < d.M; mb += gridDim.x * 4 * rows_per_iter) {
         f4e v[R], pv[R];
-        int mrow[R];
+        int mrow[R], id[R], mk[R];
         bool act[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int m = mb + u * RPW + sub;
             mrow[u] = m;
             act[u] = (m < d.M) && (l < nchunk);
-            v[u] = (f4e){0.f, 0.f, 0.f, 0.f};
+            const int mc = min(m, d.M - 1);
+            id[u] = d.ids[mc];
+            mk[u] = d.mask_ids ? d.mask_ids[mc] : 1;
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            v[u] = *reinterpret_cast<const f4e*>(d.table + (size_t)id[u] * d.D + col0);
             pv[u] = (f4e){0.f, 0.f, 0.f, 0.f};
-            if (act[u]) {
-                const int id = d.ids[m];
-                if (!(d.zero_pad && id == 0)) v[u] = *reinterpret_cast<const f4e*>(d.table + (size_t)id * d.D + col0);
-                if (d.pos_table) pv[u] = *reinterpret_cast<const f4e*>(d.pos_table + (size_t)(m % d.T) * d.D + col0);
-            }
+            if (d.pos_table) pv[u] = *reinterpret_cast<const f4e*>(d.pos_table + (size_t)(min(mrow[u], d.M - 1) % d.T) * d.D + col0);   // (wave-uniform branch)
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if (!act[u]) continue;
             const int m = mrow[u];
             float x[4], p[4];
+            if (d.zero_pad && id[u] == 0) v[u] = (f4e){0.f, 0.f, 0.f, 0.f};
             rot4(v[u], shift, x);
             rot4(pv[u], shift, p);
-            const bool dead = d.mask_ids && d.mask_ids[m] == 0;
+            const bool dead = mk[u] == 0;
             const uint32_t base = (d.drop.row_offset + (uint32_t)m) * (uint32_t)d.D + (uint32_t)c;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -103,7 +109,7 @@ extern "C" int cr_embed_fwd(const cr_embed_desc* d, void* stream) {
     CR_REQUIRE(d->ld_out >= d->col_off + d->D, "cr_embed_fwd: ld_out too small");
     if (embed_vec_ok(d)) {
         const int lpr = embed_lpr(d->D);
-        const int rows_per_block = 4 * (64 / lpr) * 4;
+        const int rows_per_block = 4 * (64 / lpr) * (lpr >= 32 ? 8 : 4);     // 4 waves x rows per group x groups in flight (k_embed_fwd_vec's R)
         int grid = cr_ceil_div(d->M, rows_per_block);
         if (grid > 8192) grid = 8192;
         hipStream_t s = cr_stream(stream);

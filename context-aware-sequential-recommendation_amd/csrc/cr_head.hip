@@ -4,6 +4,7 @@
 // known after the whole batch (all ranks) has been reduced (sasrec.py:104-108).
 #include <math.h>
 
+#include <stdlib.h>
 #include "cr_common.hpp"
 
 // Row mapping as in cr_layernorm.hip: hidden sizes <= 64 give a row 16 lanes (4 rows per wave in flight,
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_test_logits(const float* seq_emb, int l
 // The same for hidden sizes that are multiples of 4 (16-byte rows): a read-only row gather, the form the HBM-read
 // roofline of the item table is measured on (bench.py "gather" block).  16 lanes own a candidate row (float4 per lane
 // per 64 columns), a wave keeps 4 rows x NR rounds in flight, the row sum is four DPP adds.  NV = D / 64 rounded up.
-template <int NV>
+template <int NV, int NR>
 __global__ __launch_bounds__(256) void k_test_logits_v4(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                                                         int B, int T, int D, int n_cand, float* logits) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, grp = (threadIdx.x >> 4);   // 16 groups per block
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_test_logits_v4(const float* seq_emb, in
         const int c = 4 * li + 64 * i;
         sv[i] = c < D ? *reinterpret_cast<const f4a*>(s + c) : (f4a){0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int NR = 2;                                   // candidates per group and iteration
+    // NR candidates per group and iteration
     for (int j0 = grp * NR; j0 < n_cand; j0 += 16 * NR) {
         int id[NR];
         float4 rv[NR][NV];
@@ -399,9 +400,16 @@ extern "C" int cr_test_logits(const float* seq_emb, int ld, const float* table, 
     CR_REQUIRE(B > 0 && T > 0 && D > 0 && V > 0 && n_cand > 0 && ld >= D, "cr_test_logits: bad shape");
     hipStream_t st = cr_stream(stream);
     if (D % 4 == 0 && D <= 256 && (reinterpret_cast<uintptr_t>(table) & 15) == 0) {
-        if (D <= 64) hipLaunchKernelGGL(k_test_logits_v4<1>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else if (D <= 128) hipLaunchKernelGGL(k_test_logits_v4<2>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else hipLaunchKernelGGL(k_test_logits_v4<4>, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        // rows in flight per 16-lane group at D > 128 (1 KB rows): 7 puts the evaluator's 101 candidates of a query into ONE batch
+        // (16 groups x 7): 68.2 % / 68.7 % / 70.0 % / 71.1 % of the 8 TB/s HBM peak for 1 / 2 / 4 / 7 at config C5's table
+        // (tools/gather_sweep.py, a fresh row set per launch)
+        static const int nr = getenv("CASTREC_TL_NR") ? atoi(getenv("CASTREC_TL_NR")) : 7;
+        if (D <= 64) hipLaunchKernelGGL((k_test_logits_v4<1, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else if (D <= 128) hipLaunchKernelGGL((k_test_logits_v4<2, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else if (nr == 4) hipLaunchKernelGGL((k_test_logits_v4<4, 4>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else if (nr == 1) hipLaunchKernelGGL((k_test_logits_v4<4, 1>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else if (nr == 7) hipLaunchKernelGGL((k_test_logits_v4<4, 7>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        else hipLaunchKernelGGL((k_test_logits_v4<4, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
         return cr_check_launch("cr_test_logits");
     }
     hipLaunchKernelGGL(k_test_logits, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
