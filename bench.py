@@ -478,13 +478,24 @@ def main():
         eng = E.Engine(args.model, corpus.usernum, corpus.itemnum, hyper(args), B, training=True, n_slabs=args.n_slabs,
                        batch_global=Bg, row_offset=rank * B * T, attn_precision=precision, lazy_adam=args.lazy_adam)
         dp = None
-        if dist is not None:
-            rep = D_.EngineReplica(eng, use_graph=False)
-            dp = D_.DataParallel(rep, rank, world, sparse={"auto": None, "on": True, "off": False}[args.sparse_exchange])
         use_graph = not args.no_graph
-        if use_graph:
+        if dist is not None:
+            # data-parallel step: three HIP graphs (forward + backward up to the last table-gradient launch | rest of the backward
+            # + slab collapse | Adam) around the collectives; the table's exchange runs beside the second graph (dist.step_phases)
             eng.ids_all.copy_(staged[0])
-            eng.capture(dp=dp is not None)
+            rep = D_.EngineReplica(eng, use_graph=use_graph)
+            dp = D_.DataParallel(rep, rank, world, sparse={"auto": None, "on": True, "off": False}[args.sparse_exchange],
+                                 force_collectives=force_dist)
+            if use_graph:
+                # one HIP graph for the whole step INCLUDING the collectives: measured with one rank (CASTREC_FORCE_DIST=1: +0.5 % over
+                # the plain step, against +9.7 % for three graphs and eager collectives); with more ranks it is opt-in
+                # (CASTREC_DP_ONE_GRAPH=1) until a multi-GPU box has replayed captured RCCL collectives
+                one = os.environ.get("CASTREC_DP_ONE_GRAPH")
+                whole = dp.capture_step() if (one == "1" or (one is None and world == 1)) else False
+                eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
+        elif use_graph:
+            eng.ids_all.copy_(staged[0])
+            eng.capture()
             eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
 
         def step(i):
@@ -494,12 +505,11 @@ def main():
                     eng.graph.launch()
                 else:
                     eng.launch_step()
+            elif use_graph:
+                dp.step_phases()                             # graphs + RCCL over xGMI: table exchange beside the rest of the backward
             else:
-                if use_graph:
-                    eng.graph.launch()
-                else:
-                    eng.launch_backward_to_flat()
-                dp.exchange(eng.Gflat)                       # RCCL over xGMI: dense bucket all-reduce, or sparse table rows + small bucket
+                eng.launch_backward_to_flat()
+                dp.exchange(eng.Gflat)                       # dense bucket all-reduce, or sparse table rows + small bucket
                 eng.launch_adam_from_flat()
 
         for i in range(warmup):
@@ -581,6 +591,7 @@ def main():
                "attn_precision": prec, "final_loss": round(loss, 5), "final_auc": round(auc, 5)}
         if dist is not None:
             cfg["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                 "step": "one HIP graph incl. the collectives" if dp._step_graph is not None else "three HIP graphs, collectives between them (table exchange beside the rest of the backward)",
                                  "table_exchange": "sparse rows (all-gather)" if dp.sparse else "dense (in the bucket all-reduce)",
                                  "bucket_floats": int(eng.Gflat.numel())}
         out = {

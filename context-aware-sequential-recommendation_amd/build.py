@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcastrec.so")
 LIB_TL = os.path.join(PKG, "libcastrec_tl.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
-           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_head.hip", "cr_adam.hip", "cr_sampler.cpp"]
+           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_head.hip", "cr_adam.hip", "cr_dist.hip", "cr_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wall", "-Wno-unused-function",
          # no SLP vectorisation: it packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  (a) Beside MFMAs those cost more

@@ -63,11 +63,46 @@ def sparse_exchange_bytes(n_slots, D, world):
     return (world - 1) * n_slots * (4 + 4 * D)
 
 
+class RowExchange:
+    """Device form of exchange_table_rows (HIP kernels cr_rows_pack / cr_rows_add, csrc/cr_dist.hip): pack this rank's touched
+    rows into fixed slots (de-duplicated through a row-flag table, no sort), ONE all-gather of [n, D + 1] floats (the row id
+    travels as the int bits of column 0), then one add launch per rank, in rank order.  start() may be issued while the rest of
+    the backward still runs (the item rows are final after the last embedding backward); finish() adds the gathered rows."""
+
+    def __init__(self, V, D, n_slots, world, device, group=None):
+        from . import lib as L
+        self.L, self.V, self.D, self.n, self.world, self.group = L, V, D, n_slots, world, group
+        self.flags = torch.zeros(V, dtype=torch.int32, device=device)
+        self.packed = torch.empty(n_slots, D + 1, dtype=torch.float32, device=device)
+        self.gathered = torch.empty(world, n_slots, D + 1, dtype=torch.float32, device=device)
+        self.tag = torch.zeros(1, dtype=torch.int32, device=device)      # device word: advanced on the stream, so a graph replay advances it too
+        self.work = None
+
+    def start(self, table, ids):
+        import torch.distributed as dist
+        assert table.is_cuda and table.is_contiguous() and ids.dtype == torch.int32 and ids.numel() == self.n
+        self.tag.add_(1)                                # a tag no flag holds yet (flags start at 0, tags at 1)
+        st = torch.cuda.current_stream().cuda_stream
+        self.L.call("cr_rows_pack", table.data_ptr(), ids.data_ptr(), self.n, self.D, self.V, self.flags.data_ptr(), self.tag.data_ptr(),
+                    self.packed.data_ptr(), 1, st)
+        self.work = dist.all_gather_into_tensor(self.gathered.view(-1), self.packed.view(-1), group=self.group, async_op=True)
+        self._table = table
+
+    def finish(self):
+        self.work.wait()                                # the current stream waits for the all-gather
+        st = torch.cuda.current_stream().cuda_stream
+        for r in range(self.world):                     # fixed order: the sums match on every rank
+            self.L.call("cr_rows_add", self._table.data_ptr(), self.gathered[r].data_ptr(), self.n, self.D, self.V, st)
+        self.work = None
+        return self.gathered[:, :, 0].view(torch.int32)                  # [world, n] row ids of every rank (0 = empty slot)
+
+
 def exchange_table_rows(table, ids, world, group=None):
     """Sums over ranks the rows of `table` ([V, D] view of this rank's table-gradient bucket) that this step touched.
     ids: 1-D integer tensor of this rank's contributing row ids (duplicates and the zero-pad id 0 allowed; every row
     outside it must be zero).  On return `table` equals what a dense all-reduce would have produced, bit-identical on
-    all ranks: a row's partial sums are added in rank order and a rank's list holds a row once."""
+    all ranks: a row's partial sums are added in rank order and a rank's list holds a row once.
+    (Host tensors -- the gloo transport of the CPU tests and of ranks sharing a card; device tensors go through RowExchange.)"""
     import torch.distributed as dist
     srt = torch.sort(ids.to(torch.int64)).values
     first = torch.ones_like(srt, dtype=torch.bool)
@@ -90,10 +125,17 @@ class DataParallel:
 
     sparse: None = choose from the byte counts when the replica offers sparse_spec(); True / False force it."""
 
-    def __init__(self, replica, rank, world, process_group=None, sparse=None):
+    def __init__(self, replica, rank, world, process_group=None, sparse=None, force_collectives=False):
+        """force_collectives: run the collectives with a single rank as well (bench.py CASTREC_FORCE_DIST=1: the cost of the
+        data-parallel step structure on one GPU)."""
         self.replica, self.rank, self.world, self.pg = replica, rank, world, process_group
+        self.force = bool(force_collectives)
         self.sparse = False
+        self._rows = None
+        self._step_graph = None
         spec = replica.sparse_spec() if hasattr(replica, "sparse_spec") else None
+        if world == 1 and self.force and spec is not None and sparse:
+            self.sparse = True
         if world > 1 and spec is not None and sparse is not False:
             dense = dense_allreduce_bytes(spec["n_item"], world)
             sp = sparse_exchange_bytes(spec["n_slots"], spec["D"], world)
@@ -108,9 +150,65 @@ class DataParallel:
     def step(self, batch_global):
         """batch_global: tuple of [B_global, T] int arrays (seq, pos, neg, time, hours, days)."""
         lo, hi = shard_rows(len(batch_global[0]), self.rank, self.world)
-        bucket = self.replica.backward_to_flat(tuple(a[lo:hi] for a in batch_global))
+        shard = tuple(a[lo:hi] for a in batch_global)
+        if getattr(self.replica, "has_phases", False):
+            self.replica.set_batch(shard)
+            self.step_phases()
+            return
+        bucket = self.replica.backward_to_flat(shard)
         self.exchange(bucket)
         self.replica.adam_from_flat()
+
+    def step_phases(self, eager=False):
+        """Graph-resident step of a device replica (EngineReplica with use_graph): graph A1 {forward, backward up to the last
+        launch that adds to the table gradient} -> the table's exchange STARTS (asynchronous collective: it waits for A1, the
+        stream goes on) -> graph A2 {rest of the backward, slab collapse} -> all-reduce of the small part of the bucket -> the
+        table's exchange is waited for (sparse: the gathered rows are added, one launch per rank) -> graph B {Adam}."""
+        import torch.distributed as dist
+        if self._step_graph is not None and not eager:
+            self._step_graph.launch()
+            return
+        rep = self.replica
+        bucket = rep.bucket()
+        rep.phase(0, eager)
+        live = self.world > 1 or self.force
+        w = None
+        if live:
+            spec = rep.sparse_spec()
+            n_item, D = spec["n_item"], spec["D"]
+            if self.sparse:
+                if self._rows is None:
+                    self._rows = RowExchange(n_item // D, D, spec["n_slots"], self.world, bucket.device, self.pg)
+                self._rows.start(bucket[:n_item].view(-1, D), spec["ids"]())
+            else:
+                w = dist.all_reduce(bucket[:n_item], group=self.pg, async_op=True)
+        rep.phase(1, eager)
+        if live:
+            dist.all_reduce(bucket[n_item:], group=self.pg)                       # positional table, dense grads, loss statistics
+            if self.sparse:
+                all_ids = self._rows.finish()
+                if hasattr(rep, "set_lazy_ids"):
+                    rep.set_lazy_ids(all_ids.reshape(-1))
+            else:
+                w.wait()
+        rep.phase(2, eager)
+
+    def capture_step(self):
+        """Tries to capture the WHOLE step -- the three phases and the collectives between them -- into one HIP graph (the
+        collectives of torch.distributed's RCCL backend are stream-ordered and capturable; the sparse exchange's tag is a device
+        word).  One graph launch per step instead of three plus the host side of two collectives.  Returns False (and keeps the
+        three-graph form) when the capture is refused."""
+        rep = self.replica
+        if not getattr(rep, "has_phases", False) or not hasattr(rep, "capture"):
+            return False
+        try:
+            self.step_phases(eager=True)                 # every lazy initialisation (communicator, RowExchange buffers) happens here
+            torch.cuda.synchronize()
+            self._step_graph = rep.capture(lambda: self.step_phases(eager=True))
+            return True
+        except Exception:
+            self._step_graph = None
+            return False
 
     def exchange(self, bucket):
         """Sums `bucket` ([item table grads | small part]) over the ranks, in place."""
@@ -133,22 +231,57 @@ class EngineReplica:
 
     def __init__(self, engine, use_graph=True):
         self.e = engine
+        self.has_phases = bool(use_graph)
         if use_graph:
-            engine.capture(dp=True)
+            engine.capture_dp_phases()
+            engine.graph = None
+
+    def set_batch(self, shard):
+        self.e.set_batch(*shard)
+
+    def bucket(self):
+        return self.e.Gflat
+
+    def phase(self, i, eager=False):
+        if eager:
+            self.e._run(self.e.dp_progs[i], torch.cuda.current_stream().cuda_stream)
+        else:
+            self.e.dp_graphs[i].launch()
+
+    def capture(self, fn):
+        """HIP graph of fn() (kernel launches and stream-ordered collectives on the current stream)."""
+        from . import ops as O
+        s0 = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(s0)
+        g = O.Graph()
+        with torch.cuda.stream(side):
+            g.begin()
+            try:
+                fn()
+            finally:
+                g.end()
+        s0.wait_stream(side)
+        self._keep_stream = side
+        return g
 
     def param_vector(self):
         return self.e.P
 
     def backward_to_flat(self, shard):
         self.e.set_batch(*shard)
-        if self.e.graph is not None:
-            self.e.graph.launch()
+        if self.has_phases:
+            self.e.dp_graphs[0].launch()
+            self.e.dp_graphs[1].launch()
         else:
             self.e.launch_backward_to_flat()
         return self.e.Gflat
 
     def adam_from_flat(self):
-        self.e.launch_adam_from_flat()
+        if self.has_phases:
+            self.e.dp_graphs[2].launch()
+        else:
+            self.e.launch_adam_from_flat()
 
     @property
     def lazy_adam(self):

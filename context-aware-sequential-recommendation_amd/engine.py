@@ -1030,6 +1030,14 @@ class Engine:
                     self.bwd += self._fold_pairs()            # a consumer with one gradient pointer: fold the pending pairs first
                 self.bwd += lst
             assert not self._grad2, "a gradient partial was left without a consumer"
+            # data parallelism overlaps the item / positional table's exchange with what is left of the backward once the last
+            # launch that adds to the table gradient has been issued: the embedding backward of a looked-up table (its own launch,
+            # or inside a block's backward) -- the head's rows are in from the start
+            self.bwd_table_done = 0
+            for i, (name, _, a) in enumerate(self.bwd):
+                sc = a[0] if name == "cr_embed_bwd" else (a[4] if name == "cr_stack_block_bwd" else (a[1] if name.endswith("_scatter") else None))
+                if sc is not None and sc._obj.n_slabs == 0:              # (n_slabs > 0: a small context table, written as slabs)
+                    self.bwd_table_done = i + 1
             lay = self.layout
             # the step ends inside Adam (castrec.h, state block): sums and step number are read from the snapshot the
             # head kernel took, and the kernel zeroes the sums and advances the counter -- no cr_step_begin launch
@@ -1139,6 +1147,27 @@ class Engine:
     def launch_adam_from_flat(self):
         """Adam on the (all-reduced) flat bucket; the global loss statistics are read from its tail."""
         self._run(([self._l2] if self._l2 else []) + [self._adam_flat], torch.cuda.current_stream().cuda_stream)
+
+    def capture_dp_phases(self):
+        """Three HIP graphs for a data-parallel step: A1 = forward + the backward up to the last launch that adds to the table
+        gradient, A2 = the rest of the backward + the slab collapse into the flat bucket, B = Adam on the (reduced) bucket.
+        The table exchange runs between A1 and B beside A2 (castrec_amd.dist.DataParallel)."""
+        s0 = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(s0)
+        k = self.bwd_table_done
+        progs = [self.fwd + self.bwd[:k], self.bwd[k:] + [self._reduce], ([self._l2] if self._l2 else []) + [self._adam_flat]]
+        graphs = []
+        with torch.cuda.stream(side):
+            for prog in progs:
+                g = O.Graph()
+                g.begin()
+                self._run(prog, torch.cuda.current_stream().cuda_stream)
+                g.end()
+                graphs.append(g)
+        s0.wait_stream(side)
+        self.dp_graphs, self.dp_progs, self._graph_stream = graphs, progs, side
+        return graphs
 
     def capture(self, dp=False):
         """Captures launch_step() into a HIP graph (inputs are read from the static id buffers)."""

@@ -454,6 +454,18 @@ int cr_l2_penalty(const float* p, int64_t n, float scale, float* state, void* st
 int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dense, float* out,
                     const float* state, float* stats_out, const int32_t* slab_counts /* optional, as cr_adam_desc's */, void* stream);
 
+/* ---- data-parallel exchange of a row-sparse table gradient (csrc/cr_dist.hip) ----------------------
+ * cr_rows_pack: slot i of `packed` ([n, D + 1] floats: column 0 = the row id as int bits, then the row) gets row ids[i] of
+ * `table` ([V, D]) if slot i is the first to claim that row in this call (flags: [V] words holding anything but `tag`, one
+ * atomic exchange per slot; `tag` points to a DEVICE word the caller changes before every call to a value not used before --
+ * read by the kernel, so that a HIP graph of the step replays with fresh tags), else id 0 and a zero row (duplicates, id 0,
+ * ids outside [0, V)).  zero_rows != 0: the packed rows are zeroed in `table`.
+ * cr_rows_add: table[id] += row for every slot with id != 0.  One call per rank's gathered buffer, in rank order: a call has
+ * no conflicting writes (a rank's buffer holds a row once) and the sums are formed in the same order on every replica. */
+int cr_rows_pack(float* table, const int32_t* ids, int n, int D, int V, uint32_t* flags, const uint32_t* tag, float* packed,
+                 int zero_rows, void* stream);
+int cr_rows_add(float* table, const float* packed, int n, int D, int V, void* stream);
+
 /* ---- HIP graph capture of a whole step (launch-bound inner loop) ---------------------- */
 int cr_graph_begin(void* stream);
 int cr_graph_end(void* stream, void** graph_exec_out);

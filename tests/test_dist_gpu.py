@@ -208,3 +208,49 @@ def test_two_gpus_over_rccl(sparse, monkeypatch):
             # (the count of such elements is a small-number statistic: 3 of 16 384 seen at D = 128 -- allowed: 1 + 5e-4 of the tensor;
         #  the bound that matters is the maximum, 1e-4: thirty times below what three Adam steps could move an element)
         assert d.max() <= 1e-4 and (d > 5e-6).sum() <= 1 + 5e-4 * d.size, (k, float(d.max()), int((d > 5e-6).sum()))
+
+
+@pytest.mark.parametrize("sparse,one_graph", [(False, False), (True, False), (False, True), (True, True)])
+def test_graph_resident_step_with_the_collectives_on_one_rank(sparse, one_graph):
+    """The production step structure of data parallelism (castrec_amd.dist.DataParallel.step_phases: graph A1 -> table exchange
+    started -> graph A2 -> small all-reduce -> exchange finished -> graph B = Adam) over RCCL with ONE rank on the box's card
+    (force_collectives), against the plain single-graph step: same parameters after three steps up to the order in which the
+    dense slabs are summed (cr_reduce_slabs + Adam on the flat bucket against Adam's own slab sum).  sparse: the item rows
+    travel through cr_rows_pack -> all-gather -> cr_rows_add (packed, zeroed in the table, added back: exact)."""
+    import torch.distributed as dist
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine as E
+    from castrec_amd.dist import DataParallel, EngineReplica
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        items = 5000
+        a = E.Engine("cast_1", USERS, items, hyper(E), B, training=True, n_slabs=8)
+        b = E.Engine("cast_1", USERS, items, hyper(E), B, training=True, n_slabs=8)
+        perturb_start(a)
+        b.P.copy_(a.P)
+        assert 0 < b.bwd_table_done < len(b.bwd)               # something of the backward is left to run beside the exchange
+        a.capture()
+        a.set_step(1); a.Mom.zero_(); a.Vel.zero_(); a.Gflat.zero_()
+        rep = EngineReplica(b, use_graph=True)
+        dp = DataParallel(rep, 0, 1, sparse=sparse, force_collectives=True)
+        assert dp.sparse == sparse
+        if one_graph:                                          # the whole step, collectives included, as ONE HIP graph
+            assert dp.capture_step()
+            b.P.copy_(a.P)                                     # (the capture's eager rehearsal took an optimiser step)
+        b.set_step(1); b.Mom.zero_(); b.Vel.zero_(); b.Gflat.zero_()
+        for st in range(STEPS):
+            batch = make_batch(st, items)
+            a.train_step(*batch)
+            dp.step(batch)
+        torch.cuda.synchronize()
+        pa, pb = a.get_params(), b.get_params()
+        for k in pa:
+            if k.endswith(".bk"):
+                continue
+            d = (pa[k] - pb[k]).abs().max().item()
+            assert d <= 1e-5, (k, d)
+        assert a.loss_auc()[0] == pytest.approx(b.loss_auc()[0], rel=1e-5)
+    finally:
+        dist.destroy_process_group()
+
