@@ -67,8 +67,9 @@ class _Model(object):
                 if bounce:
                     rep.adopt_params()
                 if self._graph and not bounce and os.environ.get("CASTREC_DP_ONE_GRAPH") == "1":
+                    p0 = self._train.P.clone()                              # (the capture rehearses one eager step: undo its update)
                     self._dp.capture_step()                                 # opt-in: the whole step incl. the collectives as one HIP graph
-                    self._train.P.copy_(self._owner.P)
+                    self._train.P.copy_(p0)
                 if self._graph:
                     self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
                 if self._pending_opt is not None:
