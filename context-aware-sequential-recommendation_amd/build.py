@@ -45,6 +45,10 @@ def build(force=False, verbose=False, timeline=False):
     bdir = "build_tl" if timeline else "build"
     lib = LIB_TL if timeline else LIB
     flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else []) + os.environ.get("CASTREC_EXTRA_FLAGS", "").split()
+    # sources compiled WITH SLP vectorisation all the same: cr_attn_bf.hip -- its head-dim-32 forward is 37 % slower without the
+    # packed fp32 arithmetic (config C4: 29.6 -> 40.6 us per launch), and 3000 launches of its forward + backward at the C4 and
+    # headline shapes hold the same bits with and without it (tools/diag_attn_repro.py)
+    slp_ok = os.environ.get("CASTREC_SLP_FILES", "cr_attn_bf.hip").split()
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
     headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"), os.path.join(CSRC, "cr_rbwd.hpp"),
                os.path.join(ROOT, "include", "castrec.h")]
@@ -54,7 +58,8 @@ def build(force=False, verbose=False, timeline=False):
         obj = os.path.join(CSRC, bdir, s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + flags + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            fl = [f for f in flags if not (f == "-fno-slp-vectorize" and s in slp_ok)]
+            cmd = [hipcc] + fl + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
