@@ -69,8 +69,21 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb
     if ((int)blockIdx.x < nb_dense) {
         const int j0 = blockIdx.x * ADAM_COLS;
         const int ns = d.slab_counts ? min(d.slab_counts[blockIdx.x], d.n_slabs) : d.n_slabs;
-        const float g = slab_sum256(d.dense_slabs, ns, d.n_dense, j0, part);
-        if (threadIdx.x < ADAM_COLS && j0 + (int)threadIdx.x < d.n_dense) update(d.n_table + j0 + threadIdx.x, g);
+        // the parameter and its moments are requested BEFORE the slab sum (they do not depend on it): one memory round trip less on
+        // the critical path of this short kernel
+        const bool mine = threadIdx.x < ADAM_COLS && j0 + (int)threadIdx.x < d.n_dense;
+        const long long i = d.n_table + j0 + (mine ? (int)threadIdx.x : 0);
+        const float p0 = mine ? d.p[i] : 0.0f, m0 = mine ? d.m[i] : 0.0f, v0 = mine ? d.v[i] : 0.0f;
+        float g = slab_sum256(d.dense_slabs, ns, d.n_dense, j0, part);
+        if (mine) {
+            g *= inv_n;
+            if (i < d.n_l2) g = fmaf(d.l2, p0, g);
+            const float m = d.beta1 * m0 + (1.0f - d.beta1) * g;
+            const float v = d.beta2 * v0 + (1.0f - d.beta2) * g * g;
+            d.m[i] = m;
+            d.v[i] = v;
+            d.p[i] = p0 - lr_t * m / (sqrtf(v) + d.eps);
+        }
     } else if ((int)blockIdx.x < nb_dense + nb_lazy) {
         // lazy rows: wave w of the lazy blocks walks ids w, w + W, ...; the first wave to swap the step number into a row's
         // flag owns the row (every other occurrence of the id finds it there and moves on)

@@ -567,11 +567,11 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const float mrow = normal ? st.x : 1e30f, inv = normal ? st.y : 0.0f;
         bf8 qh[2], ql[2], oh[2], ol[2];
         gfrag_finish<SPLIT, 2>(qn, d.Q, d.ld, base_row + q0, 0, T - q0, D, M, qh, ql);
-        {
-            f32x4 dO[4];
-            r_finish(dO, rdo, dcx);
-            r_split<SPLIT>(dO, oh, ol);
-        }
+        f32x4 dO[4];                                      // kept for the residual branch behind the loop (dq_in = dQ Wq^T + d_o)
+        r_finish(dO, rdo, dcx);
+        r_split<SPLIT>(dO, oh, ol);
+        RRaw rx;
+        r_issue(rx, bk.x, mo, dcx);                       // the block input's rows of this tile (LayerNorm-1 backward), under the loop
         const bool tile_live = __any(normal ? 1 : 0) != 0;              // uniform and dead rows carry no score gradient
         const uint32_t ridx = attn_row_idx(d, 0, n, q);
         const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
@@ -669,9 +669,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         }
         if (ti == 0) B1_TS(6);
         // ---- the tile goes on through registers: dq_in = dQ Wq^T + d_o, LN1 backward -> this side's partial of dx ----
-        RRaw rx, rdx, rdo2;
-        r_issue(rdo2, bd.d_o, mo, dcx, rok);
-        r_issue(rx, bk.x, mo, dcx);
+        RRaw rdx;
         if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
         r_store(dQg, mo, dq, rok, dcx);                                   // for the weight-gradient images of phase 3
         f32x4 dqin[4];
@@ -679,10 +677,8 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
             bf8 gh[2], gl[2];
             r_split<SPLIT>(dq, gh, gl);
             r_gemm_t<SPLIT, false>(dqin, Wi, Wi + ST_WIMG, gh, gl);
-            f32x4 dob[4];
-            r_finish(dob, rdo2, dcx);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) dqin[ct] += dob[ct];
+            for (int ct = 0; ct < 4; ++ct) dqin[ct] += dO[ct];
         }
         f32x4 x[4], dxl[4], ag[4], ab[4];
 #pragma unroll
