@@ -535,8 +535,9 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     const cr_attn_desc& d = bd.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // FAST: images at a compile-time stride, operand reads = (per-lane base + pair offset) + immediate (see bf_bwd_k_pass)
-    constexpr bool FAST = PAIRED && !MULTI && NKS == 2;
-    constexpr int FSTR = 256 * 64;
+    constexpr bool FAST = PAIRED && !MULTI;
+    constexpr int FSTR = 256 * 32 * NKS;                  // elements between images (FAST): 256 rows
+    constexpr int TILEB = 1024 * NKS;                     // bytes of a 16-row tile of an image
     __bf16* Kh = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Kl = Kh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
     __bf16* Vh = Kl + (FAST ? FSTR : g.ch_rows * (32 * NKS));
@@ -547,12 +548,12 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     const int base_row = n * d.T, hoff = head * d.d;
     const int T = d.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    const int frk0 = 2 * img_off<NKS>(li, lg), frk1 = 2 * img_off<NKS>(li, lg + 4 * (NKS - 1));
     int ftr[4];
     {
         const int q_ = li >> 2, p_ = li & 3;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<NKS>(4 * lg + q_, (2 * jt + (p_ >> 1)) & (4 * NKS - 1)) + 4 * (p_ & 1));
     }
     BT_TS(0); BT_TS(1);
     const DropCtx dc = drop_ctx(d.drop);
@@ -606,8 +607,8 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
     if (!multi) {
         stage(0);
         if (FAST && (g.nkt & 1)) {                       // the absent second tile of the last pair: finite (zero) rows, masked keys
-            const int t = threadIdx.x, im = t >> 7, o16 = t & 127;
-            *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Kh + im * FSTR) + (size_t)g.ch_rows * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int t = threadIdx.x, im = t / (TILEB / 16), o16 = t % (TILEB / 16);
+            if (im < 4) *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Kh + im * FSTR) + (size_t)g.ch_rows * (64 * NKS) + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < 16) kb[g.ch_rows + t] = -INFINITY;
         }
         BT_TS(2);
@@ -675,14 +676,14 @@ __device__ __forceinline__ void bf_bwd_q_pass(const cr_attn_bwd_desc& bd, const 
                 // chunk-local tiles (l1 clamped: zeros below; FAST: always k0 + 1 -- real or zeroed rows, coefficients 0)
                 const int l0 = k0 - kt_c0, l1 = FAST ? k1 : (k1 <= hi ? k1 : k0) - kt_c0;
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-                const int po = 4096 * kp;
+                const int po = 2 * TILEB * kp;
                 auto rfF = [&](int base, int ks, int second, int lo_) {
-                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + 2048 * second + 2 * FSTR * lo_);
+                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + TILEB * second + 2 * FSTR * lo_);
                 };
                 auto trF = [&](int base, int jt, int lo_) {
                     const unsigned char* pa = smem_raw + (base + po + ftr[jt]) + 2 * FSTR * lo_;
                     const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
-                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + TILEB));
                     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
                 {
@@ -804,8 +805,9 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     // pair loop an operand read is (per-lane base + pair offset) + immediate: 12 address adds per iteration instead of one per
     // read (the run-time image pointers and tile indices made every one of the 60 reads of an iteration compute its own
     // address: 99 of the 313 vector instructions of the loop)
-    constexpr bool FAST = PAIRED && !MULTI && NKS == 2;
-    constexpr int FSTR = 256 * 64;                        // elements between images (FAST)
+    constexpr bool FAST = PAIRED && !MULTI;
+    constexpr int FSTR = 256 * 32 * NKS;                  // elements between images (FAST): 256 rows
+    constexpr int TILEB = 1024 * NKS;                     // bytes of a 16-row tile of an image
     __bf16* Qh = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Ql = Qh + (FAST ? FSTR : (SPLIT ? g.ch_rows * (32 * NKS) : 0));
     __bf16* Oh = Ql + (FAST ? FSTR : g.ch_rows * (32 * NKS));
@@ -826,12 +828,12 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     // FAST: per-lane byte offsets of the operand reads at tile 0 of an image (see img_off: the swizzle term (row & 6) does not
     // depend on the tile, so a tile adds 2048 bytes)
-    const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
+    const int frk0 = 2 * img_off<NKS>(li, lg), frk1 = 2 * img_off<NKS>(li, lg + 4 * (NKS - 1));
     int ftr[4];
     {
         const int q = li >> 2, p = li & 3;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q, 2 * jt + (p >> 1)) + 4 * (p & 1));
+        for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<NKS>(4 * lg + q, (2 * jt + (p >> 1)) & (4 * NKS - 1)) + 4 * (p & 1));
     }
     BT_TS(8);
     const DropCtx dc = drop_ctx(d.drop);
@@ -898,8 +900,8 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
         if (FAST && (g.nkt & 1)) {
             // an odd tile count: the last pair's second tile does not exist; its rows are read all the same (with zero
             // coefficients) and must hold finite values: zero them (16 rows x 128 bytes x 4 images, 16 bytes per thread)
-            const int t = threadIdx.x, im = t >> 7, o16 = t & 127;
-            *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Qh + im * FSTR) + (size_t)g.ch_rows * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int t = threadIdx.x, im = t / (TILEB / 16), o16 = t % (TILEB / 16);
+            if (im < 4) *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(Qh + im * FSTR) + (size_t)g.ch_rows * (64 * NKS) + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         BT_TS(9);
         __syncthreads();
@@ -959,14 +961,14 @@ __device__ __forceinline__ void bf_bwd_k_pass(const cr_attn_bwd_desc& bd, const 
                 if (!w0 && !w1) continue;
                 f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
                 // FAST: byte addresses of this pair's tiles: (lane base + 4096 * qp); second tile + 2048, lo image + 32768
-                const int po = 4096 * qp;
+                const int po = 2 * TILEB * qp;
                 auto rfF = [&](int base, int ks, int second, int lo) {
-                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + 2048 * second + 2 * FSTR * lo);
+                    return *reinterpret_cast<const bf8*>(smem_raw + (base + po + (ks ? frk1 : frk0)) + TILEB * second + 2 * FSTR * lo);
                 };
                 auto trF = [&](int base, int jt, int lo) {
                     const unsigned char* pa = smem_raw + (base + po + ftr[jt]) + 2 * FSTR * lo;
                     const bf4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa));
-                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
+                    const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + TILEB));
                     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
                 {
@@ -1249,7 +1251,7 @@ static int launch_bf_bwd(const cr_attn_bwd_desc* bd, const BfGeom& g, hipStream_
         BfGeom gf = g;
         if (g_attn_ts_which == 5) gf.ts = g_attn_ts;
         // (the key-owner workgroups at NKS == 2 keep their four images at a fixed stride of 256 rows)
-        const size_t img_k = NKS == 2 ? (size_t)4 * 256 * 64 * 2 : img;
+        const size_t img_k = (size_t)4 * 256 * (32 * NKS) * 2;               // four images at the fixed stride of 256 rows
         hipLaunchKernelGGL((k_bf_bwd_fused<NKS, SPLIT>), dim3(d->B * d->H, 2), dim3(512), (img_k > img ? img_k : img) + (size_t)g.ch_rows * 4 * 5 + (size_t)(g.ch_rows / 16) * 4 + 64, s, *bd, gf);
         return cr_check_launch("cr_attn_bwd(bf16, fused)");
     }

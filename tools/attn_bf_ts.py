@@ -8,7 +8,7 @@ import castrec_amd
 from castrec_amd import ops as O, lib as L
 
 PREC = int(os.environ.get("PREC", "1"))
-B, T, H, d = 128, 200, 1, 50
+B, T, H, d = 128, 200, int(os.environ.get("H", 1)), int(os.environ.get("DH", 50))
 M, D = B * T, H * d
 rs = np.random.RandomState(0)
 f = lambda *s: torch.randn(*s, device="cuda")
@@ -25,7 +25,7 @@ drop = O.Drop(0.2, 1, state)
 row_stats = torch.empty(H * B * T * 4, device="cuda")
 desc = O.attn_desc(Q, K, V, D, kv, qv, R, D, out, D, B, T, H, d, rng=drop.rng(3), dead_ids=idd, row_stats=row_stats, precision=PREC)
 stats = torch.empty(H * B * T * 4, device="cuda")
-delta = f(M)
+delta = f(H * M)
 fn = getattr(L._lib, "cr_debug_attn_ts"); fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = None
 
 def run():
@@ -33,7 +33,7 @@ def run():
     O.attn_bwd(desc, dO, D, dQ, dK, dV, D, stats, delta=delta)
 
 def timeline(which, title, names):
-    ts = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    ts = torch.zeros(2 * B * H * 8 * 16, dtype=torch.int64, device="cuda")     # every wave of both workgroups of every (sample, head)
     for _ in range(3): run()
     torch.cuda.synchronize()
     fn(ts.data_ptr(), which)
