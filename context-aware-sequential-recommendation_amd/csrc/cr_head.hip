@@ -165,11 +165,23 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
     }
     const float invD = 1.0f / (float)d.D;
     float loss_acc = 0.0f, auc_acc = 0.0f, n_acc = 0.0f;
+    // the ids of a row group are requested one iteration ahead: id -> table row is a dependent pair of memory round trips, and a
+    // wave runs only two iterations (100 rows per workgroup, 16 waves x 4 rows)
+    int p_n = 0, ng_n = 0;
+    {
+        const int m = m0 + wave * RPW + sub;
+        if (m < m1) { p_n = d.pos[m]; ng_n = d.neg[m]; }
+    }
     for (int mb = m0 + wave * RPW; mb < m1; mb += 16 * RPW) {
         const int m = mb + sub;
         const bool act = m < m1;
         const int mm = act ? m : m0;
-        const int p = act ? d.pos[mm] : 0, ng = act ? d.neg[mm] : 0;
+        const int p = act ? p_n : 0, ng = act ? ng_n : 0;
+        {
+            const int mn = m + 16 * RPW;
+            p_n = 0; ng_n = 0;
+            if (mn < m1) { p_n = d.pos[mn]; ng_n = d.neg[mn]; }
+        }
         float s[MAXC], ep[MAXC], en[MAXC], x[MAXC];
         float pl = 0.0f, nl = 0.0f, xs = 0.0f;
 #pragma unroll
