@@ -32,6 +32,20 @@ def test_version_and_error_string_without_gpu():
     assert rc == -1 and b"cr_adam_step" in L.lib.cr_last_error()
 
 
+def test_round3_entries_validate_their_arguments_without_gpu():
+    """cr_stack_block_bwd / cr_rows_pack / cr_rows_add reject NULL and unsupported descriptions before any HIP call."""
+    bd, ad, ext = L.BlockBwdDesc(), L.AttnDesc(), L.BlockBwd1Ext()
+    assert L.lib.cr_stack_block_bwd_supported(ctypes.byref(bd), ctypes.byref(ad), 4, 20, L.PREC_BF16X3) == 0     # D = 0
+    rc = L.lib.cr_stack_block_bwd(ctypes.byref(bd), ctypes.byref(ad), ctypes.byref(ext), None, None, 4, 20, L.PREC_BF16X3, None)
+    assert rc == -1 and b"cr_stack_block_bwd" in L.lib.cr_last_error()
+    bd.f.D, bd.f.M, bd.n_slabs = 64, 80, 4                     # D = 64: the bias gradients need a spare column (D < 64)
+    assert L.lib.cr_stack_block_bwd_supported(ctypes.byref(bd), ctypes.byref(ad), 4, 20, L.PREC_BF16X3) == 0
+    bd.f.D = 50
+    assert L.lib.cr_stack_block_bwd_supported(ctypes.byref(bd), ctypes.byref(ad), 4, 20, L.PREC_F32) == 0      # bf16 arithmetic only
+    assert L.lib.cr_rows_pack(None, None, 1, 1, 1, None, None, None, 1, None) == -1 and b"cr_rows_pack" in L.lib.cr_last_error()
+    assert L.lib.cr_rows_add(None, None, 1, 1, 1, None) == -1 and b"cr_rows_add" in L.lib.cr_last_error()
+
+
 def test_struct_sizes_match_c_layout(tmp_path):
     """sizeof of every descriptor as gcc lays it out from include/castrec.h == the ctypes mirror."""
     import shutil
