@@ -495,6 +495,9 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
     if ((size_t)b0.M * (size_t)(s->out && s->ld_out > b0.D ? s->ld_out : b0.D) * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
     const int T16 = (a0.T + 15) / 16 * 16;
     if (stack_lds_bytes(T16, a0.precision == CR_PREC_BF16X3) > 160 * 1024) return "K / V images + weights exceed the LDS";
+    // (more than 13 tiles: plain bf16 and one head only -- the split form does not fit the LDS there anyway, and the two-head
+    //  16-tile instantiations needed 200+ spilled registers: retired, those shapes take the unfused kernels)
+    if (T16 > 208 && (a0.precision == CR_PREC_BF16X3 || a0.H != 1)) return "T <= 208 (bf16x3, or two heads)";
     for (int i = 0; i < s->n_blocks; ++i) {
         const cr_block_desc& b = s->blocks[i];
         const cr_attn_desc& a = s->attn[i];
@@ -530,7 +533,9 @@ static int launch_stack_d(const StackArgs& a, int B, hipStream_t s) {
 template <int NKT, bool SPLIT>
 static int launch_stack(const StackArgs& a, int B, bool pair, hipStream_t s) {
     constexpr int DS = (NKT == 4 || NKT == 13) ? 50 : 0;                 // the headline hidden size as a constant
-    if (a.blk[0].ad.H == 2) return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
+    if constexpr (NKT <= 13) {
+        if (a.blk[0].ad.H == 2) return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
+    }
     if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false, 1>(a, B, s);
     return pair ? launch_stack_d<NKT, SPLIT, 0, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 1>(a, B, s);
 }
@@ -538,7 +543,7 @@ static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, hi
     if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, st) : launch_stack<4, false>(a, B, pair, st);
     if (a.nkt <= 8) return split ? launch_stack<8, true>(a, B, pair, st) : launch_stack<8, false>(a, B, pair, st);
     if (a.nkt <= 13) return split ? launch_stack<13, true>(a, B, pair, st) : launch_stack<13, false>(a, B, pair, st);
-    return split ? launch_stack<16, true>(a, B, pair, st) : launch_stack<16, false>(a, B, pair, st);
+    return launch_stack<16, false>(a, B, pair, st);       // (stack_unsupported: plain bf16, one head)
 }
 
 // batches up to this size run two workgroups per sequence, one launch per block (256 CUs, one workgroup each)

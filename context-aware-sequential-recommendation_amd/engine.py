@@ -850,6 +850,8 @@ class Engine:
             return False
         T16, split = (self.T + 15) // 16 * 16, self.attn_precision == "bf16x3"
         lds = T16 * 64 * 2 * (4 if split else 2) + 3 * 4096 * 2 * (2 if split else 1) + 11 * 64 * 4 + T16 * 4
+        if T16 > 208 and (split or self.H != 1):                 # more than 13 tiles: plain bf16, one head (castrec.h)
+            return False
         return lds <= 160 * 1024
 
     def op_stack(self, x, prefix, nblocks, out, out_ld, out_col, want_attn=False):

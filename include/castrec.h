@@ -282,7 +282,7 @@ int cr_block_ln_ffn_fwd_tail(const cr_block_desc* d, const cr_block_tail_desc* t
  * final LayerNorm of kind-2 tails, up to the rounding of the bf16 split products (the projections and the feed-forward
  * run on the bf16 matrix pipe here as well): every buffer of the descriptions is written as those calls write it, so
  * the backward entry points are unchanged.  Requirements (cr_stack_fwd_supported): 1..CR_STACK_MAX_BLOCKS blocks of one
- * shape, H = 1 with D = d in 8..64 (or H = 2, d = 32, D = 64), T <= 208 (CR_PREC_BF16X3) or 256 (CR_PREC_BF16), attn[i] wired
+ * shape, H = 1 with D = d in 8..64 (or H = 2, d = 32, D = 64), T <= 208 (CR_PREC_BF16X3, or two heads) or 256 (CR_PREC_BF16, one head), attn[i] wired
  * to blocks[i]'s buffers
  * (Q/K/V = qkv parts, residual = q_in, out = o, masks), no attention weights, blocks[i+1].x == blocks[i].y. */
 #define CR_STACK_MAX_BLOCKS 4
