@@ -493,13 +493,21 @@ def main():
                 one = os.environ.get("CASTREC_DP_ONE_GRAPH")
                 whole = dp.capture_step() if (one == "1" or (one is None and world == 1)) else False
                 eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
-        elif use_graph:
+        ring = dist is None and os.environ.get("CASTREC_NO_ID_RING") != "1"
+        if ring:
+            # the NB staged batches ARE the id ring: a step ends by moving the next step's batch (slot = step number mod NB) into
+            # the static id buffers beside Adam (Engine.use_id_ring) -- no host-issued copy between two steps
+            eng.use_id_ring(staged)
+        if dist is None and use_graph:
             eng.ids_all.copy_(staged[0])
             eng.capture()
             eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
+        if ring:
+            eng.ids_all.copy_(staged[eng.step_number() % NB])
 
         def step(i):
-            eng.ids_all.copy_(staged[i % NB])
+            if not ring:
+                eng.ids_all.copy_(staged[i % NB])
             if dp is None:
                 if use_graph:
                     eng.graph.launch()

@@ -49,9 +49,23 @@ __device__ __forceinline__ float slab_sum256(const float* slabs, int n_slabs, in
 
 // blocks [0, nb_dense): 256 dense parameters each (slab reduction + update); then nb_lazy blocks (lazy item-table rows,
 // one wave per listed id); the rest: table entries, grid-stride
-__global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy) {
+__global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy, int nb_ring) {
     __shared__ float part[ADAM_WAVES][ADAM_COLS];
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
+    if ((int)blockIdx.x >= (int)gridDim.x - nb_ring) {
+        // the last nb_ring blocks: the next step's ids out of the resident ring (nothing else in this launch reads ids)
+        constexpr int NT = 64 * ADAM_WAVES;
+        const int32_t* src1 = d.ids_ring + (long long)((t + 1u) % (uint32_t)d.ids_ring_slots) * d.ids_slot_elems;
+        const long long first = (long long)((int)blockIdx.x - ((int)gridDim.x - nb_ring)) * NT + threadIdx.x, stride = (long long)nb_ring * NT;
+        if ((d.ids_slot_elems & 3) == 0 && (((uintptr_t)d.ids_ring | (uintptr_t)d.ids_dst) & 15) == 0) {
+            const int4* src = reinterpret_cast<const int4*>(src1);
+            int4* dst = reinterpret_cast<int4*>(d.ids_dst);
+            for (long long i = first; i < (d.ids_slot_elems >> 2); i += stride) dst[i] = src[i];
+        } else {                                         // (a slot that is no multiple of 16 bytes: B * T odd)
+            for (long long i = first; i < d.ids_slot_elems; i += stride) d.ids_dst[i] = src1[i];
+        }
+        return;
+    }
     const float* st = d.stats ? d.stats : d.state;
     const float n = st[2];
     const float inv_n = n > 0.0f ? 1.0f / n : 0.0f;
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb
         // table section: 16 bytes per lane per array (4-byte accesses moved 3.2 TB/s on a 188 MB table), two
         // groups of four in flight per thread; the scalar head / tail (a start or an end that is not a multiple of 4) goes to
         // the first table block
-        const int nb_table = gridDim.x - nb_dense - nb_lazy;
+        const int nb_table = gridDim.x - nb_dense - nb_lazy - nb_ring;
         const int tb = (int)blockIdx.x - nb_dense - nb_lazy;
         const long long first = nb_lazy > 0 ? (long long)d.lazy_rows * d.lazy_D : 0;   // the lazy part of the table section is not swept
         constexpr int NT = 64 * ADAM_WAVES;
@@ -184,7 +198,14 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     const long long groups = n_swept / 4 + 1;                                 // 16-byte groups (+ one block's worth of head / tail)
     int nb_table = (int)((groups + NT - 1) / NT > 1024 ? 1024 : (groups + NT - 1) / NT);
     if (nb_table < 1) nb_table = 1;
-    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table), dim3(NT), 0, cr_stream(stream), *d, nb_dense, nb_lazy);
+    int nb_ring = 0;
+    if (d->ids_ring) {
+        CR_REQUIRE(d->lazy_ids == nullptr, "cr_adam_step: ids_ring and lazy_ids exclude each other (row-sparse Adam reads the step's ids)");
+        CR_REQUIRE(d->ids_dst && d->ids_ring_slots > 0 && d->ids_slot_elems > 0, "cr_adam_step: bad id-ring arguments");
+        const long long slot4 = (d->ids_slot_elems + 3) / 4;
+        nb_ring = (int)((slot4 + NT - 1) / NT > 256 ? 256 : (slot4 + NT - 1) / NT);
+    }
+    hipLaunchKernelGGL(k_adam, dim3(nb_dense + nb_lazy + nb_table + nb_ring), dim3(NT), 0, cr_stream(stream), *d, nb_dense, nb_lazy, nb_ring);
     return cr_check_launch("cr_adam_step");
 }
 

@@ -29,6 +29,33 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 #define CR_WAVE 64
 
+// Every 64-byte line of the kernel-argument segment requested at once, at the top of a kernel whose argument block is large.
+// The compiler fetches arguments where it first needs them, each fetch behind an s_waitcnt: the one-launch block backward
+// (1.2 KB of descriptors) opened with twelve dependent scalar-cache misses -- 3.7 us before its first vector load went out
+// (tools/b1_ts.py).  With the lines requested together the misses overlap and the compiler's own loads hit the scalar cache.
+// BYTES: the explicit arguments (the hidden ones behind them are requested where the code uses them).
+template <int BYTES>
+__device__ __forceinline__ void cr_kernarg_touch() {
+    static_assert(BYTES > 0 && BYTES <= 20 * 64, "at most 20 lines");
+    constexpr int LAST = BYTES - 4;
+    const auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t;
+#define CR_KT_O(i) "n"((i) * 64 < LAST ? (i) * 64 : LAST)
+    asm volatile(
+        "s_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3\n\ts_load_dword %0, %1, %4\n\ts_load_dword %0, %1, %5\n\t"
+        "s_load_dword %0, %1, %6\n\ts_load_dword %0, %1, %7\n\ts_load_dword %0, %1, %8\n\ts_load_dword %0, %1, %9\n\t"
+        "s_load_dword %0, %1, %10\n\ts_load_dword %0, %1, %11\n\ts_load_dword %0, %1, %12\n\ts_load_dword %0, %1, %13\n\t"
+        "s_load_dword %0, %1, %14\n\ts_load_dword %0, %1, %15\n\ts_load_dword %0, %1, %16\n\ts_load_dword %0, %1, %17\n\t"
+        "s_load_dword %0, %1, %18\n\ts_load_dword %0, %1, %19\n\ts_load_dword %0, %1, %20\n\ts_load_dword %0, %1, %21\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(t)
+        : "s"(p), CR_KT_O(0), CR_KT_O(1), CR_KT_O(2), CR_KT_O(3), CR_KT_O(4), CR_KT_O(5), CR_KT_O(6), CR_KT_O(7), CR_KT_O(8), CR_KT_O(9),
+          CR_KT_O(10), CR_KT_O(11), CR_KT_O(12), CR_KT_O(13), CR_KT_O(14), CR_KT_O(15), CR_KT_O(16), CR_KT_O(17), CR_KT_O(18), CR_KT_O(19)
+        : "memory");
+#undef CR_KT_O
+    (void)t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -64,9 +64,12 @@ struct B1Args {
 #ifdef CR_TIMELINE
 #define B1_TS(slot)                                                                                          \
     do {                                                                                                     \
-        if (a.ts && (threadIdx.x & 63) == 0)                                                                 \
-            a.ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SB_WAVES + (threadIdx.x >> 6)) * 32 + (slot)] = \
-                ((slot) == 0 || (slot) == 31) ? wall_clock64() : clock64();                                  \
+        if (a.ts && (threadIdx.x & 63) == 0) {                                                               \
+            unsigned long long* ts_ = a.ts + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SB_WAVES + (threadIdx.x >> 6)) * 32; \
+            ts_[(slot)] = ((slot) == 0 || (slot) == 31) ? wall_clock64() : clock64();                        \
+            if ((slot) == 0) ts_[30] = clock64();         /* both clocks at the ends: the shader clock's rate */ \
+            if ((slot) == 31) ts_[29] = clock64();                                                           \
+        }                                                                                                    \
     } while (0)
 #else
 #define B1_TS(slot) do { } while (0)
@@ -152,6 +155,10 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     const int wave = threadIdx.x >> 6;
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
+#ifdef CR_TIMELINE
+    asm volatile("" :: "v"(scale1), "s"(d2.key));
+#endif
+    B1_TS(13);
     f32x4 (&aw1)[2] = A.aw1; f32x4 (&aw2)[2] = A.aw2; f32x4 (&ag)[4] = A.ag; f32x4 (&ab)[4] = A.ab; f32x4 (&agF)[4] = A.agF; f32x4 (&abF)[4] = A.abF;
     f32x4 nob[2];
 #pragma unroll
@@ -190,11 +197,14 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         // (memory returns in order: the weights are requested first, or their staging would wait for the tile as well)
         WRegs<2, SB_NT> w;
         w_issue<2, SB_NT>(w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        B1_TS(14);
         const int t = threadIdx.x;
         const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
         const float gf = (a.has_ln && t < D) ? a.ln.gamma[t] : 0.0f;
         issue(0);
+        B1_TS(11);
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
+        B1_TS(12);
         if (t < 64) { gam[t] = gv; gamF[t] = gf; }
         if (!QSIDE && (a.nkt & 1)) {
             // an odd tile count: the key-owner pass reads the absent second tile of the last pair (with zero coefficients):
@@ -741,10 +751,13 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt, dQ);
     }
     __syncthreads();
+    B1_TS(16);
     wgrad_accum<SPLIT, false, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);      // dWq (+ dbq) += q_in^T dQ
+    B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
+    B1_TS(18);
     if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part + partF: 8 x 224 list entries)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
@@ -1045,13 +1058,17 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, g);
         }
         __syncthreads();
+        if (rd == 0) B1_TS(16);
         wgrad_accum<SPLIT, false>(awk, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
         wgrad_accum<SPLIT, false>(awv, nob, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
         __syncthreads();
+        if (rd == 0) B1_TS(19);
     }
+    B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
     b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
+    B1_TS(18);
     if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
@@ -1061,6 +1078,8 @@ template <bool SPLIT, int DS>
 __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     B1_TS(0);
+    cr_kernarg_touch<sizeof(B1Args)>();
+    B1_TS(15);
     // ONE sequence per workgroup pair and launch: sequence a.n0 + blockIdx.x, slab blockIdx.x.  (A loop over sequences in here
     // made every per-lane address and mask of both sides loop-invariant: hoisted to the top of the kernel and spilled, 269
     // registers.  More sequences than slabs are further launches that ADD to the slabs -- the host's loop.)

@@ -277,6 +277,7 @@ class Engine:
         self._build()
         self._finalize()
         self.graph = None
+        self._id_ring, self._ring_next = None, None
 
     # ---- small helpers -------------------------------------------------------------------------
     def buf(self, name, cols, rows=None):
@@ -1110,6 +1111,12 @@ class Engine:
         self.state[:4].zero_()
         self.state[8:].zero_()
         self.state[4:5].view(torch.int32)[0] = k
+        if getattr(self, "_feed_ring", None) is not None:
+            if self._feed_have:
+                raise RuntimeError("set_step(): %d fed batches are waiting (their ring slots follow the step number)" % self._feed_have)
+            self._feed_next, self._feed_started, self._feed_first = int(k), False, int(k)
+            torch.cuda.synchronize()
+            self._feed_done.clear()
         if getattr(self, "lazy_flags", None) is not None:
             # row-sparse Adam claims a row with atomicExch(flag, step) != step: a flag left by an earlier run of the same
             # step number (counter moved back, checkpoint loaded) would read as "already claimed" and skip the row
@@ -1137,6 +1144,120 @@ class Engine:
                 between()
             if apply:
                 self._run(([self._l2] if self._l2 else []) + [self._adam], s)
+                if self._id_ring is not None and self.lazy_adam:     # (row-sparse Adam reads this step's ids: the batch moves behind it)
+                    self._run([self._ring_next], s)
+
+    # ---- the id batches of the coming steps, resident in HBM -------------------------------------
+    def use_id_ring(self, ring):
+        """`ring`: int32 device tensor [n_slots, 6, M] (rows in ID_KEYS order), or None to go back to set_batch() per step.
+        Slot (k mod n_slots) holds the batch of step number k.  From the next launch_step() / capture() on, a step ends by moving
+        the batch of the following step into the static id buffers (inside the cr_adam_step launch): the caller sets the first
+        batch with set_batch() and keeps the slots of the coming steps filled -- no copy between two steps."""
+        ad = self._adam[2][0]._obj
+        if ring is None:
+            self._id_ring = None
+            ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = None, 0, 0, None
+            return
+        assert ring.dtype == torch.int32 and ring.is_cuda and ring.is_contiguous() and tuple(ring.shape[1:]) == (6, self.M), ring.shape
+        self._id_ring = ring
+        if self.lazy_adam:
+            self._ring_next = ("cr_ids_ring_next", L.lib.cr_ids_ring_next,
+                               (ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr(), self.state.data_ptr() + 4 * 11))
+        else:
+            # extra workgroups of the Adam launch move the batch (castrec.h cr_adam_desc.ids_ring): no launch of its own.  (A forked
+            # graph branch beside Adam was measured first: the fork and join cost 17 us per step, four times the copy they hid.)
+            ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr()
+
+    # ---- host batches fed AHEAD of the steps that use them --------------------------------------
+    def enable_feed(self, n_slots=8):
+        """Turns on the pipelined input path of a training engine: feed() packs a host batch into a pinned buffer and sends
+        it -- ONE copy over PCIe, on a copy stream, while earlier steps run -- into a slot of a device ring; train_fed() runs the
+        step of the oldest waiting batch, whose tail moves the following batch into the static id buffers (use_id_ring).  With
+        one batch fed ahead nothing stands between two steps on the device.  (set_batch() per step: six pageable copies on the
+        compute stream, 0.45 ms per step at the headline shape against 0.37 for the device step, tools/e2e_rate.py.)"""
+        assert self.training and n_slots >= 4
+        # an event behind every `_feed_every`-th step tells feed() that a slot's last reader has finished (behind EVERY step it
+        # cost 5 us per step, tools/probes/ev_cost.py); a slot is rewritten n_slots steps after its batch ran
+        self._feed_every = 4 if n_slots >= 8 else 1
+        self._feed_ring = torch.zeros(n_slots, 6, self.M, dtype=torch.int32, device=self.dev)
+        self._feed_host = torch.zeros(n_slots, 6, self.M, dtype=torch.int32).pin_memory()
+        self._feed_np = self._feed_host.numpy()
+        self._feed_stream = torch.cuda.Stream()
+        self._feed_h2d = [None] * n_slots            # per slot: its host -> device copy has finished
+        self._feed_done = {}                         # step number -> event behind that step's launch
+        recapture = self.graph is not None
+        self.use_id_ring(self._feed_ring)
+        if recapture:
+            self.capture()                           # (the ring's address travels in the Adam launch's arguments)
+        self._feed_next, self._feed_have, self._feed_started = self.step_number(), 0, False
+        self._feed_first = self._feed_next           # steps before it did not read the ring
+        used = {"seq", "pos", "neg"} | ({"time"} if "time_emb" in self.layout.entries else set()) \
+            | ({"hours", "days"} if "hours_emb" in self.layout.entries else set())
+        limits = dict(seq=self.itemnum, pos=self.itemnum, neg=self.itemnum, time=self.hp.max_bins, hours=24, days=7)
+        self._feed_limits = [(i, k, limits[k]) for i, k in enumerate(self.ID_KEYS) if k in used]
+
+    def feed(self, seq, pos, neg, time=None, hours=None, days=None):
+        """Queues the batch of the next step that has none yet (at most 5 wait at a time in the ring of 8, n_slots - 1 in a ring
+        of fewer than 8 slots).  Ids are range checked as set_batch() does."""
+        n = self._feed_ring.shape[0]
+        # a free slot beside the one the running step's tail reads, and a recorded step in [k - n, last launched]
+        if self._feed_have > min(n - self._feed_every, n - 2):
+            raise RuntimeError("feed(): %d batches are waiting already (ring of %d slots)" % (self._feed_have, n))
+        k = self._feed_next
+        slot = k % n
+        if self._feed_h2d[slot] is not None:
+            self._feed_h2d[slot].synchronize()       # the pinned buffer's previous copy (n batches ago) has left it
+        host = self._feed_np[slot]
+        for i, a in enumerate((seq, pos, neg, time, hours, days)):
+            if a is None:
+                host[i] = 0
+            else:
+                host[i] = np.asarray(a).reshape(-1)
+        if self._check_ids:
+            lo, hi = host.min(axis=1), host.max(axis=1)
+            for i, key, lim in self._feed_limits:
+                if lo[i] < 0 or hi[i] > lim:
+                    raise ValueError("%s ids outside [0, %d] (min %d, max %d): the lookup table has %d rows" % (key, lim, lo[i], hi[i], lim + 1))
+        # the slot held batch k - n: read by the tail of step k - n - 1 or, where that step ran with nothing fed ahead, by step
+        # k - n's own copy into the static buffers -- the new copy waits for the launch of step k - n
+        # (a HOST wait, like the two in train_fed: step k - n ended long ago, while a device-side wait between two streams
+        # costs ~10 us of the waiting stream's time on this stack -- measured as 17 us per step for a forked graph branch)
+        behind = [j for j in self._feed_done if j >= k - n]
+        if behind and k - n >= self._feed_first:
+            self._feed_done[min(behind)].synchronize()
+        with torch.cuda.stream(self._feed_stream):
+            self._feed_ring[slot].copy_(self._feed_host[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._feed_h2d[slot] = ev
+        self._feed_next += 1
+        self._feed_have += 1
+
+    def train_fed(self):
+        """Runs the step of the oldest fed batch."""
+        if self._feed_have < 1:
+            raise RuntimeError("train_fed(): no batch has been fed")
+        n = self._feed_ring.shape[0]
+        k = self._feed_next - self._feed_have
+        cur = torch.cuda.current_stream()
+        if not self._feed_started:
+            # nobody moved this batch into the static buffers (first step, or the step before ran with no batch fed ahead)
+            self._feed_h2d[k % n].synchronize()
+            self.ids_all.copy_(self._feed_ring[k % n])
+        if self._feed_have >= 2:
+            self._feed_h2d[(k + 1) % n].synchronize()        # this step's tail moves batch k + 1 (fed a step ago: long there)
+        self._feed_started = self._feed_have >= 2
+        if self.graph is not None:
+            self.graph.launch()
+        else:
+            self.launch_step()
+        if k % self._feed_every == 0:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._feed_done[k] = ev
+            for old in [j for j in self._feed_done if j < k - n]:
+                del self._feed_done[old]
+        self._feed_have -= 1
 
     # ---- data-parallel pieces (castrec_amd.dist drives them around an RCCL all-reduce) ----------
     def launch_backward_to_flat(self):

@@ -122,7 +122,8 @@ class AdamDesc(C.Structure):
     _fields_ = [("p", c_p), ("m", c_p), ("v", c_p), ("table_grad", c_p), ("dense_slabs", c_p),
                 ("n_table", C.c_int64), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
                 ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", C.c_int64),
-                ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p), ("slab_counts", c_p)]
+                ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p), ("slab_counts", c_p),
+                ("ids_ring", c_p), ("ids_ring_slots", c_i), ("ids_slot_elems", C.c_int64), ("ids_dst", c_p)]
 
 
 def _sig(name, restype, argtypes):
@@ -136,6 +137,7 @@ def _sig(name, restype, argtypes):
 _sig("cr_version", c_i, [])
 _sig("cr_last_error", C.c_char_p, [])
 _sig("cr_step_begin", c_i, [c_p, c_p])
+_sig("cr_ids_ring_next", c_i, [c_p, c_i, C.c_int64, c_p, c_p, c_p])
 _sig("cr_embed_fwd", c_i, [C.POINTER(EmbedDesc), c_p])
 _sig("cr_embed_bwd", c_i, [C.POINTER(EmbedBwdDesc), c_p])
 _sig("cr_layernorm_fwd", c_i, [C.POINTER(LnDesc), c_p])
@@ -185,7 +187,7 @@ _sig("cr_sampler_create", c_p, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i
 _sig("cr_sampler_next", c_i, [c_p] + [c_p] * 8)
 _sig("cr_sampler_destroy", None, [c_p])
 
-EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
+EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_ids_ring_next", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
            "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_rows_pack", "cr_rows_add", "cr_block_ln_qkv_bwd_scatter",
            "cr_wide_supported", "cr_wide_ln_qkv_fwd", "cr_wide_ln_ffn_fwd", "cr_wide_ln_ffn_fwd_tail", "cr_wide_ln_ffn_bwd", "cr_wide_ln_qkv_bwd",

@@ -27,6 +27,7 @@ class _Model(object):
         self._train = None
         self._pending_opt = None              # optimiser state loaded before the training engine exists (load / load_tf_checkpoint)
         self._eval = {}
+        self._fed = []                        # data parallel: batches handed over by feed() wait here
         self._graph = bool(int(os.environ.get("CASTREC_GRAPH", "1")))
         # parameters exist from construction on (tf.global_variables_initializer, main.py:150)
         self._owner = Engine(self.name, usernum, itemnum, self.hp, 1, training=False)
@@ -103,6 +104,33 @@ class _Model(object):
             self._dp.step(arrs)                            # this rank's rows -> backward -> exchange -> Adam (loss / auc: global)
         else:
             eng.train_step(*arrs)
+        if fetch:
+            loss, auc = eng.loss_auc()
+            return auc, loss
+        return None
+
+    # -- the same step with its batch handed over AHEAD of time ------------------------------------------------------
+    def feed(self, u, seq, pos, neg, time_seq=None, hours=None, days=None):
+        """Hands over the batch of a coming step (the sampler's output, as train_step takes it) while earlier steps run:
+        one pinned copy over PCIe on a copy stream into a device ring (Engine.enable_feed).  train_fed() then runs the oldest
+        waiting batch.  Feeding one batch ahead -- feed(b0); loop: feed(b[i + 1]); train_fed() -- leaves no copy between two
+        steps on the device.  Same arithmetic, same batches as train_step: only the transport differs."""
+        seq = np.asarray(seq)
+        eng = self._train_engine(seq.shape[0])
+        if getattr(self, "_dp", None) is not None:
+            self._fed.append((u, seq, pos, neg, time_seq, hours, days))     # data parallel: the batch waits on the host
+            return
+        if getattr(eng, "_feed_ring", None) is None:
+            eng.enable_feed()
+        eng.feed(seq, pos, neg, time_seq, hours, days)
+
+    def train_fed(self, fetch=True):
+        if getattr(self, "_dp", None) is not None:
+            return self.train_step(*self._fed.pop(0), fetch=fetch)
+        eng = self._train
+        if eng is None or getattr(eng, "_feed_ring", None) is None:
+            raise RuntimeError("train_fed(): feed() a batch first")
+        eng.train_fed()
         if fetch:
             loss, auc = eng.loss_auc()
             return auc, loss

@@ -67,6 +67,13 @@ typedef struct {
  *     sets [4] to the next step -- one kernel boundary per step less. */
 int cr_step_begin(float* state, void* stream);
 
+/* The id batch of the NEXT step out of a ring of batches resident in HBM: dst[0 .. slot_elems) <- ring slot
+ * ((*step + 1) mod n_slots), `step` = the snapshot of the running step's number (state + 11).  The reference feeds every
+ * step through sess.run's feed_dict (/root/reference/main.py:190-196); here a step's graph ends with this launch beside
+ * cr_adam_step, so that consecutive steps need no host-side copy between them.  (16-byte moves when slot_elems is a multiple
+ * of 4 and ring, dst are 16-byte aligned.) */
+int cr_ids_ring_next(const int32_t* ring, int n_slots, int64_t slot_elems, int32_t* dst, const uint32_t* step, void* stream);
+
 /* ---- embedding gather (modules.py:83-164 `embedding`, sasrec.py:27-62, cast_1.py:86-91) */
 typedef struct {
     const int32_t* ids;     /* [M] */
@@ -440,6 +447,10 @@ typedef struct {
     const int32_t* slab_counts;       /* optional (device) [ceil(n_dense / 256)]: slabs that hold gradient for the 256 dense
                                          parameters of block b (the others are known zero and are not read): producers that
                                          reduce more rows per workgroup (cr_gemm_wgrad at large hidden sizes) write fewer slabs */
+    /* Optional: the NEXT step's id batch, moved by extra workgroups of this launch (cr_ids_ring_next's job without a launch
+     * of its own): ids_dst[0 .. ids_slot_elems) <- ids_ring slot ((t + 1) mod ids_ring_slots), t = the step number this
+     * launch reads.  Not together with lazy_ids (row-sparse Adam reads the current step's ids out of those buffers). */
+    const int32_t* ids_ring; int ids_ring_slots; int64_t ids_slot_elems; int32_t* ids_dst;
 } cr_adam_desc;
 int cr_adam_step(const cr_adam_desc* d, void* stream);
 

@@ -127,12 +127,23 @@ def main(argv=None):
         json.dump(args.__dict__, f, indent=2)
     f = open(os.path.join(files_path, 'log.txt'), 'w')
     T, t0, rc = 0.0, time.time(), 0
+    def hand_over():
+        # the sampler's next batch goes to the device while the steps before it run (model.feed: one pinned copy on a copy
+        # stream); the reference feeds each step through sess.run's feed_dict (main.py:212-219) -- same batches, same order
+        u, seq, pos, neg, timeseq, ratings_seq, hours_seq, days_seq, _ = sampler.next_batch()
+        model.feed(u, seq, pos, neg, timeseq, hours_seq, days_seq)
+
     try:
+        total, done = args.num_epochs * num_batch, 0
+        if total > 0:
+            hand_over()
         for epoch in range(1, args.num_epochs + 1):
             for step in range(num_batch):
-                u, seq, pos, neg, timeseq, ratings_seq, hours_seq, days_seq, _ = sampler.next_batch()
+                done += 1
+                if done < total:
+                    hand_over()                                    # one batch ahead of the step that runs now
                 last = (step == num_batch - 1)
-                out = model.train_step(u, seq, pos, neg, timeseq, hours_seq, days_seq, fetch=last)
+                out = model.train_fed(fetch=last)
             if out is not None:
                 logger.info('epoch %d: TRAIN/loss %.5f TRAIN/auc %.5f' % (epoch, out[1], out[0]))
             if epoch % args.eval_every == 0 and rank != 0:

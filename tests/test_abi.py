@@ -44,6 +44,16 @@ def test_round3_entries_validate_their_arguments_without_gpu():
     assert L.lib.cr_stack_block_bwd_supported(ctypes.byref(bd), ctypes.byref(ad), 4, 20, L.PREC_F32) == 0      # bf16 arithmetic only
     assert L.lib.cr_rows_pack(None, None, 1, 1, 1, None, None, None, 1, None) == -1 and b"cr_rows_pack" in L.lib.cr_last_error()
     assert L.lib.cr_rows_add(None, None, 1, 1, 1, None) == -1 and b"cr_rows_add" in L.lib.cr_last_error()
+    assert L.lib.cr_ids_ring_next(None, 2, 8, None, None, None) == -1 and b"cr_ids_ring_next" in L.lib.cr_last_error()
+    buf = (ctypes.c_int32 * 64)()
+    p = ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 16
+    assert L.lib.cr_ids_ring_next(p, 0, 6, p + 64, p, None) == -1 and b"n_slots" in L.lib.cr_last_error()
+    # the id ring inside the Adam launch: not together with the row-sparse update (it reads the step's ids)
+    ad = L.AdamDesc()
+    ad.p = ad.m = ad.v = ad.state = ad.table_grad = p
+    ad.n_table, ad.lazy_ids, ad.lazy_flags, ad.n_lazy_ids, ad.lazy_rows, ad.lazy_D = 8, p, p, 4, 2, 4
+    ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = p, 2, 8, p + 64
+    assert L.lib.cr_adam_step(ctypes.byref(ad), None) == -1 and b"exclude each other" in L.lib.cr_last_error()
 
 
 def test_struct_sizes_match_c_layout(tmp_path):

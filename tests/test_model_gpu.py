@@ -61,6 +61,19 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def same_run(a, b):
+    """Two engines after the same batches in the same order: the dense parameters agree to rounding (the table gradients are
+    float atomics, so runs of several steps are not bit-identical, and Adam turns a rounding-level change of a near-zero gradient
+    into a step of ~lr on a few parameters), where a swapped or stale batch moves MOST parameters by ~lr (median 3e-3 when the
+    first version of feed() let a copy overtake the step that still read its slot)."""
+    d = (a.P - b.P).abs()
+    st = (float(d.median()), float(torch.quantile(d[:1 << 20], 0.99)), float(d.max()))
+    ok = st[0] <= 1e-7 and st[1] <= 1e-4 and st[2] <= 5e-3
+    if not ok:
+        print("same_run: median %.3g, 99 %% quantile %.3g, max %.3g of |difference|" % st)
+    return ok
+
+
 CASES = [(m, 0.0, True) for m in fm.MODELS] + [("sasrec", 0.3, True), ("cast_1", 0.3, True), ("cast_4", 0.25, True), ("cast_9", 0.2, True)]
 # the unfused kernel path (used for hidden sizes > 64) stays covered at the same small shapes
 CASES += [("sasrec", 0.0, False), ("cast_1", 0.3, False), ("cast_3", 0.0, False), ("cast_9", 0.2, False)]
@@ -611,6 +624,88 @@ def test_graph_replay_equals_eager(E):
     torch.cuda.synchronize()
     la, lb = a.loss_auc(), b.loss_auc()
     assert la[0] == pytest.approx(lb[0], rel=1e-3) and b.step_number() == 5
+
+
+@pytest.mark.parametrize("lazy,graph", [(False, False), (False, True), (True, True), (None, True)])
+def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
+    """Engine.use_id_ring: the batch of step k sits in ring slot k mod n_slots and the step before moves it into the static id
+    buffers (extra workgroups of the Adam launch; cr_ids_ring_next behind a row-sparse Adam).  Same batches, same order =
+    the run that copies one batch per step."""
+    rs = np.random.RandomState(16)
+    B, T, D, itemnum, NS = (6, 32, 50, 90, 3) if lazy is False else (5, 31, 50, 90, 3)      # (5 x 31 rows: a slot that is no multiple of 16 bytes)
+    lazy = bool(lazy)
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=20, seed=5)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True, lazy_adam=lazy)
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, lazy_adam=lazy)
+    b.P.copy_(a.P)
+    batches = [make_batch(rs, B, T, itemnum, 20) for _ in range(NS)]
+    ring = torch.from_numpy(np.stack([np.stack([x.reshape(-1) for x in bt]) for bt in batches]).astype(np.int32)).cuda()
+    b.use_id_ring(ring)
+    if graph:
+        b.capture()
+    first = b.step_number()
+    b.set_batch(*batches[first % NS])
+    for k in range(first, first + 2 * NS + 1):                      # more steps than slots: the ring wraps
+        a.train_step(*batches[k % NS])
+        if graph:
+            b.graph.launch()
+        else:
+            b.launch_step()
+    torch.cuda.synchronize()
+    assert b.step_number() == first + 2 * NS + 1
+    assert torch.equal(b.ids_all.cpu(), ring[b.step_number() % NS].cpu())       # the coming step's batch is in place
+    nt = a.layout.n_table
+    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=1e-4)
+    b.P.copy_(a.P); b.Mom.copy_(a.Mom); b.Vel.copy_(a.Vel)
+    b.use_id_ring(None)                                             # ... and back to a batch per call
+    batch = make_batch(rs, B, T, itemnum, 20)
+    if graph:
+        b.capture()
+    a.train_step(*batch)
+    b.train_step(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(b.ids_all.cpu(), a.ids_all.cpu()) and torch.equal(a.P[nt:], b.P[nt:])
+
+
+@pytest.mark.parametrize("graph,n_slots", [(False, 4), (True, 4), (True, 8)])
+def test_fed_batches_train_like_batches_set_per_step(E, graph, n_slots):
+    """Engine.enable_feed / feed / train_fed: pinned host batches sent ahead over a copy stream into the id ring.  Every
+    feeding pattern (one ahead, two ahead, none ahead) runs the batches in order; an out-of-range id is refused."""
+    rs = np.random.RandomState(17)
+    B, T, D, itemnum = 5, 32, 50, 80
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=20, seed=6)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b.P.copy_(a.P)
+    if graph:
+        b.capture()
+    b.enable_feed(n_slots=n_slots)
+    batches = [make_batch(rs, B, T, itemnum, 20) for _ in range(12)]
+    for bt in batches:
+        a.train_step(*bt)
+    it = iter(batches)
+    b.feed(*next(it))
+    for _ in range(4):                                             # one batch ahead
+        b.feed(*next(it))
+        b.train_fed()
+    b.train_fed()                                                  # the queue runs dry: the next batch takes the direct way
+    b.feed(*next(it)); b.feed(*next(it))                           # two ahead
+    for _ in range(3):
+        b.feed(*next(it))
+        b.train_fed()
+    b.train_fed(); b.train_fed()
+    b.feed(*next(it)); b.train_fed()                               # none ahead
+    b.feed(*next(it)); b.train_fed()
+    torch.cuda.synchronize()
+    assert next(it, None) is None and b.step_number() == a.step_number() == 13
+    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=1e-4)
+    bad = list(batches[0]); bad[0] = bad[0].copy(); bad[0][1, -1] = itemnum + 1
+    with pytest.raises(ValueError):
+        b.feed(*bad)
+    for _ in range(5 if n_slots == 8 else 3):
+        b.feed(*batches[0])
+    with pytest.raises(RuntimeError):                              # no more than 5 (ring of 8) / n_slots - 1 batches wait
+        b.feed(*batches[0])
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])

@@ -43,10 +43,14 @@ for side, sname in ((0, "K side (blockIdx.y = 0)"), (1, "Q side (blockIdx.y = 1)
     life = (tt[:, :, 31] - tt[:, :, 0]) * 10.0 / 1e3
     print("== %s: wave life us  all p50 %.1f max %.1f | full-length sequences p50 %.1f max %.1f" %
           (sname, np.median(life), life.max(), np.median(life[full]), life[full].max()))
+    clk = tt[:, :, 29] - tt[:, :, 30]
+    mhz = np.median(clk[full] / life[full])
+    print("   shader clock over the wave lives: median %.0f MHz" % mhz)
     for wave in (0, 3, 7):
         print(" -- wave %d, full-length sequences" % wave)
         prev = tt[full, wave, 0] * 0 + np.nan
-        order = [1, 2, 9, 3, 6, 8, 4, 7, 5] if side == 1 else [1, 2, 3, 6, 8, 4, 7, 5]
+        order = [30, 15, 13, 14, 11, 12, 1, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 5, 29]
+        names[29] = "end (scatter issue)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table)"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
         base = None
         for k in order:
             cur = tt[full, wave, k]
@@ -57,5 +61,5 @@ for side, sname in ((0, "K side (blockIdx.y = 0)"), (1, "Q side (blockIdx.y = 1)
             ok = (cur > 0) & (prev > 0)
             if ok.sum():
                 dlt = (cur - prev)[ok]
-                print("    %-44s median %7.0f clk (%5.2f us)  p90 %7.0f" % (names[k], np.median(dlt), np.median(dlt) / 2.4e3, np.percentile(dlt, 90)))
+                print("    %-44s median %7.0f clk (%5.2f us)  p90 %7.0f" % (names[k], np.median(dlt), np.median(dlt) / mhz, np.percentile(dlt, 90)))
             prev = np.where(cur > 0, cur, prev)
