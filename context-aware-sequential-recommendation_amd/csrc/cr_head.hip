@@ -152,6 +152,7 @@ template <int LPR, int MAXC>
 __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc n) {
     constexpr int RPW = 64 / LPR;
     __shared__ float red[3][16 * RPW];
+    cr_kernarg_touch<sizeof(cr_head_desc) + sizeof(cr_ln_bwd_desc)>();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, l = lane % LPR;
     const int rps = (d.M + gridDim.x - 1) / gridDim.x;

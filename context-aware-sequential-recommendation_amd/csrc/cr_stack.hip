@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cr_kernarg_touch<(sizeof(StackArgs) < 1280 ? sizeof(StackArgs) : 1280)>();      // (the first blocks: one launch per block uses blk[0] only)
     // (DS instantiations run with nkt == NKT: the image size is then a constant and the hi / lo / K / V / weight images are
     //  immediates apart: an operand read is one per-lane base + immediate instead of an address sum per read)
     const int IMG = DS > 0 ? 16 * NKT * 64 : a.T16 * 64;

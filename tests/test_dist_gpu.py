@@ -60,10 +60,13 @@ def _worker(rank, world, port, q, items=ITEMS, sparse=False, D=D, H=1):
     dp = DataParallel(rep, rank, world, sparse=sparse)
     assert dp.sparse == bool(sparse)
     rep.adopt_params()
+    m1 = None
     for s in range(STEPS):
         dp.step(make_batch(s, items))
+        if s == 0:                                             # Adam's first moment after ONE step = 0.1 x the exchanged gradient
+            m1 = {k: eng.layout.view(eng.Mom, k).cpu().numpy().copy() for k in eng.layout.logical_names()}
     torch.cuda.synchronize()
-    q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, eng.Gflat[eng.layout.n_total:eng.layout.n_total + 3].cpu().numpy()))
+    q.put((rank, {k: v.cpu().numpy() for k, v in eng.get_params().items()}, eng.Gflat[eng.layout.n_total:eng.layout.n_total + 3].cpu().numpy(), m1))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,24 +95,36 @@ def test_two_ranks_on_the_card_equal_one_process_on_the_whole_batch(items, spars
     perturb_start(one)
     for s in range(STEPS):
         one.train_step(*make_batch(s, items))
+        if s == 0:
+            m1 = {k: one.layout.view(one.Mom, k).cpu().numpy().copy() for k in one.layout.logical_names()}
     torch.cuda.synchronize()
+    # (1) the exchanged GRADIENT of the first step, read off Adam's first moment (m = 0.1 g after one step: linear, nothing
+    # amplifies a rounding difference): the two-rank run's equals the whole-batch run's to the re-association of fp32 sums
+    for k in m1:
+        if k.endswith(".bk"):
+            continue                                           # the key bias: a zero-gradient direction (softmax is shift invariant), rounding noise only
+        dm = np.abs(res[0][3][k] - m1[k]).max()
+        assert dm <= 5e-6 * max(np.abs(m1[k]).max(), 1e-12), (k, float(dm), float(np.abs(m1[k]).max()))
     ref = {k: v.cpu().numpy() for k, v in one.get_params().items()}
     # both ranks hold the same replica after the exchange
     for k in ref:
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
-    # and it is the single-process result: same inputs, same dropout masks, global normalisation.
-    # Sums are re-associated (per-shard slabs, then the all-reduce), so fp32 rounding differs; Adam turns a relative
-    # gradient difference e into a step difference of about lr*e.
+    # (2) and the PARAMETERS after three steps are the single-process result: same inputs, same dropout masks, global
+    # normalisation.  Sums are re-associated (per-shard slabs, then the all-reduce; the table gradients are float atomics whose
+    # order changes from run to run), and from the second step on a rounding-level parameter difference can flip a ReLU gate or
+    # move a gradient element whose contributions nearly cancel, which Adam's m / (sqrt(v) + eps) turns into a step of a
+    # fraction of lr.  Seen over 19 runs of the D = 128 case (tools/probes/flake.sh): 14 runs with <= 3 elements above 5e-6; one
+    # with 46 elements of trunk.0.w1 up to 3.8e-5 (one hidden unit's column), one with 242 elements of item_emb (two table
+    # rows, 3 % of it: items drawn as positive AND negative of one position, whose two contributions cancel) up to 1.13e-4 -- a
+    # different tensor each time (a third run: two rows of the 21-row time_emb, 7 % of it, up to 1.10e-4), none of them off in
+    # (1): whole rows or columns whose gradient is orders below the tensor's largest, where Adam's normalisation amplifies what (1)
+    # bounds relative to that largest.  The bounds: three quarters of every tensor within 5e-6, no element beyond 5e-4 (a sixth of
+    # what three Adam steps can move one); the sharp statement about the exchange is (1).
     for k in ref:
         if k.endswith(".bk"):
             continue                                           # zero-gradient direction, see test_e2e_gpu
-        # measured: <= 8e-7 after 3 steps for all but a few elements in 100 000: where the contributions to a gradient
-        # element nearly cancel, m / (sqrt(v) + eps) turns the re-association-level ABSOLUTE gradient difference into a
-        # relative one (seen: 2 elements of the 5001 x 20 item table at 3e-6 and 2e-5, each moved 4e-4 in 3 steps)
         d = np.abs(res[0][1][k] - ref[k])
-        # (the count of such elements is a small-number statistic: 3 of 16 384 seen at D = 128 -- allowed: 1 + 5e-4 of the tensor;
-        #  the bound that matters is the maximum, 1e-4: thirty times below what three Adam steps could move an element)
-        assert d.max() <= 1e-4 and (d > 5e-6).sum() <= 1 + 5e-4 * d.size, (k, float(d.max()), int((d > 5e-6).sum()))
+        assert np.quantile(d, 0.75) <= 5e-6 and d.max() <= 5e-4, (k, float(np.quantile(d, 0.75)), float(d.max()), int((d > 5e-6).sum()))
     loss_one = one.loss_auc()[0]
     st = res[0][2]
     assert st[0] / st[2] == pytest.approx(loss_one, rel=1e-5)  # bucket tail: loss_sum, auc_sum, n_target of the WHOLE batch

@@ -64,11 +64,11 @@ def rel(a, b):
 def same_run(a, b):
     """Two engines after the same batches in the same order: the dense parameters agree to rounding (the table gradients are
     float atomics, so runs of several steps are not bit-identical, and Adam turns a rounding-level change of a near-zero gradient
-    into a step of ~lr on a few parameters), where a swapped or stale batch moves MOST parameters by ~lr (median 3e-3 when the
-    first version of feed() let a copy overtake the step that still read its slot)."""
+    into a step of ~lr on a few parameters: medians of 1e-8 .. 7e-6 over repeated runs), where a swapped or stale batch moves MOST
+    parameters by ~lr (median 3e-3 when the first version of feed() let a copy overtake the step that still read its slot)."""
     d = (a.P - b.P).abs()
     st = (float(d.median()), float(torch.quantile(d[:1 << 20], 0.99)), float(d.max()))
-    ok = st[0] <= 1e-7 and st[1] <= 1e-4 and st[2] <= 5e-3
+    ok = st[0] <= 2e-4 and st[1] <= 1.5e-3 and st[2] <= 5e-3
     if not ok:
         print("same_run: median %.3g, 99 %% quantile %.3g, max %.3g of |difference|" % st)
     return ok
@@ -655,7 +655,7 @@ def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
     assert b.step_number() == first + 2 * NS + 1
     assert torch.equal(b.ids_all.cpu(), ring[b.step_number() % NS].cpu())       # the coming step's batch is in place
     nt = a.layout.n_table
-    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=1e-4)
+    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=2e-3)
     b.P.copy_(a.P); b.Mom.copy_(a.Mom); b.Vel.copy_(a.Vel)
     b.use_id_ring(None)                                             # ... and back to a batch per call
     batch = make_batch(rs, B, T, itemnum, 20)
@@ -698,7 +698,7 @@ def test_fed_batches_train_like_batches_set_per_step(E, graph, n_slots):
     b.feed(*next(it)); b.train_fed()
     torch.cuda.synchronize()
     assert next(it, None) is None and b.step_number() == a.step_number() == 13
-    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=1e-4)
+    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=2e-3)
     bad = list(batches[0]); bad[0] = bad[0].copy(); bad[0][1, -1] = itemnum + 1
     with pytest.raises(ValueError):
         b.feed(*bad)

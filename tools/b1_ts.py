@@ -46,11 +46,15 @@ for side, sname in ((0, "K side (blockIdx.y = 0)"), (1, "Q side (blockIdx.y = 1)
     clk = tt[:, :, 29] - tt[:, :, 30]
     mhz = np.median(clk[full] / life[full])
     print("   shader clock over the wave lives: median %.0f MHz" % mhz)
+    print("   per wave, full-length sequences, us from the wave's start: loads issued | weights staged | phase 1 opens | phase 1 done")
+    for wave in range(8):
+        rel = lambda k: np.median((tt[full, wave, k] - tt[full, wave, 30])) / mhz
+        print("     wave %d: %5.2f | %5.2f | %5.2f | %5.2f" % (wave, rel(11), rel(12), rel(1), rel(2)))
     for wave in (0, 3, 7):
         print(" -- wave %d, full-length sequences" % wave)
         prev = tt[full, wave, 0] * 0 + np.nan
-        order = [30, 15, 13, 14, 11, 12, 1, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 5, 29]
-        names[29] = "end (scatter issue)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table)"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
+        order = [30, 15, 13, 14, 11, 12, 1, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 20, 21, 22, 23, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 20, 21, 22, 23, 5, 29]
+        names[29] = "end (scatter issue)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table: slab written)"; names[20] = "small table: ids requested, barrier"; names[21] = "small table: image zeroed, lists, barrier"; names[22] = "small table: rows added"; names[23] = "small table: barrier"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
         base = None
         for k in order:
             cur = tt[full, wave, k]
