@@ -425,6 +425,8 @@ def main():
                     help="synthetic corpus preset (castrec_amd/synth.py); the headline line is ml-1m")
     ap.add_argument("--lazy_adam", action="store_true", help="row-sparse Adam on the item table (a deviation, DESIGN.md section 8)")
     ap.add_argument("--sparse-exchange", default="auto", choices=["auto", "on", "off"], help="DP: item-table gradient exchange")
+    ap.add_argument("--condition-ms", type=float, default=15.0, help="untimed steps of the workload run in front of the warm-up steps for this "
+                    "many milliseconds (the clock governor's transient after idle, reported as `conditioning`); 0 = none")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel HIP-event table here")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -474,11 +476,19 @@ def main():
     smp.close()
     staged = torch.from_numpy(np.stack([np.stack([a.reshape(-1) for a in hb]) for hb in host_batches]).astype(np.int32)).cuda()
 
+    conditioning = []
+
     def run(precision, steps, warmup):
         eng = E.Engine(args.model, corpus.usernum, corpus.itemnum, hyper(args), B, training=True, n_slabs=args.n_slabs,
                        batch_global=Bg, row_offset=rank * B * T, attn_precision=precision, lazy_adam=args.lazy_adam)
         dp = None
         use_graph = not args.no_graph
+        ring = (dist is None or not args.lazy_adam) and os.environ.get("CASTREC_NO_ID_RING") != "1"
+        if ring:
+            # the NB staged batches ARE the id ring: a step ends by moving the next step's batch (slot = step number mod NB) into
+            # the static id buffers with extra workgroups of its Adam launch (Engine.use_id_ring; set before any capture: the
+            # ring's address travels in that launch's arguments) -- no host-issued copy between two steps
+            eng.use_id_ring(staged)
         if dist is not None:
             # data-parallel step: three HIP graphs (forward + backward up to the last table-gradient launch | rest of the backward
             # + slab collapse | Adam) around the collectives; the table's exchange runs beside the second graph (dist.step_phases)
@@ -493,11 +503,6 @@ def main():
                 one = os.environ.get("CASTREC_DP_ONE_GRAPH")
                 whole = dp.capture_step() if (one == "1" or (one is None and world == 1)) else False
                 eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
-        ring = dist is None and os.environ.get("CASTREC_NO_ID_RING") != "1"
-        if ring:
-            # the NB staged batches ARE the id ring: a step ends by moving the next step's batch (slot = step number mod NB) into
-            # the static id buffers beside Adam (Engine.use_id_ring) -- no host-issued copy between two steps
-            eng.use_id_ring(staged)
         if dist is None and use_graph:
             eng.ids_all.copy_(staged[0])
             eng.capture()
@@ -520,6 +525,26 @@ def main():
                 dp.exchange(eng.Gflat)                       # dense bucket all-reduce, or sparse table rows + small bucket
                 eng.launch_adam_from_flat()
 
+        # Conditioning (untimed, reported): after ANY idle period the chip needs ~35 steps (13 ms) of this workload before its step
+        # time settles -- 0.390 ms for the first steps, 0.372 from about the 35th on, whatever ran before (30 ms of streaming
+        # kernels do not shorten it; tools/probes/step_transient.py) -- so a window of W = 5 + K = 20 steps right behind the
+        # setup measures the governor's transient, not the training rate.  `--condition-ms` (default 15) of the same steps run
+        # first; their own mean time goes into the line as `cold_ms_per_step`.  0 turns it off.
+        cond = {"steps": 0, "cold_ms_per_step": None}
+        if args.condition_ms > 0:
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            nc = 0
+            # (with collectives every rank must run the SAME number of steps: a fixed 250 -- RCCL's lazy set-up of its channels
+            #  skews the first ~200 exchanges)
+            while (nc < 250) if dist is not None else (nc < 8 or (time.perf_counter() - tc) * 1e3 < args.condition_ms):
+                step(nc)
+                nc += 1
+                if nc % 8 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            cond = {"steps": nc, "cold_ms_per_step": round((time.perf_counter() - tc) / nc * 1e3, 4)}
+        conditioning.append(cond)
         for i in range(warmup):
             step(i)
         torch.cuda.synchronize()
@@ -605,6 +630,8 @@ def main():
         out = {
             "metric": "user-sequences/sec (fwd+bwd)", "value": round(Bg * args.steps / dt, 1), "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "conditioning": dict(conditioning[0], note="untimed steps of the same workload in front of the W warm-up steps (--condition-ms): the chip's "
+                                 "step time settles ~35 steps after any idle period; cold_ms_per_step = the mean over these first steps"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 split MFMA in attention)", "bf16": "bf16 (attention) / f32"}[prec],
             "data": "synthetic", "config": cfg, "roofline": roofline, "attention": attn, "kernels": kernels,

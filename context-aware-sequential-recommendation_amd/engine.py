@@ -1153,10 +1153,11 @@ class Engine:
         Slot (k mod n_slots) holds the batch of step number k.  From the next launch_step() / capture() on, a step ends by moving
         the batch of the following step into the static id buffers (inside the cr_adam_step launch): the caller sets the first
         batch with set_batch() and keeps the slots of the coming steps filled -- no copy between two steps."""
-        ad = self._adam[2][0]._obj
+        ads = [self._adam[2][0]._obj, self._adam_flat[2][0]._obj]      # the plain step's Adam and the data-parallel one (on the reduced bucket)
         if ring is None:
             self._id_ring = None
-            ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = None, 0, 0, None
+            for ad in ads:
+                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = None, 0, 0, None
             return
         assert ring.dtype == torch.int32 and ring.is_cuda and ring.is_contiguous() and tuple(ring.shape[1:]) == (6, self.M), ring.shape
         self._id_ring = ring
@@ -1166,7 +1167,8 @@ class Engine:
         else:
             # extra workgroups of the Adam launch move the batch (castrec.h cr_adam_desc.ids_ring): no launch of its own.  (A forked
             # graph branch beside Adam was measured first: the fork and join cost 17 us per step, four times the copy they hid.)
-            ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr()
+            for ad in ads:
+                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr()
 
     # ---- host batches fed AHEAD of the steps that use them --------------------------------------
     def enable_feed(self, n_slots=8):
