@@ -24,6 +24,7 @@ from castrec_amd import synth  # noqa: E402
 from castrec_amd.engine import MODELS  # noqa: E402
 from castrec_amd.models import build_model  # noqa: E402
 from castrec_amd.sampler import WarpSampler  # noqa: E402
+from castrec_amd.tb_events import EventWriter  # noqa: E402
 from castrec_amd.util import data_partition, evaluate, evaluate_valid, partition, train_corpus  # noqa: E402
 
 
@@ -126,6 +127,9 @@ def main(argv=None):
     with open(os.path.join(files_path, 'params.txt'), 'w') as f:   # main.py:196-197
         json.dump(args.__dict__, f, indent=2)
     f = open(os.path.join(files_path, 'log.txt'), 'w')
+    # TensorBoard scalars as the reference's tf.summary.FileWriter(TRAIN_FILES_PATH) leaves them (main.py:203,222-224,240-249;
+    # sasrec.py:112-118): TRAIN/loss, TRAIN/auc of each epoch's last step; VALID/* and TEST/* at every evaluation
+    writer = EventWriter(files_path)
     T, t0, rc = 0.0, time.time(), 0
     def hand_over():
         # the sampler's next batch goes to the device while the steps before it run (model.feed: one pinned copy on a copy
@@ -146,6 +150,8 @@ def main(argv=None):
                 out = model.train_fed(fetch=last)
             if out is not None:
                 logger.info('epoch %d: TRAIN/loss %.5f TRAIN/auc %.5f' % (epoch, out[1], out[0]))
+                writer.add_scalars(epoch, {'TRAIN/loss': out[1], 'TRAIN/auc': out[0]})
+                writer.flush()
             if epoch % args.eval_every == 0 and rank != 0:
                 tdist.barrier()                                    # rank 0 evaluates; parameters are identical everywhere
                 t0 = time.time()
@@ -159,6 +165,9 @@ def main(argv=None):
                     epoch, T, t_valid[0], t_valid[1], t_test[0], t_test[1]))
                 f.write(str(tuple(float(x) for x in t_valid)) + ' ' + str(tuple(float(x) for x in t_test)) + '\n')   # plain floats, as main.py:238 prints under numpy 1.16
                 f.flush()
+                writer.add_scalars(epoch, {'VALID/NDCG@10': float(t_valid[0]), 'VALID/HR@10': float(t_valid[1]),
+                                           'TEST/NDCG@10': float(t_test[0]), 'TEST/HR@10': float(t_test[1])})
+                writer.flush()
                 if world > 1:
                     tdist.barrier()
                 t0 = time.time()
@@ -173,6 +182,7 @@ def main(argv=None):
             logging.shutdown()
             os._exit(1)
     f.close()
+    writer.close()
     sampler.close()
     if rc == 0:
         print("Done")

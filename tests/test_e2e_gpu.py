@@ -65,6 +65,16 @@ def test_main_cli_trains_evaluates_and_writes_reference_artifacts(tmp_path, monk
     assert (d / "params.txt").exists() and (d / "model.ckpt").exists()
     lines = (d / "log.txt").read_text().strip().splitlines()
     assert len(lines) == 2 and lines[0].startswith("(")            # "(ndcg, hr) (ndcg, hr)" per evaluation (main.py:238)
+    # TensorBoard scalars of the run directory (main.py:203,222-224,240-249): per epoch the training pair, then the evaluation
+    from castrec_amd.tb_events import read_events
+    evf = [x for x in os.listdir(d) if x.startswith("events.out.tfevents.")]
+    assert len(evf) == 1
+    ev = read_events(str(d / evf[0]))
+    assert [s for s, _ in ev] == [1, 1, 2, 2] and set(ev[0][1]) == {"TRAIN/loss", "TRAIN/auc"}
+    assert set(ev[1][1]) == {"VALID/NDCG@10", "VALID/HR@10", "TEST/NDCG@10", "TEST/HR@10"}
+    import ast
+    valid2, test2 = (ast.literal_eval(x) for x in lines[1].replace(") (", ")|(").split("|"))
+    assert ev[3][1]["TEST/NDCG@10"] == pytest.approx(test2[0], rel=1e-6) and ev[3][1]["VALID/HR@10"] == pytest.approx(valid2[1], rel=1e-6)
     # --test_model mode re-loads the checkpoint (main.py:161-189)
     rc = cli.main(["--dataset", "synthetic:tiny", "--train_dir", "t", "--model", "cast_3", "--maxlen", "12", "--batch_size", "4",
                    "--hidden_units", "16", "--max_bins", "20", "--test_model", str(d), "--test_seq_len", "5"])
