@@ -138,7 +138,7 @@ def main(argv=None):
         model.feed(u, seq, pos, neg, timeseq, hours_seq, days_seq)
 
     try:
-        total, done = args.num_epochs * num_batch, 0
+        total, done, out = args.num_epochs * num_batch, 0, None
         if total > 0:
             hand_over()
         for epoch in range(1, args.num_epochs + 1):
