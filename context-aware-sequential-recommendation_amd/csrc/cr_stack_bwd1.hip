@@ -173,7 +173,8 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         rok = q < T;
         m = n * T + min(q, T - 1);
     };
-    auto issue = [&](int rd) {
+    // the rows of a tile in two halves: what the chain opens with (dy, dy2, y, hid), and what its end needs (f_in / Q, o, q_in)
+    auto issue_a = [&](int rd) {
         if (rd * SB_TPR < a.nkt && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
             int m; bool rok;
             tile_rows(rd, m, rok);
@@ -187,11 +188,19 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
                 if (a.dy2) r_issue(rdy2, a.dy2, mo, dcx);
             }
             r_issue(rhid, d.hid, mo, dcx);
+        }
+    };
+    auto issue_b = [&](int rd) {
+        if (rd * SB_TPR < a.nkt && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+            int m; bool rok;
+            tile_rows(rd, m, rok);
+            const u32 mo = (u32)m * (u32)(4 * D);
             r_issue(rfin, QSIDE ? d.f_in : d.qkv, mo, dcx);
             r_issue(ro, d.o, mo, dcx);
             r_issue(rq, d.q_in, mo, dcx);
         }
     };
+    auto issue = [&](int rd) { issue_a(rd); issue_b(rd); };
     const int R = a.nkt > SB_TPR ? 2 : 1;
     {
         // (memory returns in order: the weights are requested first, or their staging would wait for the tile as well)
@@ -201,7 +210,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         const int t = threadIdx.x;
         const float gv = (t < D) ? d.ln2_g[t] : 0.0f;
         const float gf = (a.has_ln && t < D) ? a.ln.gamma[t] : 0.0f;
-        issue(0);
+        // (only the first half of the tile's rows in front of the weights' staging: the CU's address pipeline takes ~1.6 us to
+        //  issue 7 waves x 24 row loads, and the waves that get theirs out last hold the barrier below: tools/b1_ts.py)
+        issue_a(0);
         B1_TS(11);
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
         B1_TS(12);
@@ -215,6 +226,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     }
     __syncthreads();
     B1_TS(1);
+    issue_b(0);                                                    // ... the second half behind it, under the chain's first product
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
         const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);          // tiles of this round (wave-uniform)
