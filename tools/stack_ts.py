@@ -53,6 +53,22 @@ if WHICH == 8:
     sys.exit(0)
 names = {0: "weights staged (barrier)", 1: "phase A first tile", 2: "phase A all tiles", 3: "W1/W2 staged (2 barriers)",
          4: "scores + softmax (first tile)", 5: "A V + o (first tile)", 6: "LN2 + FFN (first tile)", 8: "all tiles done"}
+# full-length sequences, per workgroup of the pair and wave: us from the wave's start to each stamp (shader clock from the wall-clock ends)
+lens = (seq != 0).sum(1)
+full = np.where(lens >= 193)[0]
+tt = ts.cpu().numpy().reshape(2, B, 8, NS).astype(np.float64)
+if (tt[1, :, 0, 63] > 0).any():
+    for y in range(2):
+        life = (tt[y][full][:, :, 63] - tt[y][full][:, :, 0]) * 10.0 / 1e3
+        print("== workgroup y = %d of a full-length sequence: wave life us p50 %.1f max %.1f" % (y, np.median(life), life.max()))
+        print("   wave: weights staged | phase A first | phase A all | W1/W2 staged | scores+softmax | A V + o | LN2 + FFN | all tiles | end    (us from the first stamp, 2.28 GHz assumed)")
+        for wave in range(8):
+            row = []
+            for k in (0, 1, 2, 3, 4, 5, 6, 8):
+                cur = tt[y][full][:, wave, 2 + k]; base = tt[y][full][:, wave, 1]
+                ok = (cur > 0) & (base > 0)
+                row.append("%5.2f" % (np.median((cur - base)[ok]) / 2.28e3) if ok.sum() else "  -  ")
+            print("   %d: %s | life %.1f" % (wave, " | ".join(row), np.median(life[:, wave])))
 for wave in (0, 3, 7):
     print("-- wave", wave)
     prev = t[:, wave, 1]
