@@ -17,10 +17,12 @@ SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wall", "-Wno-unused-function",
          # no SLP vectorisation: it packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  (a) Beside MFMAs those cost more
-         # than the two scalar ops (MI355X_MICROARCH.md, cycle constants).  (b) Round 3: in cr_stack_bwd1.hip a compiler-made
-         # v_pk_mul_f32 whose source pair was overwritten by the very next instruction returned a wrong LOW half in lanes 48..63,
-         # about once in 350 steps (single columns of a gradient tile; 7 of 2400 runs against 0 of 2400 without the packing, same
-         # box, tools/diag_repro.py).  Not understood further; the hand-written f32x2 arithmetic (cr_bf16.hpp split8) is unaffected.
+         # than the two scalar ops (MI355X_MICROARCH.md, cycle constants).  (b) profiles/r04_flake/README.md: with SLP on, the last
+         # statement of the LayerNorm backward in cr_stack_bwd1.hip becomes in-place v_pk_add -> v_pk_fma -> v_pk_mul chains on one
+         # register pair, and in 1 replay of 5 .. 350 (schedule dependent; 111 recorded cases, all alike) the v_pk_fma's contribution
+         # is missing in the low register of lanes 48..63; 0 of 3 000 on the same source without SLP.  Every pattern of the chain
+         # is exact in isolation (seven probes, ~1e9 executions each): the trigger inside the kernel is not isolated, so the packing
+         # itself is kept out.
          "-fno-slp-vectorize"]
 
 
@@ -46,8 +48,9 @@ def build(force=False, verbose=False, timeline=False):
     lib = LIB_TL if timeline else LIB
     flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else []) + os.environ.get("CASTREC_EXTRA_FLAGS", "").split()
     # sources compiled WITH SLP vectorisation all the same: cr_attn_bf.hip -- its head-dim-32 forward is 37 % slower without the
-    # packed fp32 arithmetic (config C4: 29.6 -> 40.6 us per launch), and 3000 launches of its forward + backward at the C4 and
-    # headline shapes hold the same bits with and without it (tools/diag_attn_repro.py)
+    # packed fp32 arithmetic (config C4: 29.6 -> 40.6 us per launch); its 392 compiler-made v_pk_fma_f32 are all out-of-place (the
+    # failing form above is the in-place chain: 47 of them in the SLP build of cr_stack_bwd1.hip, none here), and 4 000 replays of a
+    # D = 128 / 4-head step hold the same bits (tools/diag_repro2.py, profiles/r04_flake/reproducibility_runs.json)
     slp_ok = os.environ.get("CASTREC_SLP_FILES", "cr_attn_bf.hip").split()
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
     headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"), os.path.join(CSRC, "cr_rbwd.hpp"),

@@ -33,6 +33,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "cr_rbwd.hpp"
 
@@ -261,7 +262,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
                 for (int r = 0; r < 4; ++r) {
                     dy[ct][r] *= msk;
                     float v = dy[ct][r];
-                    if (d2.on) v *= drop_factor_x(d2, e2 + (uint32_t)(16 * ct + r) * CR_PHI);
+                    v *= drop_factor_x(d2, e2 + (uint32_t)(16 * ct + r) * CR_PHI);      // (rate 0: threshold 0, factor 1.0 -- no branch per element)
                     g2[ct][r] = v;
                 }
             r_finish(hid, rhid, dcx);
@@ -361,7 +362,7 @@ __device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = dxl[ct][r] * kf;
-            if (dce.on) v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
+            v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
             dxl[ct][r] = v;
         }
 }
@@ -562,6 +563,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
     }
+    // byte offset of this lane group's four keys in the additive key bias (a key tile adds 64): an opaque value, so that the
+    // loop's reads are (one base + pair offset) + immediate
+    int vkb = L::F_OFF_BYTES + 4 * (L::KB + 4 * lg);
+    asm volatile("" : "+v"(vkb));
     const unsigned tpk = a.qpk[wave];
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
     // a tile's inputs (Q fragment in operand layout, d_o in layout R, the forward's row statistics); the NEXT tile's are
@@ -588,7 +593,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const bool rok = q < T;
         const int m = base_row + min(q, T - 1);
         const u32 mo = (u32)m * (u32)(4 * D);
-        const float qvq = rok ? qv_n : 0.0f;
+        const float qvs = rok ? qv_n * dc.scale : 0.0f;               // the kept scores' factor: query validity x 1 / (1 - rate)
         const float delta = sdel[min(q, T16 - 1)];
         const bool normal = rok && st.z == 0.0f;
         // P[q][k] = exp2(s c - m) / sum = exp2(s c - (m - log2(1 / sum))): the row's 1 / sum goes into the exponent (one multiply per
@@ -661,27 +666,32 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
                     bl[jt] = SPLIT ? trF(0, jt, 1) : bh[jt];
                 }
                 float x[8];
-                // per score: the key mask is an ADDITIVE bias in the exponent (0 / -inf: kb), the causal compare only exists on the
-                // diagonal tile, 1 / sum sits in m', 1 / sqrt(d) is applied to dQ behind the loop: fma, add, exp2 [+ compare, select],
-                // the dropout factor, fma, mul -- 11 vector instructions per score instead of 17
-                auto finish = [&](int kt, const f32x4& s, const f32x4& p, int xo) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(kb + 16 * kt + 4 * lg);
+                // per score: the key mask is an ADDITIVE bias in the exponent (0 / -inf: kb), 1 / sum sits in m', the query's validity
+                // and the dropout scale are one factor, 1 / sqrt(d) is applied to dQ behind the loop; the causal compare exists only
+                // in the code of the pair that holds the diagonal tile (the last one: a wave-uniform branch picks the body):
+                // fma, add, exp2, the keep test (add, xor-shift, multiply, compare, select), fma, mul
+                const float4 b40 = *reinterpret_cast<const float4*>(smem + (vkb + 128 * kp));
+                const float4 b41 = *reinterpret_cast<const float4*>(smem + (vkb + 128 * kp) + 64);
+                auto finish = [&](auto diag_c, int kt, const float4& b4, const f32x4& s, const f32x4& p, int xo) {
+                    constexpr bool DIAG = decltype(diag_c)::value;
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-                    const bool diag = kt == qt;                                           // (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float pn = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mrow) + bb[r]);
-                        if (diag) pn = (16 * kt + 4 * lg + r <= q) ? pn : 0.0f;           // causal
-                        float w = qvq;
-                        if (dc.on) w *= drop_factor_x(dc, xrow + (uint32_t)(16 * kt + r) * CR_PHI);
+                        if (DIAG) pn = (16 * kt + 4 * lg + r <= q) ? pn : 0.0f;                 // causal (kt == qt)
+                        const float w = (cr_mix(xrow + (uint32_t)(16 * kt + r) * CR_PHI) >= dc.thresh) ? qvs : 0.0f;
                         x[xo + r] = pn * (p[r] * w - delta);                              // dS (1 / sqrt(d): behind the loop)
                     }
                 };
-                finish(k0, s0, p0, 0);                                                    // (a tile below `lo` holds masked keys only: bias -inf)
-                if (k1 <= hi) {
-                    finish(k1, s1, p1, 4);
-                } else {                                                                  // beyond the diagonal (or absent)
+                if (k1 > hi) {                                                            // the diagonal pair, second tile beyond it (or absent)
+                    finish(std::true_type{}, k0, b40, s0, p0, 0);
                     x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
+                } else if (k1 == hi) {                                                    // the diagonal pair
+                    finish(std::false_type{}, k0, b40, s0, p0, 0);
+                    finish(std::true_type{}, k1, b41, s1, p1, 4);
+                } else {                                                                  // (a tile below `lo` holds masked keys only: bias -inf)
+                    finish(std::false_type{}, k0, b40, s0, p0, 0);
+                    finish(std::false_type{}, k1, b41, s1, p1, 4);
                 }
                 bf8 ah, al;
                 split8<SPLIT>(x, ah, al);
@@ -805,6 +815,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     float* dVg = const_cast<float*>(bd.dqkv) + 2 * MD;
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
     // ---- phase 2 staging: row statistics of every query row; Wk, Wv over W1, W2 ----
+    const DropCtx dc = drop_ctx(d.drop);
     {
         WRegs<2, SB_NT> w;
         w_issue<2, SB_NT>(w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
@@ -833,7 +844,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             sinv[t] = normal ? 1.0f : 0.0f;                      // (the tile flags read it)
             if (!normal || t >= T16) sdel[t] = 0.0f;
             suni[t] = (flag == 1.0f) ? a.invT : 0.0f;
-            sqv[t] = t < T ? qv : 0.0f;
+            sqv[t] = t < T ? qv * dc.scale : 0.0f;               // query validity x 1 / (1 - rate): the kept scores' factor
         }
     }
     __syncthreads();
@@ -854,7 +865,15 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     }
     __syncthreads();
     B1_TS(3);
-    const DropCtx dc = drop_ctx(d.drop);
+    // the tile flags as wave-uniform bit masks: the loops test scalars (a flag read from LDS inside the loop is a read, a full
+    // wait and a branch per tile)
+    unsigned live_m, uni_m;
+    {
+        const float tf = tile_flag[lane & 15];
+        const unsigned nm = (1u << a.nkt) - 1u;
+        live_m = (unsigned)__ballot(lane < 16 && tf != 0.0f) & nm;
+        uni_m = (unsigned)__ballot(lane < 16 && tf == 2.0f) & nm;
+    }
     const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
     int ftr[4];
     {
@@ -862,6 +881,10 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) ftr[jt] = 2 * (img_off<2>(4 * lg + q_, 2 * jt + (p_ >> 1)) + 4 * (p_ & 1));
     }
+    // byte offset of this lane group's four rows in the row vectors (from sdel; a query tile adds 64): an opaque value, so that
+    // the vectors' reads are (one base + tile offset) + immediates instead of one 32-bit add each
+    int vrow = L::F_OFF_BYTES + 4 * (L::SDEL + 4 * lg);
+    asm volatile("" : "+v"(vrow));
     const unsigned tpk = a.kpk[wave];
     // a tile's own K / V rows (operand layout, from memory); the NEXT tile's are requested behind the current tile's loop
     GFrag<2> kn, vn;
@@ -896,16 +919,15 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             dv[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const int ntile = a.nkt;
+        // x = idx * PHI + key of attention_weights[n, 4 lg, key]: a query tile adds 16 T PHI, a row T PHI (scalars)
+        const uint32_t xbase = (drop_base + (uint32_t)(4 * lg) * (uint32_t)T) * CR_PHI + dc.key;
+        const uint32_t xT = (uint32_t)T * CR_PHI;
         for (int qp = 0; 2 * qp < ntile; ++qp) {                         // pairs of query tiles 2 qp, 2 qp + 1
             const int l0 = 2 * qp, l1 = 2 * qp + 1;
-            const bool two = l1 < ntile;
-            auto wanted = [&](int lt) {
-                const float f = tile_flag[lt];
-                if (f == 0.0f) return false;                                     // nothing flows through dead query tiles
-                if (f == 2.0f) return true;                                      // uniform rows see every key
-                return (lt >= kt) && tile_has_key;                               // causal / padding skip
-            };
-            const bool w0 = wanted(l0), w1 = two && wanted(l1);
+            // nothing flows through dead query tiles; uniform rows see every key; else the causal / padding skip (scalar bit tests)
+            const unsigned pairbits = (live_m >> l0) & 3u, unibits = (uni_m >> l0) & 3u;
+            const bool w0 = (pairbits & 1u) && ((unibits & 1u) || (l0 >= kt && tile_has_key));
+            const bool w1 = (pairbits & 2u) && ((unibits & 2u) || (l1 >= kt && tile_has_key));
             if (!w0 && !w1) continue;
             f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
             const int po = 4096 * qp;
@@ -948,6 +970,16 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
                 BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
                 BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
             }
+            // the rows' vectors of both query tiles (m', delta, validity x dropout scale), in front of the transposed reads (LDS returns
+            // in order: they are there when the element-wise phase opens)
+            const unsigned char* vq = smem + (vrow + 128 * qp);
+            float4 m4[2], d4[2], w4[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                m4[h] = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SMX - L::SDEL));
+                d4[h] = *reinterpret_cast<const float4*>(vq + 64 * h);
+                w4[h] = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SQV - L::SDEL));
+            }
             // dOut columns for the dV product: first batch requested before the element-wise phase that hides it
             constexpr int JB = SPLIT ? 2 : 4;
             bf8 oth[JB], otl[JB];
@@ -958,29 +990,26 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             }
             float xa[8], xd[8];
             // per score: the key's validity (this lane's key: loop-invariant) and "query tile above the key tile" are an ADDITIVE bias
-            // in the exponent (0 / -inf), the causal compare only exists on the diagonal tile, 1 / sum sits in m' (smx), 1 / sqrt(d) is
-            // applied to dK behind the loop, the uniform-row term only exists in tiles that hold such a row: 12 vector instructions per
-            // score instead of 18.  (The absent second tile of an odd count reads as dead rows: m' = 1e30, everything 0.)
-            auto finish = [&](int lt, const f32x4& s, const f32x4& p, int xo) {
-                const int q4 = 16 * lt + 4 * lg;                             // this lane's 4 query rows
-                const float4 m4 = *reinterpret_cast<const float4*>(smx + q4), d4 = *reinterpret_cast<const float4*>(sdel + q4);
-                const float4 w4 = *reinterpret_cast<const float4*>(sqv + q4);
-                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-                const uint32_t x0 = (drop_base + (uint32_t)q4 * (uint32_t)T) * CR_PHI + dc.key;   // counter of attention_weights[n, q4, key]
-                const uint32_t xT = (uint32_t)T * CR_PHI;
+            // in the exponent (0 / -inf), 1 / sum sits in m' (smx), the query's validity and the dropout scale in one factor (sqv),
+            // 1 / sqrt(d) is applied to dK behind the loop; the causal compare exists only in the code of the one pair that holds
+            // the diagonal tile (DIAG: a wave-uniform branch picks the body), the uniform-row term only in tiles that hold such a
+            // row: 11 vector instructions per score.  (The absent second tile of an odd count reads as dead rows: m' = 1e30.)
+            auto finish = [&](auto diag_c, int h, int xo, const f32x4& s, const f32x4& p) {
+                constexpr bool DIAG = decltype(diag_c)::value;
+                const int lt = 2 * qp + h;
+                const float mm[4] = {m4[h].x, m4[h].y, m4[h].z, m4[h].w}, dd[4] = {d4[h].x, d4[h].y, d4[h].z, d4[h].w}, ww[4] = {w4[h].x, w4[h].y, w4[h].z, w4[h].w};
+                const uint32_t x0 = xbase + (uint32_t)lt * (16u * xT);       // counter of attention_weights[n, 16 lt + 4 lg, key]
                 const float bias = (lt < kt) ? -INFINITY : kbias;            // query tile above the key tile: causally masked as a whole
-                const bool diag = lt == kt, uni = tile_flag[lt] == 2.0f;     // (wave-uniform)
                 float pn[4], w[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pn[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mm[r]) + bias);
-                    if (diag) pn[r] = (key <= q4 + r) ? pn[r] : 0.0f;        // causal
-                    w[r] = ww[r];
-                    if (dc.on) w[r] *= drop_factor_x(dc, x0 + (uint32_t)r * xT);
+                    if (DIAG) pn[r] = (lt != kt || key <= 16 * lt + 4 * lg + r) ? pn[r] : 0.0f;        // causal
+                    w[r] = (cr_mix(x0 + (uint32_t)r * xT) >= dc.thresh) ? ww[r] : 0.0f;                // validity x keep / (1 - rate)
                     xd[xo + r] = pn[r] * (p[r] * w[r] - dd[r]);              // dS (1 / sqrt(d): behind the loop)
                 }
-                if (uni) {                                                   // rows without a valid key: 1 / T on every key < T
-                    const float4 u4 = *reinterpret_cast<const float4*>(suni + q4);
+                if ((uni_m >> lt) & 1u) {                                    // rows without a valid key: 1 / T on every key < T
+                    const float4 u4 = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SUNI - L::SDEL));
                     const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xa[xo + r] = (pn[r] + key_in_T * uu[r]) * w[r];
@@ -989,8 +1018,13 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
                     for (int r = 0; r < 4; ++r) xa[xo + r] = pn[r] * w[r];   // A after mask + dropout
                 }
             };
-            finish(l0, s0, p0, 0);
-            finish(l1, s1, p1, 4);
+            if (qp == (kt >> 1)) {
+                finish(std::true_type{}, 0, 0, s0, p0);
+                finish(std::true_type{}, 1, 4, s1, p1);
+            } else {
+                finish(std::false_type{}, 0, 0, s0, p0);
+                finish(std::false_type{}, 1, 4, s1, p1);
+            }
             bf8 ah, al, dh, dl;
             split8<SPLIT>(xa, ah, al);
             split8<SPLIT>(xd, dh, dl);

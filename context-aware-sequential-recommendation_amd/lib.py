@@ -14,6 +14,8 @@ from . import PKG_DIR
 
 # CASTREC_TIMELINE=1 selects the instrumented build (python -m castrec_amd.build --timeline); debugging tools only
 LIB_PATH = os.path.join(PKG_DIR, "libcastrec_tl.so" if os.environ.get("CASTREC_TIMELINE") == "1" else "libcastrec.so")
+if os.environ.get("CASTREC_LIB"):           # diagnostics: another build of the same sources (tools/diag_repro2.py compares builds)
+    LIB_PATH = os.path.abspath(os.environ["CASTREC_LIB"])
 if not os.path.exists(LIB_PATH):
     raise ImportError("castrec_amd: native library %s not found -- build it with "
                       "`python -m castrec_amd.build` (needs hipcc, gfx950). There is no CPU fallback." % LIB_PATH)

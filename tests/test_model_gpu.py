@@ -368,9 +368,11 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
 @pytest.mark.parametrize("model", ["cast_1", "cast_3"])
 def test_block_backward_rows_are_reproducible_at_the_headline_length(E, model):
     """Every activation-gradient buffer of a step (d_o, dQ / dK / dV, both partials of every block input, what the consumers
-    make of them) and the dense slabs hold the same bits on ten runs of the same step at T = 200: the rows that cross from one
-    wave to another inside cr_stack_block_bwd (through memory, behind workgroup barriers) included.  (A variant of the kernel
-    that requested the next tile's inputs unconditionally differed in single columns of dx in about one run in four.)"""
+    make of them) and the dense slabs hold the same bits on 400 replays of the same step at T = 200.  Round 3 lost this twice
+    (1 replay in 37 and 1 in 350 on this round's boxes, profiles/r04_flake/README.md: with the SLP vectoriser on, the last
+    statement of the LayerNorm backward becomes in-place v_pk_fma_f32 chains, and one of them goes missing in one register of
+    lanes 48..63); the library is built without SLP vectorisation, and 400 replays see a 1-in-350 defect with probability 0.68
+    per model (ten replays, the round-3 form, saw a 1-in-4 one only)."""
     rs = np.random.RandomState(250)
     B, T, D, itemnum = 3, 200, 50, 300
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.1, max_bins=200, num_context_blocks=1, lr=1e-3, seed=11)
@@ -379,19 +381,20 @@ def test_block_backward_rows_are_reproducible_at_the_headline_length(E, model):
     eng.P.add_(0.05 * torch.randn(eng.P.numel(), generator=torch.Generator().manual_seed(5)).to(eng.P.device))
     batch = make_batch(rs, B, T, itemnum, 200)
     ref = None
-    for _ in range(10):
+    for it in range(400):
         eng.set_batch(*batch)
         eng.set_step(1)
         eng.Gflat.zero_()
         eng.launch_step(apply=False)
         torch.cuda.synchronize()
-        cur = {k: v.clone() for k, v in eng._bufs.items() if v.dtype == torch.float32}
-        cur["Gs"] = eng.Gs.clone()
+        cur = {k: v for k, v in eng._bufs.items() if v.dtype == torch.float32}
+        cur["Gs"] = eng.Gs
         if ref is None:
-            ref = cur
+            ref = {k: v.clone() for k, v in cur.items()}
+            assert not [k for k, v in ref.items() if torch.isnan(v).any()]
         else:
-            bad = [k for k in cur if not torch.equal(cur[k], ref[k]) and not torch.isnan(cur[k]).any()]
-            assert not bad, bad
+            bad = [k for k in cur if not torch.equal(cur[k], ref[k])]
+            assert not bad, (it, bad)
 
 
 @pytest.mark.parametrize("B,n_slabs", [(6, 16), (9, 4)])
