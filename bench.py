@@ -16,6 +16,7 @@ HIP graph; the id batches are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
 (the oracle's torch-CPU restatement of the same step on the host cores; rank 0, N=1 only)."""
 import argparse
+import glob
 import json
 import os
 import socket
@@ -396,6 +397,20 @@ def gather_block(reps=24):
                note="MI355X_MICROARCH.md: float4 copy ceiling 6.29 TB/s (79 % of the 8 TB/s spec); random whole-row gathers into "
                     "registers 5.5-5.8 TB/s.  embed_fwd (the training-path gather) writes as many bytes as it reads: read_write_frac is "
                     "its number to hold against the roof; the read-only form is the one to hold against the >= 70 % READ target")
+    # the same two kernels under rocprofv3 (committed summary of tools/gather_pmc.py, a fresh row set per launch as here): profiled
+    # passes clock lower (MI355X_MICROARCH.md, DVFS item 2), so these fractions are the conservative ones to quote
+    prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gather_pmc_summary.json")))
+    if prof:
+        try:
+            pj = json.load(open(prof[-1]))
+            for key, kern, nbytes in (("read_only", "k_test_logits", rd_b), ("embed_fwd", "k_embed_fwd", rd_a + wr_a)):
+                ent = [v for k, v in pj.items() if k.startswith(kern)]
+                if ent:
+                    us = ent[0]["avg_ns"] / 1e3
+                    res[key]["rocprof"] = dict(source=os.path.basename(prof[-1]), us=round(us, 2), frac=round(nbytes / us / 1e3 / 8000.0, 4),
+                                               hbm_traffic_bytes=ent[0].get("hbm_traffic_bytes"), algorithmic_bytes=nbytes)
+        except Exception as e:
+            res["rocprof_error"] = repr(e)[:120]
     del table, out
     torch.cuda.empty_cache()
     return res
@@ -620,7 +635,7 @@ def main():
                            "num_heads=%d dropout=%.2f, batch %d/GPU (global %d), fwd+bwd+%s TF-Adam per step"
                            % (args.corpus, corpus.usernum, corpus.itemnum, args.model, T, args.hidden_units, args.num_blocks, args.num_heads,
                               args.dropout_rate, B, Bg, "row-sparse (lazy)" if args.lazy_adam else "dense"),
-               "parallelism": "dp%d" % world, "hip_graph": use_graph, "launches_per_step": eng.n_launches(),
+               "parallelism": "dp%d" % world, "hip_graph": use_graph, "launches_per_step": eng.n_kernel_launches(), "abi_calls_per_step": eng.n_launches(),
                "attn_precision": prec, "final_loss": round(loss, 5), "final_auc": round(auc, 5)}
         if dist is not None:
             cfg["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),

@@ -1347,4 +1347,22 @@ class Engine:
         return {k: self.layout.view(flat, k).clone() for k in self.layout.logical_names()}
 
     def n_launches(self):
+        """C-ABI calls per step (an entry may launch more than one kernel: n_kernel_launches)."""
         return len(self.fwd) + len(self.bwd) + (1 if self.training else 0) + (1 if self.training and self._l2 else 0)
+
+    def n_kernel_launches(self):
+        """Kernel launches per step, as rocprofv3 counts them: cr_stack_fwd launches once per block when a sequence gets two
+        workgroups (B <= 160, more than one tile: cr_stack.hip, g_stack_pair_max_b), cr_stack_block_bwd once per min(B, n_slabs)
+        sequences; every other entry of the fused path is one kernel."""
+        n = 0
+        pair_max = int(os.environ.get("CASTREC_STACK_PAIR_MAX_B", 160))
+        for name, _, args in self.fwd + self.bwd:
+            if name == "cr_stack_fwd":
+                sd = args[0]._obj
+                n += sd.n_blocks if (self.B <= pair_max and self.T > 16) else 1
+            elif name == "cr_stack_block_bwd":
+                per = min(self.B, self.n_slabs)
+                n += -(-self.B // per)
+            else:
+                n += 1
+        return n + (1 if self.training else 0) + (1 if self.training and self._l2 else 0)

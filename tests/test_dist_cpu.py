@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the data-parallel wrapper (castrec_amd.dist) on CPU.
+"""world_size-2 / 4 / 8 gloo tests of the data-parallel wrapper (castrec_amd.dist) on CPU.
 
 The replica is oracle-backed (the HIP engine needs a GPU): it produces UN-normalised gradients of its
 row shard in the flat bucket layout the engine uses, so the test covers row sharding, the single flat
@@ -96,18 +96,21 @@ def test_shard_rows():
         shard_rows(10, 0, 4)
 
 
-@pytest.mark.timeout(120)
-@pytest.mark.parametrize("itemnum,sparse", [(ITEMS, False), (ITEMS, True), (3000, True)])
-def test_two_rank_step_equals_single_process(itemnum, sparse):
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,itemnum,sparse", [(2, ITEMS, False), (2, ITEMS, True), (2, 3000, True),
+                                                  (4, ITEMS, False), (4, 3000, True), (8, ITEMS, False), (8, ITEMS, True), (8, 3000, True)])
+def test_n_rank_step_equals_single_process(world, itemnum, sparse):
     """dense: one flat all-reduce.  sparse: all-gather of de-duplicated (row id, gradient row) pairs for the item table
-    (hot rows shared by both ranks at 20 items; V = 3001 >> 240 touched rows: the C5 regime) + all-reduce of the rest."""
+    (hot rows shared by the ranks at 20 items; V = 3001 >> 240 touched rows: the C5 regime) + all-reduce of the rest.
+    World 2, 4 and 8 (one batch row per rank at 8): the rank-ordered sums of the sparse exchange and the shard arithmetic
+    at every rank count the node has."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, itemnum, sparse)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, itemnum, sparse)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=100) for _ in procs])
+    res = sorted([q.get(timeout=200) for _ in procs])
     for p in procs:
         p.join(timeout=30)
     ref = OracleReplica(seed=0, itemnum=itemnum)
@@ -115,10 +118,13 @@ def test_two_rank_step_equals_single_process(itemnum, sparse):
     batch = make_batch(itemnum=itemnum)
     for _ in range(2):
         one.step(batch)
+    # (more ranks = another association of the fp64 shard sums; the key bias' gradient is identically 0 and Adam turns its
+    #  1e-17 rounding residue into moves of up to ~1e-11 -- DESIGN section 2, "known ill-conditioned quantity")
     for rank, vec, loss in res:
-        np.testing.assert_allclose(vec, ref.param_vector().numpy(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vec, ref.param_vector().numpy(), rtol=0, atol=1e-12 if world == 2 else 1e-10)
         assert loss == pytest.approx(ref.loss, rel=1e-12)
-    assert np.array_equal(res[0][1], res[1][1])                   # replicas bit-identical (fixed summation order)
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1])                    # replicas bit-identical (fixed summation order)
 
 
 def test_exchange_picks_the_cheaper_form():

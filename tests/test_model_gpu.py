@@ -419,17 +419,17 @@ def test_block_backward_is_bitwise_reproducible(E, B, n_slabs):
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
 
 
-def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False):
+def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False, n_slabs=5, dropout=0.1):
     """kink_free: the feed-forward pre-activations are pushed away from the ReLU kink (small W1, biases of +-1 alternating by
     unit), the oracle runs with ITS OWN gates (no hand-over), and the test first proves that the engine's gates are the
     same everywhere: gradient parity of the split-precision kernels with nothing taken from the engine but the dropout masks."""
     tol = TOL[prec]
     rs = np.random.RandomState(D + T)
-    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=dropout, max_bins=max_bins,
                  num_context_blocks=1, lr=1e-3, seed=11)
-    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=0.1, max_bins=max_bins,
+    ohp = fm.Hyper(maxlen=T, hidden_units=D, num_blocks=L, num_heads=H, dropout_rate=dropout, max_bins=max_bins,
                    num_context_blocks=1, lr=1e-3)
-    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=5, attn_precision=prec)
+    eng = E.Engine(model, 9, itemnum, hp, B, training=True, n_slabs=n_slabs, attn_precision=prec)      # n_slabs None: the engine's own choice
     assert eng.fused == (D <= 64)
     P = fm.init_params(model, 9, itemnum, ohp, seed=8)
     P = {k: v + 0.05 * torch.tensor(rs.standard_normal(tuple(v.shape))) for k, v in P.items()}
@@ -452,7 +452,7 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9,
     eng.set_batch(seq, pos, neg, time, hours, days)
     eng.launch_step(apply=False)
     torch.cuda.synchronize()
-    drop = oracle_drop(E, 11, 1, 0.1, B, T, H)
+    drop = oracle_drop(E, 11, 1, dropout, B, T, H)
     # split-precision attention perturbs activations by ~1e-5: the oracle takes the engine's ReLU gates like it takes its
     # dropout masks, so that units within 1e-5 of the kink do not flip on one side only (see fpmodel.RELU_GATES)
     run = lambda: fm.loss_and_grads(model, P, ohp, fm.to_batch(seq, pos, neg, time, hours, days), drop)
@@ -477,6 +477,15 @@ def test_config_c1_exact_shape(E):
     """BASELINE configs[0]: ml-1m SASRec maxlen=50 hidden_units=50 num_blocks=2 num_heads=1 batch=128."""
     _other_shapes(E, "sasrec", 50, 1, 50, 2, B=128, prec="f32", itemnum=3416)
     _other_shapes(E, "sasrec", 50, 1, 50, 2, B=128, prec="bf16x3", itemnum=3416)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+def test_config_c2_exact_shape(E, prec):
+    """BASELINE configs[1], the bench workload itself: ml-1m CAST(1) maxlen=200 hidden_units=50 num_blocks=2 num_heads=1, batch 128,
+    3 416 items, 200 time bins, dropout 0.2, the engine's own slab count (128 sequences on 256 workgroups: one launch per block,
+    the PAIR mode of the forward, one slab per sequence pair in the backward) -- loss, every gradient and the forward rows against
+    the fp64 oracle (models/cast_1.py:29-91)."""
+    _other_shapes(E, "cast_1", 50, 1, 200, 2, B=128, prec=prec, itemnum=3416, max_bins=200, n_slabs=None, dropout=0.2)
 
 
 def test_config_c3_long_tail_vocabulary(E):
