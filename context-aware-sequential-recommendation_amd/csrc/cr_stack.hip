@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     constexpr int WST = SPLIT ? 2 * ST_WIMG : ST_WIMG;   // elements per weight slot
     float* vec = reinterpret_cast<float*>(Wi + 3 * WST);  // [ST_NVEC][64]
     float* kb = vec + ST_NVEC * 64;                      // [T16] additive key bias
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x;
     const int D = DS > 0 ? DS : a.blk[0].bd.D, T = a.blk[0].ad.T;
     const int base_row = n * T;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = (padrow ? 0.0f : x[ct][r]) * e.scale + pv[ct][r] + av[ct][r];
-                        if (dce.on) v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);
+                        v *= drop_factor_x(dce, eb + (uint32_t)(16 * ct + r) * CR_PHI);       // (rate 0: threshold 0, factor 1.0 -- no branch per element)
                         x[ct][r] = dead ? 0.0f : v;
                     }
                 // the wave writes x for the tile it takes through phase B / C (it re-reads those rows there)
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = fmaxf(acc[ct][r] + bias[ct][r], 0.0f);
-                    if (d1.on) v *= drop_factor_x(d1, e1 + d1.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:303-304
+                    v *= drop_factor_x(d1, e1 + d1.key + (uint32_t)(16 * ct + r) * CR_PHI);                // modules.py:303-304
                     acc[ct][r] = v;
                 }
             r_store(d.hid, mo, acc, rok, dcx);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[ct][r] + bias[ct][r];
-                    if (d2.on) v *= drop_factor_x(d2, e1 + d2.key + (uint32_t)(16 * ct + r) * CR_PHI);     // modules.py:309-310
+                    v *= drop_factor_x(d2, e1 + d2.key + (uint32_t)(16 * ct + r) * CR_PHI);                // modules.py:309-310
                     acc[ct][r] = (v + fin[ct][r]) * msk;                                                  // modules.py:313, sasrec.py:83
                 }
             r_store(d.y, mo, acc, rok, dcx);

@@ -62,6 +62,15 @@ struct B1Args {
     unsigned long long* ts;
 };
 
+// The kernel's argument block read again through an opaque pointer: what a late phase needs (output pointers, flags) is fetched from
+// the scalar cache where it is used instead of being held in scalar registers across the loops in front of it -- held, the
+// pointers were copied to vector registers and spilled to scratch (a reload + full vector-memory wait in front of the row chain)
+__device__ __forceinline__ const B1Args& b1_args_again() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const B1Args*>((const void*)p);
+}
+
 #ifdef CR_TIMELINE
 #define B1_TS(slot)                                                                                          \
     do {                                                                                                     \
@@ -113,16 +122,20 @@ __device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, 
 }
 // LayerNorm column sums: per-lane partials -> sums over the wave's 16 rows -> the wave's LDS slot (+=: a wave folds once per
 // tile); b1_ln_flush adds the eight slots in wave order
+// SET: the wave's only fold -- the slot is written, not added to (no zeroing pass, no barrier in front)
+template <bool SET = false>
 __device__ __forceinline__ void b1_ln_fold(float* part, const f32x4 (&ag)[4], const f32x4 (&ab)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float sg = cr_row16_sum(ag[ct][r]), sb = cr_row16_sum(ab[ct][r]);
             if (li == 0) {
-                part[wave * 64 + 16 * ct + 4 * lg + r] += sg;
-                part[(SB_WAVES + wave) * 64 + 16 * ct + 4 * lg + r] += sb;
+                float* pg = part + wave * 64 + 16 * ct + 4 * lg + r;
+                float* pb = part + (SB_WAVES + wave) * 64 + 16 * ct + 4 * lg + r;
+                *pg = SET ? sg : *pg + sg;
+                *pb = SET ? sb : *pb + sb;
             }
         }
 }
@@ -153,7 +166,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     constexpr int WST = L::WST, IST = L::IST;
     const int D = DS > 0 ? DS : d.D, T = a.T;
     const DCtx dcx = d_ctx(D);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DropCtx d2 = drop_ctx(d.drop_ffn2);
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
 #ifdef CR_TIMELINE
@@ -373,7 +386,7 @@ __device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4]
 __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* buf, int n, int D) {
     if (!a.sc.table_grad && !a.sc.pos_grad) return;
     const cr_embed_desc& e = a.sc.f;
-    const int wave = threadIdx.x >> 6, col = threadIdx.x & 63, T = a.T;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = threadIdx.x & 63, T = a.T;
     for (int t0 = 16 * wave; t0 < T; t0 += 16 * SB_WAVES) {
         const int nr = min(16, T - t0);
         const int m0 = n * T + t0;
@@ -400,7 +413,7 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
 __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* lst, const float* buf, int n, int D, bool add) {
     const cr_embed_desc& e = a.sc.f;
     float* tab = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, T = a.T;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T;
     const int nt = e.V * D;
     // ids of all rows of the sequence (T <= 224: four per lane), requested before the image is zeroed
     int id4[4];
@@ -525,7 +538,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
     const DCtx dcx = d_ctx(D);
     const int base_row = n * T, M = bk.M;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
     const size_t MD = (size_t)M * D;
     float* dQg = const_cast<float*>(bd.dqkv);
     B1_TS(9);
@@ -716,9 +729,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         for (int jt = 0; jt < 4; ++jt) dq[jt] *= a.isd;                                   // dS / sqrt(d), once per output element
         if (ti == 0) B1_TS(6);
         // ---- the tile goes on through registers: dq_in = dQ Wq^T + d_o, LN1 backward -> this side's partial of dx ----
+        const B1Args& ar = b1_args_again();                               // (this chain's pointers: not carried across the loop)
         RRaw rdx;
-        if (bd.dx_accumulate) r_issue(rdx, bd.dx, mo, dcx, rok);
-        r_store(dQg, mo, dq, rok, dcx);                                   // for the weight-gradient images of phase 3
+        if (ar.bd.dx_accumulate) r_issue(rdx, ar.bd.dx, mo, dcx, rok);
+        r_store(const_cast<float*>(ar.bd.dqkv), mo, dq, rok, dcx);        // dQ, for the weight-gradient images of phase 3
         f32x4 dqin[4];
         {
             bf8 gh[2], gl[2];
@@ -737,17 +751,17 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));
         r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
         b1_ln_fold(part, ag, ab);
-        if (bd.dx_accumulate) {
+        if (ar.bd.dx_accumulate) {
             f32x4 old[4];
             r_finish(old, rdx, dcx);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) dxl[ct] += old[ct];
         }
-        if (a.scatter) {
-            b1_scatter_prep(a, dxl, m, rok, D);
-            r_store(a.sbuf, mo, dxl, rok, dcx);
+        if (ar.scatter) {
+            b1_scatter_prep(ar, dxl, m, rok, D);
+            r_store(ar.sbuf, mo, dxl, rok, dcx);
         } else {
-            r_store(bd.dx, mo, dxl, rok, dcx);
+            r_store(ar.bd.dx, mo, dxl, rok, dcx);
         }
     }
     B1_TS(4);
@@ -803,13 +817,13 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     __bf16* Im = reinterpret_cast<__bf16*>(smem);
     __bf16* Wi = Im + L::W_OFF;                           // slot 0: Wk, slot 1: Wv (permuted)
     float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
-    float* sdel = fl + L::SDEL; float* smx = fl + L::SMX; float* sinv = fl + L::SINV; float* suni = fl + L::SUNI; float* sqv = fl + L::SQV;
+    float* sdel = fl + L::SDEL; float* smx = fl + L::SMX; float* suni = fl + L::SUNI; float* sqv = fl + L::SQV;
     float* tile_flag = fl + L::TFLAG;
     constexpr int WST = L::WST, IST = L::IST;
     const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
     const DCtx dcx = d_ctx(D);
     const int base_row = n * T, M = bk.M;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
     const size_t MD = (size_t)M * D;
     float* dKg = const_cast<float*>(bd.dqkv) + MD;
     float* dVg = const_cast<float*>(bd.dqkv) + 2 * MD;
@@ -823,38 +837,33 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + tc) * 4);
         const float qv = d.q_valid[base_row + tc];
         {
-            // dgamma2 dbeta2 (+ the final LayerNorm's sums) of this side's phase 1: slots zeroed, folded, flushed
+            // dgamma2 dbeta2 (+ the final LayerNorm's sums) of this side's phase 1: every wave WRITES its slots (its accumulators cover all
+            // its tiles; a wave without a tile writes zeros), one barrier, flush
             float* part = fl + L::PART; float* partF = fl + L::PARTF;
-            for (int i = threadIdx.x; i < 4 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;       // part and partF are adjacent
-            __syncthreads();                              // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete
-            b1_ln_fold(part, A.ag, A.ab);
-            if (a.has_ln) b1_ln_fold(partF, A.agF, A.abF);
-            __syncthreads();
+            b1_ln_fold<true>(part, A.ag, A.ab);
+            if (a.has_ln) b1_ln_fold<true>(partF, A.agF, A.abF);
+            __syncthreads();                              // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete, the folds are visible
             const size_t so = (size_t)blockIdx.x * bd.slab_stride;
             b1_ln_flush(part, bd.g_ln2_g + so, bd.g_ln2_b + so, D, add);
             if (a.has_ln) b1_ln_flush(partF, a.ln.dgamma + so, a.ln.dbeta + so, D, add);
         }
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
-        // stored so that the inner loop is branch-free: A[q][key] = valid * exp2(s c - smx) * sinv + (key < T ? suni : 0);
-        // normal row: suni = 0; uniform row: sinv = 0, suni = 1/T; dead row: both 0 (smx = 1e30 wherever sinv = 0)
+        // stored so that the inner loop is branch-free: A[q][key] = valid * exp2(s c - smx) + (key < T ? suni : 0);
+        // normal row: suni = 0; uniform row: suni = 1/T; dead row: neither (smx = 1e30 wherever the row is not normal)
+        const float flag = t < T ? st.z : 2.0f;
+        const bool normal = flag == 0.0f;
         if (t < T16 + ((a.nkt & 1) ? 16 : 0)) {             // (an odd tile count: the absent tile of the last pair reads as dead rows)
-            const float flag = t < T ? st.z : 2.0f;
-            const bool normal = flag == 0.0f;
             smx[t] = normal ? st.x - __log2f(st.y) : 1e30f;      // 1 / sum inside the exponent: P = exp2(s c - m')
-            sinv[t] = normal ? 1.0f : 0.0f;                      // (the tile flags read it)
             if (!normal || t >= T16) sdel[t] = 0.0f;
             suni[t] = (flag == 1.0f) ? a.invT : 0.0f;
             sqv[t] = t < T ? qv * dc.scale : 0.0f;               // query validity x 1 / (1 - rate): the kept scores' factor
         }
-    }
-    __syncthreads();
-    {
-        // per query tile: 0 nothing flows, 1 normal rows only, 2 has a uniform row (one lane per row, folded by ballots)
-        const int t = threadIdx.x;
+        // per query tile: 0 nothing flows, 1 normal rows only, 2 has a uniform row -- from the row statistics this thread holds (one
+        // lane per row, folded by ballots: no second pass over the vectors, no barrier of its own)
         if ((t & ~63) < T16) {
             const bool live = t < T16;
-            const unsigned long long bn = __ballot(live && sinv[live ? t : 0] != 0.0f);
-            const unsigned long long bu = __ballot(live && suni[live ? t : 0] != 0.0f);
+            const unsigned long long bn = __ballot(live && normal);
+            const unsigned long long bu = __ballot(live && flag == 1.0f);
             if ((t & 15) == 0 && live) {
                 const int sh = t & 48;
                 const bool anyu = ((bu >> sh) & 0xFFFFull) != 0, anyn = ((bn >> sh) & 0xFFFFull) != 0;
@@ -1061,8 +1070,9 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         if (ti == 0) B1_TS(6);
         if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));   // the next tile's K / V rows, under this tile's row chain
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
-        r_store(dKg, mo, dk, rok, dcx);                                   // for the weight-gradient images of phase 3
-        r_store(dVg, mo, dv, rok, dcx);
+        const B1Args& ar = b1_args_again();                               // (this chain's pointers: not carried across the loop)
+        r_store(const_cast<float*>(ar.bd.dqkv) + MD, mo, dk, rok, dcx);   // dK, dV: for the weight-gradient images of phase 3
+        r_store(const_cast<float*>(ar.bd.dqkv) + 2 * MD, mo, dv, rok, dcx);
         f32x4 dxp[4];
         {
             bf8 gh[2], gl[2];
@@ -1071,11 +1081,11 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             r_split<SPLIT>(dv, gh, gl);
             r_gemm_t<SPLIT, true>(dxp, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
         }
-        if (a.scatter) {
-            b1_scatter_prep(a, dxp, m, rok, D);
-            r_store(a.sbuf2, mo, dxp, rok, dcx);
+        if (ar.scatter) {
+            b1_scatter_prep(ar, dxp, m, rok, D);
+            r_store(ar.sbuf2, mo, dxp, rok, dcx);
         } else {
-            r_store(a.dx2, mo, dxp, rok, dcx);
+            r_store(ar.dx2, mo, dxp, rok, dcx);
         }
     }
     B1_TS(4);
@@ -1088,17 +1098,22 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; nob[j] = awk[j]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
     const int R = a.nkt > SB_TPR ? 2 : 1;
+    // a round's rows (x, dK, dV of the wave's tile) are requested one round ahead: the second round's fly under the first round's products
+    RRaw r1, r2, r3;
+    auto issue3 = [&](int rd) {
+        if (rd < R && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+            const int qq = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
+            const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
+            r_issue(r1, bk.x, mo, dcx);
+            r_issue(r2, dKg, mo, dcx, qq < T);
+            r_issue(r3, dVg, mo, dcx, qq < T);
+        }
+    };
+    issue3(0);
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
         const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
         if (wave < ntr) {
-            const int qq = 16 * (rd * SB_TPR + wave) + li;
-            const bool rok = qq < T;
-            const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
-            RRaw r1, r2, r3;
-            r_issue(r1, bk.x, mo, dcx);
-            r_issue(r2, dKg, mo, dcx, rok);
-            r_issue(r3, dVg, mo, dcx, rok);
             f32x4 x[4], g[4];
             r_finish(x, r1, dcx);
             plant_one(x, D);
@@ -1108,6 +1123,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             r_finish(g, r3, dcx);
             img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, g);
         }
+        issue3(rd + 1);
         __syncthreads();
         if (rd == 0) B1_TS(16);
         wgrad_accum<SPLIT, false>(awk, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
