@@ -512,11 +512,11 @@ def main():
             dp = D_.DataParallel(rep, rank, world, sparse={"auto": None, "on": True, "off": False}[args.sparse_exchange],
                                  force_collectives=force_dist)
             if use_graph:
-                # one HIP graph for the whole step INCLUDING the collectives: measured with one rank (CASTREC_FORCE_DIST=1: +0.5 % over
-                # the plain step, against +9.7 % for three graphs and eager collectives); with more ranks it is opt-in
-                # (CASTREC_DP_ONE_GRAPH=1) until a multi-GPU box has replayed captured RCCL collectives
-                one = os.environ.get("CASTREC_DP_ONE_GRAPH")
-                whole = dp.capture_step() if (one == "1" or (one is None and world == 1)) else False
+                # one HIP graph for the whole step INCLUDING the collectives (one rank, CASTREC_FORCE_DIST=1: +3.3 % over the plain step
+                # against +12.8 % for three graphs and eager collectives): the default at every rank count since round 4 -- with more
+                # than one rank the capture is followed by one replayed step whose result must leave the replicas identical
+                # (dist.DataParallel._replayed_step_agrees), else the three-graph form runs; CASTREC_DP_ONE_GRAPH=0 forces that form
+                whole = dp.capture_step() if os.environ.get("CASTREC_DP_ONE_GRAPH") != "0" else False
                 eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
         if dist is None and use_graph:
             eng.ids_all.copy_(staged[0])

@@ -50,8 +50,11 @@ __device__ __forceinline__ void r_issue(RRaw& w, const float* base, u32 rowb, co
     }
     w.p[0] = w.p[1] = w.p[2] = 0.0f;
     if (dc.np) {                                          // wave-uniform
-        if (rok && lgb < dc.rem && lgb + 4 > dc.rem) {
-            const float* q = reinterpret_cast<const float*>(b + (ob + 64u * (u32)dc.nfull));
+        // the crossing piece (columns 16 nfull + (rem & ~3) ..: np elements) is read by EVERY lane of the row, from an address that
+        // does not depend on the lane group -- inside the row, same cache line -- and r_finish keeps it in the one lane group that owns
+        // it: no lane predicate, i.e. no exec-mask branch around the load (seven per tile in the block backward's chains)
+        if (rok) {
+            const float* q = reinterpret_cast<const float*>(b + (rowb + 64u * (u32)dc.nfull + 4u * (u32)(dc.rem & ~3)));
             w.p[0] = q[0];
             if (dc.np > 1) w.p[1] = q[1];
             if (dc.np > 2) w.p[2] = q[2];

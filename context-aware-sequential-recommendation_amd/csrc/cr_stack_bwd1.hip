@@ -1296,6 +1296,14 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     const int nwg = B < bd->n_slabs ? B : bd->n_slabs;
     const bool split = precision == CR_PREC_BF16X3;
     hipStream_t s = cr_stream(stream);
-    if (d->D == 50) return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
-    return split ? launch_b1<true, 0>(a, nwg, s) : launch_b1<false, 0>(a, nwg, s);
+    // the hidden size as a compile-time constant where it is a common one (column-tile predicates fold: 240 .. 255 registers, no
+    // scratch); any other size runs the generic instantiation (live predicates: it spills -- see DESIGN.md section 4)
+    switch (d->D) {
+    case 50: return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
+    case 32: return split ? launch_b1<true, 32>(a, nwg, s) : launch_b1<false, 32>(a, nwg, s);
+    case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);
+    case 48: return split ? launch_b1<true, 48>(a, nwg, s) : launch_b1<false, 48>(a, nwg, s);
+    case 16: return split ? launch_b1<true, 16>(a, nwg, s) : launch_b1<false, 16>(a, nwg, s);
+    default: return split ? launch_b1<true, 0>(a, nwg, s) : launch_b1<false, 0>(a, nwg, s);
+    }
 }

@@ -193,22 +193,63 @@ class DataParallel:
                 w.wait()
         rep.phase(2, eager)
 
-    def capture_step(self):
+    def capture_step(self, validate=True):
         """Tries to capture the WHOLE step -- the three phases and the collectives between them -- into one HIP graph (the
         collectives of torch.distributed's RCCL backend are stream-ordered and capturable; the sparse exchange's tag is a device
         word).  One graph launch per step instead of three plus the host side of two collectives.  Returns False (and keeps the
-        three-graph form) when the capture is refused."""
+        three-graph form) when the capture is refused -- or, with more than one rank and `validate`, when one replayed step
+        leaves the replicas apart (_replayed_step_agrees)."""
         rep = self.replica
         if not getattr(rep, "has_phases", False) or not hasattr(rep, "capture"):
             return False
+        captured = True
         try:
             self.step_phases(eager=True)                 # every lazy initialisation (communicator, RowExchange buffers) happens here
             torch.cuda.synchronize()
             self._step_graph = rep.capture(lambda: self.step_phases(eager=True))
-            return True
         except Exception:
             self._step_graph = None
+            captured = False
+        if self.world > 1:
+            # one verdict for all ranks: a rank alone on the other form would leave the rest waiting in a collective
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if captured else 0.0], device=self.replica.param_vector().device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            captured = bool(flag.item() > 0.5)
+        if not captured:
+            self._step_graph = None
             return False
+        if self.world > 1 and validate and not self._replayed_step_agrees():
+            self._step_graph = None                      # captured collectives that do not replay as they ran: the three-graph form
+            return False
+        return True
+
+    def _replayed_step_agrees(self):
+        """One REPLAYED step of the whole-step graph on every rank, then the replicas' parameter vectors compared over the ranks
+        (sum and sum of squares, finite and equal everywhere): a captured collective that did nothing, or reduced stale buffers,
+        leaves the replicas apart after one Adam step on different shards.  The parameters are put back afterwards (broadcast of
+        rank 0's) whatever the outcome, so the caller's state is one and the same on every rank."""
+        import torch.distributed as dist
+        p = self.replica.param_vector()
+        before = p.clone()
+        ok = True
+        try:
+            self._step_graph.launch() if hasattr(self._step_graph, "launch") else self._step_graph.replay()
+            if p.is_cuda:
+                torch.cuda.synchronize()
+            chk = torch.stack([p.double().sum(), (p.double() ** 2).sum()])
+            got = [torch.empty_like(chk) for _ in range(self.world)]
+            dist.all_gather(got, chk, group=self.pg)
+            ok = all(bool(torch.isfinite(g).all()) and bool(torch.equal(g, got[0])) for g in got)
+            moved = bool((p != before).any())
+            ok = ok and moved
+        except Exception:
+            ok = False
+        p.copy_(before)
+        dist.broadcast(p, 0, group=self.pg)
+        flag = torch.tensor([1.0 if ok else 0.0], device=p.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)      # one verdict for all ranks (a rank alone on the other form would hang the rest)
+        return bool(flag.item() > 0.5)
 
     def exchange(self, bucket):
         """Sums `bucket` ([item table grads | small part]) over the ranks, in place."""

@@ -67,10 +67,10 @@ class _Model(object):
                 self._dp = D_.DataParallel(rep, rank, world, pg, sparse=sparse)
                 if bounce:
                     rep.adopt_params()
-                if self._graph and not bounce and os.environ.get("CASTREC_DP_ONE_GRAPH") == "1":
+                if self._graph and not bounce and os.environ.get("CASTREC_DP_ONE_GRAPH") != "0":
                     p0 = self._train.P.clone()                              # (the capture rehearses one eager step: undo its update)
-                    self._dp.capture_step()                                 # opt-in: the whole step incl. the collectives as one HIP graph
-                    self._train.P.copy_(p0)
+                    self._dp.capture_step()                                 # the whole step incl. the collectives as one HIP graph; validated by
+                    self._train.P.copy_(p0)                                 # one replayed step, else the three-graph form (dist.capture_step)
                 if self._graph:
                     self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
                 if self._pending_opt is not None:

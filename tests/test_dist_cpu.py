@@ -127,6 +127,58 @@ def test_n_rank_step_equals_single_process(world, itemnum, sparse):
         assert np.array_equal(res[0][1], r[1])                    # replicas bit-identical (fixed summation order)
 
 
+class _StubReplica:
+    def __init__(self):
+        self.vec = torch.zeros(16, dtype=torch.float64)
+
+    def param_vector(self):
+        return self.vec
+
+
+class _StubGraph:
+    """Stands for the captured whole-step graph: `reduces` = its collective really runs at replay."""
+    def __init__(self, rep, rank, reduces):
+        self.rep, self.rank, self.reduces = rep, rank, reduces
+
+    def launch(self):
+        g = torch.full((16,), float(self.rank + 1), dtype=torch.float64)
+        if self.reduces:
+            dist.all_reduce(g)
+        self.rep.vec -= 0.1 * g
+
+
+def _validate_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for reduces in (True, False):
+        rep = _StubReplica()
+        dp = DataParallel(rep, rank, world)
+        dp._step_graph = _StubGraph(rep, rank, reduces)
+        ok = dp._replayed_step_agrees()
+        out.append((ok, float(rep.vec.abs().max())))          # the parameters are put back either way
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_whole_step_graph_is_validated_by_one_replayed_step():
+    """More than one rank: a captured step whose collective does not run at replay leaves the replicas apart after one update --
+    every rank gets the same verdict (no rank alone on the other form), the parameters are restored."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_validate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in procs])
+    for p in procs:
+        p.join(timeout=30)
+    for rank, out in res:
+        assert out[0] == (True, 0.0), (rank, out)
+        assert out[1] == (False, 0.0), (rank, out)
+
+
 def test_exchange_picks_the_cheaper_form():
     from castrec_amd.dist import dense_allreduce_bytes, sparse_exchange_bytes
     # C3 (Beauty, V = 57 290, D = 64, B 128 x T 50 per rank, 8 ranks): dense 25.7 MB < sparse 34.9 MB
