@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             vec_issue<NT>(vv, dn, a, D);
             issue_x(dn.x, max(tile_a(0), 0), 0, false);
         }
-        __syncthreads();                                  // B3: images, weights and vectors are rewritten by the next block
+        if (!last) __syncthreads();                       // B3: images, weights and vectors are rewritten by the next block
     }
     SK_TS(63);
 }

@@ -765,31 +765,40 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(4);
+    // phase 3's rows: wave w images tiles w and w + 8.  Their q_in rows (the forward's: nothing here writes them) are requested in
+    // front of the drain, their dQ rows right behind the barrier, all before the first image is built: one exposed round trip
+    RRaw rq0, rq1, rg0, rg1;
+    const int tt0 = wave, tt1 = wave + SB_WAVES;
+    const u32 mo0 = (u32)(base_row + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), mo1 = (u32)(base_row + min(16 * tt1 + li, T - 1)) * (u32)(4 * D);
+    if (tt0 < a.nkt) r_issue(rq0, bk.q_in, mo0, dcx);
+    if (tt1 < a.nkt) r_issue(rq1, bk.q_in, mo1, dcx);
     B1_DRAIN();
     __syncthreads();                                      // every pass is done: the K / V images are dead, dQ rows are visible
     B1_TS(7);
+    if (tt0 < a.nkt) r_issue(rg0, dQg, mo0, dcx, 16 * tt0 + li < T);
+    if (tt1 < a.nkt) r_issue(rg1, dQg, mo1, dcx, 16 * tt1 + li < T);
     // ---- phase 3: dWq dbq from images of q_in and dQ, dgamma1 dbeta1; then the scatter of this side's partial ----
     f32x4 awq[2], nob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { awq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; nob[j] = awq[j]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
-    // ONE round: the images of q_in and dQ over all tiles (2 x 14 tiles x hi, lo) are exactly the image area; wave w writes
-    // tiles w and w + 8
+    // ONE round: the images of q_in and dQ over all tiles (2 x 14 tiles x hi, lo) are exactly the image area
     __bf16* Gm = reinterpret_cast<__bf16*>(smem + L::MATB);
-#pragma unroll 1
-    for (int tt = wave; tt < a.nkt; tt += SB_WAVES) {
-        const int qq = 16 * tt + li;
-        const bool rok = qq < T;
-        const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
-        RRaw r1, r2;
-        r_issue(r1, bk.q_in, mo, dcx);
-        r_issue(r2, dQg, mo, dcx, rok);
+    if (tt0 < a.nkt) {
         f32x4 qin[4], dQ[4];
-        r_finish(qin, r1, dcx);
+        r_finish(qin, rq0, dcx);
         plant_one(qin, D);
-        img_put<SPLIT>(Im, Im + B1_FSTR, 16 * tt, qin);
-        r_finish(dQ, r2, dcx);
-        img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt, dQ);
+        img_put<SPLIT>(Im, Im + B1_FSTR, 16 * tt0, qin);
+        r_finish(dQ, rg0, dcx);
+        img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt0, dQ);
+    }
+    if (tt1 < a.nkt) {
+        f32x4 qin[4], dQ[4];
+        r_finish(qin, rq1, dcx);
+        plant_one(qin, D);
+        img_put<SPLIT>(Im, Im + B1_FSTR, 16 * tt1, qin);
+        r_finish(dQ, rg1, dcx);
+        img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt1, dQ);
     }
     __syncthreads();
     B1_TS(16);
