@@ -310,7 +310,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) qv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                img_put<SPLIT>(Im, Im + B1_FSTR, trow, qv);
+                img_put<SPLIT, true>(Im, Im + B1_FSTR, trow, qv);
             }
             // df = g1 W1^T + dy * mask (residual of modules.py:313)
             f32x4 df[4];
@@ -329,7 +329,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) dout[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                img_put<SPLIT>(Im + (L::MATB >> 1), Im + (L::MATB >> 1) + B1_FSTR, trow, dout);
+                img_put<SPLIT, true>(Im + (L::MATB >> 1), Im + (L::MATB >> 1) + B1_FSTR, trow, dout);
             }
             {
                 // delta[row] = sum_c d_o[c] * (o[c] - q_in[c]) (the attention core's output is o - q_in, modules.py:262-269)
