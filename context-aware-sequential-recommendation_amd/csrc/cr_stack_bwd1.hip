@@ -154,8 +154,10 @@ __device__ __forceinline__ void b1_ln_flush(const float* part, float* dg, float*
 // =====================================================================================================
 struct B1Acc { f32x4 aw1[2], aw2[2], ag[4], ab[4], agF[4], abF[4]; };   // Q side: what phase 1 leaves in registers
 
-template <bool SPLIT, int DS, bool QSIDE>
-__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A) {
+// before_last_products: called by the query side in its last round between the chain and the barrier in front of the round's weight
+// gradients (the phase-2 staging's loads go out there: their latency passes under the products)
+template <bool SPLIT, int DS, bool QSIDE, class F>
+__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, F&& before_last_products) {
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -344,13 +346,25 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
                 if (lg == 0) sdel[trow + (lane_now() & 15)] = rok ? acc : 0.0f;
             }
         }
-        if (rd + 1 < R) issue(rd + 1);
-        if (QSIDE) {
-            __syncthreads();
-            wgrad_accum<SPLIT, false>(aw2, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
-            wgrad_accum<SPLIT, false>(aw1, nob, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
-            __syncthreads();
+        if (rd + 1 < R) {
+            issue(rd + 1);
+            if (QSIDE) {
+                __syncthreads();
+                wgrad_accum<SPLIT, false>(aw2, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
+                wgrad_accum<SPLIT, false>(aw1, nob, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+                __syncthreads();
+            }
         }
+    }
+    // the last round's products stand behind the loop: what the caller requests in front of them (the query side: phase 2's K / V
+    // rows and Wq) has its addresses formed HERE, not hoisted in front of the round loop and carried through the chains
+    before_last_products();
+    if (QSIDE) {
+        const int ntr = min(SB_TPR, a.nkt - (R - 1) * SB_TPR);
+        __syncthreads();
+        wgrad_accum<SPLIT, false>(aw2, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);
+        wgrad_accum<SPLIT, false>(aw1, nob, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);
+        __syncthreads();
     }
     B1_TS(2);
     if (QSIDE) {
@@ -524,8 +538,16 @@ __device__ __forceinline__ void b1_stage_kv_put(B1Stage& r, unsigned char* smem,
     }
 }
 
+template <int DS>
+__device__ __forceinline__ void b1_q_stage_issue(const B1Args& a, int n, B1Stage& st, WRegs<1, SB_NT>& w) {
+    const cr_block_desc& bk = a.bd.f;
+    const int D = DS > 0 ? DS : bk.D, T = a.T;
+    w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
+    b1_stage_kv_issue(st, a, n * T, 16 * a.nkt, D, bk.M);
+}
+
 template <bool SPLIT, int DS>
-__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A) {
+__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, B1Stage& stg, WRegs<1, SB_NT>& w) {
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -547,17 +569,14 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     {
         float* partF = fl + L::PARTF; float* gamF = fl + L::GAMF;
         (void)gamF;
-        WRegs<1, SB_NT> w;
-        B1Stage st;
-        w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
-        b1_stage_kv_issue(st, a, base_row, T16, D, M);
+        // (Wq and the K / V rows were requested in front of phase 1's last weight-gradient products: b1_q_stage_issue)
         const float gv = (threadIdx.x < D) ? bk.ln1_g[threadIdx.x] : 0.0f;
         const size_t so = (size_t)blockIdx.x * bd.slab_stride;
         const int it = wave >> 1, jt0 = 2 * (wave & 1);
         b1_wstore(bd.g_w1 + so, D, bd.g_b1 + so, A.aw1, D, it, jt0, add);
         b1_wstore(bd.g_w2 + so, D, bd.g_b2 + so, A.aw2, D, it, jt0, add);
         // (dgamma2 dbeta2 and the final LayerNorm's sums leave on the K side: it runs the same chain and is the shorter side)
-        b1_stage_kv_put<SPLIT>(st, smem, kb, a, base_row, T16, D, M);
+        b1_stage_kv_put<SPLIT>(stg, smem, kb, a, base_row, T16, D, M);
         w_put_perm<1, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
         if (threadIdx.x < 64) gam[threadIdx.x] = gv;      // (gamma2 is dead behind phase 1's last barrier)
         for (int i = threadIdx.x; i < 2 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;
@@ -1162,12 +1181,14 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     const int n = a.n0 + (int)blockIdx.x;
     if (blockIdx.y == 0) {
         B1Acc acc;
-        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, acc);
+        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, acc, [] {});
         b1_k_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc);
     } else {
         B1Acc acc;
-        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, acc);
-        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc);
+        B1Stage st;
+        WRegs<1, SB_NT> w;
+        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, acc, [&] { b1_q_stage_issue<DS>(a, n, st, w); });
+        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc, st, w);
     }
     B1_TS(31);
 }
