@@ -96,16 +96,20 @@ struct B1Lds {
     static constexpr int LOB = B1_FSTR * 2;                        // bytes from a hi image to its lo image
     static constexpr int W_OFF = NIMG * B1_FSTR;                   // elements
     static constexpr int F_OFF_BYTES = (W_OFF + 2 * WST) * 2;
-    // float vectors behind the weights
+    // float vectors behind the weights.  Per-head vectors (delta, m') come twice (two heads of 32 columns at D = 64).  A workgroup is
+    // ONE side: the query side's key bias (KB) and the key side's row vectors (SMX .. TFLAG) are the same floats.
     static constexpr int GAM = 0, GAMF = 64, PART = 128, PARTF = PART + 2 * SB_WAVES * 64, SDEL = PARTF + 2 * SB_WAVES * 64,
-                         KB = SDEL + B1_ROWS, SMX = KB + B1_ROWS + 16, SINV = SMX + B1_ROWS, SUNI = SINV + B1_ROWS, SQV = SUNI + B1_ROWS,
+                         KB = SDEL + 2 * B1_ROWS, SMX = KB, SUNI = SMX + 2 * B1_ROWS, SQV = SUNI + B1_ROWS,
                          TFLAG = SQV + B1_ROWS, NFLOAT = TFLAG + 16;
+    static_assert(SUNI >= KB + B1_ROWS + 16, "the key bias (one extra tile) inside the shared floats");
     static constexpr int BYTES = F_OFF_BYTES + NFLOAT * 4;
 };
 
 // accumulators D[in = 16 it + 4 lg + r][out = 16 (jt0 + j) + li] -> slab (row pitch ldw), row D = the bias gradient; `add`: the
 // workgroup's second and later sequences add to what its first one stored
-__device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, const f32x4 (&acc)[2], int D, int it, int jt0, bool add) {
+// BIAS (D == 64: no spare column for the ones trick): the bias gradient comes from accb (row 0 of the all-ones product: wgrad_accum)
+template <bool BIAS = false>
+__device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, const f32x4 (&acc)[2], const f32x4 (&accb)[2], int D, int it, int jt0, bool add) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -113,11 +117,12 @@ __device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * it + 4 * lg + r;
-            if (col < D && k <= D) {
+            if (col < D && (BIAS ? k < D : k <= D)) {
                 float* p = (k < D) ? dst + (size_t)k * ldw + col : bias_dst + col;
                 *p = add ? *p + acc[j][r] : acc[j][r];
             }
         }
+        if (BIAS && it == 0 && lg == 0 && col < D) bias_dst[col] = add ? bias_dst[col] + accb[j][0] : accb[j][0];
     }
 }
 // LayerNorm column sums: per-lane partials -> sums over the wave's 16 rows -> the wave's LDS slot (+=: a wave folds once per
@@ -152,12 +157,13 @@ __device__ __forceinline__ void b1_ln_flush(const float* part, float* dg, float*
 // =====================================================================================================
 // phase 1: LN2 + feed-forward backward of every tile of sequence n (both sides)
 // =====================================================================================================
-struct B1Acc { f32x4 aw1[2], aw2[2], ag[4], ab[4], agF[4], abF[4]; };   // Q side: what phase 1 leaves in registers
+struct B1Acc { f32x4 aw1[2], aw2[2], aw1b[2], aw2b[2], ag[4], ab[4], agF[4], abF[4]; };   // Q side: what phase 1 leaves in registers (aw?b: bias sums at D = 64)
 
 // before_last_products: called by the query side in its last round between the chain and the barrier in front of the round's weight
 // gradients (the phase-2 staging's loads go out there: their latency passes under the products)
-template <bool SPLIT, int DS, bool QSIDE, class F>
+template <bool SPLIT, int DS, bool QSIDE, int HD, class F>
 __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, F&& before_last_products) {
+    constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -176,9 +182,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
 #endif
     B1_TS(13);
     f32x4 (&aw1)[2] = A.aw1; f32x4 (&aw2)[2] = A.aw2; f32x4 (&ag)[4] = A.ag; f32x4 (&ab)[4] = A.ab; f32x4 (&agF)[4] = A.agF; f32x4 (&abF)[4] = A.abF;
-    f32x4 nob[2];
+    f32x4 (&aw1b)[2] = A.aw1b; f32x4 (&aw2b)[2] = A.aw2b;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; nob[j] = aw1[j]; }
+    for (int j = 0; j < 2; ++j) { aw1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw2[j] = aw1[j]; aw1b[j] = aw1[j]; aw2b[j] = aw1[j]; }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { ag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[ct] = ag[ct]; agF[ct] = ag[ct]; abF[ct] = ag[ct]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
@@ -337,21 +343,26 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
                 // delta[row] = sum_c d_o[c] * (o[c] - q_in[c]) (the attention core's output is o - q_in, modules.py:262-269)
                 f32x4 qin[4];
                 r_finish(qin, rq, dcx);
-                float acc = 0.0f;
+                float acc[HD];
+#pragma unroll
+                for (int h = 0; h < HD; ++h) acc[h] = 0.0f;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc);
-                acc = grp_sum(acc);
-                if (lg == 0) sdel[trow + (lane_now() & 15)] = rok ? acc : 0.0f;
+                    for (int r = 0; r < 4; ++r) acc[HD == 2 ? ct >> 1 : 0] = fmaf(dout[ct][r], o[ct][r] - qin[ct][r], acc[HD == 2 ? ct >> 1 : 0]);   // (a head: 32 columns)
+#pragma unroll
+                for (int h = 0; h < HD; ++h) {
+                    acc[h] = grp_sum(acc[h]);
+                    if (lg == 0) sdel[h * B1_ROWS + trow + (lane_now() & 15)] = rok ? acc[h] : 0.0f;
+                }
             }
         }
         if (rd + 1 < R) {
             issue(rd + 1);
             if (QSIDE) {
                 __syncthreads();
-                wgrad_accum<SPLIT, false>(aw2, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
-                wgrad_accum<SPLIT, false>(aw1, nob, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+                wgrad_accum<SPLIT, BIAS>(aw2, aw2b, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
+                wgrad_accum<SPLIT, BIAS>(aw1, aw1b, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
                 __syncthreads();
             }
         }
@@ -362,8 +373,8 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     if (QSIDE) {
         const int ntr = min(SB_TPR, a.nkt - (R - 1) * SB_TPR);
         __syncthreads();
-        wgrad_accum<SPLIT, false>(aw2, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);
-        wgrad_accum<SPLIT, false>(aw1, nob, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);
+        wgrad_accum<SPLIT, BIAS>(aw2, aw2b, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);
+        wgrad_accum<SPLIT, BIAS>(aw1, aw1b, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);
         __syncthreads();
     }
     B1_TS(2);
@@ -546,8 +557,9 @@ __device__ __forceinline__ void b1_q_stage_issue(const B1Args& a, int n, B1Stage
     b1_stage_kv_issue(st, a, n * T, 16 * a.nkt, D, bk.M);
 }
 
-template <bool SPLIT, int DS>
+template <bool SPLIT, int DS, int HD>
 __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, B1Stage& stg, WRegs<1, SB_NT>& w) {
+    constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -573,8 +585,8 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const float gv = (threadIdx.x < D) ? bk.ln1_g[threadIdx.x] : 0.0f;
         const size_t so = (size_t)blockIdx.x * bd.slab_stride;
         const int it = wave >> 1, jt0 = 2 * (wave & 1);
-        b1_wstore(bd.g_w1 + so, D, bd.g_b1 + so, A.aw1, D, it, jt0, add);
-        b1_wstore(bd.g_w2 + so, D, bd.g_b2 + so, A.aw2, D, it, jt0, add);
+        b1_wstore<BIAS>(bd.g_w1 + so, D, bd.g_b1 + so, A.aw1, A.aw1b, D, it, jt0, add);
+        b1_wstore<BIAS>(bd.g_w2 + so, D, bd.g_b2 + so, A.aw2, A.aw2b, D, it, jt0, add);
         // (dgamma2 dbeta2 and the final LayerNorm's sums leave on the K side: it runs the same chain and is the shorter side)
         b1_stage_kv_put<SPLIT>(stg, smem, kb, a, base_row, T16, D, M);
         w_put_perm<1, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
@@ -605,14 +617,17 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     // requested behind the current tile's loop, under its row chain
     GFrag<2> qn;
     RRaw rdo;
-    f4s st = (f4s){0.f, 0.f, 2.0f, 0.f};
+    f4s st[HD];
+#pragma unroll
+    for (int h = 0; h < HD; ++h) st[h] = (f4s){0.f, 0.f, 2.0f, 0.f};
     float qv_n = 0.0f;
     auto issue_tile = [&](int qt_) {
         const int q0_ = 16 * qt_, q_ = q0_ + (lane_now() & 15);
         const int m_ = base_row + min(q_, T - 1);
         gfrag_issue<2>(qn, d.Q, d.ld, base_row + q0_, 0, T - q0_, D, M);
         r_issue(rdo, bd.d_o, (u32)m_ * (u32)(4 * D), dcx, q_ < T);
-        st = *reinterpret_cast<const f4s*>(d.row_stats + (size_t)m_ * 4);
+#pragma unroll
+        for (int h = 0; h < HD; ++h) st[h] = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)h * d.B * T + m_) * 4);   // [head][sequence][row]
         qv_n = d.q_valid[m_];
     };
     if ((int)(tpk & 31u) < a.nkt) issue_tile((int)(tpk & 31u));
@@ -626,11 +641,15 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const int m = base_row + min(q, T - 1);
         const u32 mo = (u32)m * (u32)(4 * D);
         const float qvs = rok ? qv_n * dc.scale : 0.0f;               // the kept scores' factor: query validity x 1 / (1 - rate)
-        const float delta = sdel[min(q, T16 - 1)];
-        const bool normal = rok && st.z == 0.0f;
+        const bool normal = rok && st[0].z == 0.0f;                  // (normal / uniform / dead is the same in every head: the masks are)
         // P[q][k] = exp2(s c - m) / sum = exp2(s c - (m - log2(1 / sum))): the row's 1 / sum goes into the exponent (one multiply per
         // score less); rows without score gradient (uniform, dead, beyond T) get m' = 1e30: P = 0 exactly
-        const float mrow = normal ? st.x - __log2f(st.y) : 1e30f;
+        float delta[HD], mrow[HD];
+#pragma unroll
+        for (int h = 0; h < HD; ++h) {
+            delta[h] = sdel[h * B1_ROWS + min(q, T16 - 1)];
+            mrow[h] = normal ? st[h].x - __log2f(st[h].y) : 1e30f;
+        }
         bf8 qh[2], ql[2], oh[2], ol[2];
         gfrag_finish<SPLIT, 2>(qn, d.Q, d.ld, base_row + q0, 0, T - q0, D, M, qh, ql);
         f32x4 dO[4];                                      // kept for the residual branch behind the loop (dq_in = dQ Wq^T + d_o)
@@ -639,8 +658,9 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         RRaw rx;
         r_issue(rx, bk.x, mo, dcx);                       // the block input's rows of this tile (LayerNorm-1 backward), under the loop
         const bool tile_live = __any(normal ? 1 : 0) != 0;              // uniform and dead rows carry no score gradient
-        const uint32_t ridx = attn_row_idx(d, 0, n, q);
-        const uint32_t xrow = (ridx + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
+        uint32_t xrow[HD];
+#pragma unroll
+        for (int h = 0; h < HD; ++h) xrow[h] = (attn_row_idx(d, h, n, q) + (uint32_t)(4 * lg)) * CR_PHI + dc.key;
         f32x4 dq[4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) dq[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -648,7 +668,6 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
             const int lo = kt_first, hi = qt;
             for (int kp = lo >> 1; 2 * kp <= hi; ++kp) {                 // pairs of key tiles 2 kp, 2 kp + 1
                 const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
                 const int po = 4096 * kp;
                 auto rfF = [&](int base, int ks, int second, int lo_) {
                     return *reinterpret_cast<const bf8*>(smem + (base + po + (ks ? frk1 : frk0)) + 2048 * second + L::LOB * lo_);
@@ -659,88 +678,101 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
                     const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
                     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
-                {
-                    bf8 a0h[2], a0l[2], a1h[2], a1l[2];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
-                        a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        s0 = mma<SPLIT>(a0h[ks], a0l[ks], qh[ks], ql[ks], s0);      // S^T[key][q] = K Q^T
-                        s1 = mma<SPLIT>(a1h[ks], a1l[ks], qh[ks], ql[ks], s1);
-                    }
-                    BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
-                    BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
-                }
-                {
-                    bf8 v0h[2], v0l[2], v1h[2], v1l[2];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        v0h[ks] = rfF(L::MATB, ks, 0, 0); v1h[ks] = rfF(L::MATB, ks, 1, 0);
-                        v0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : v0h[ks]; v1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : v1h[ks];
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        p0 = mma<SPLIT>(v0h[ks], v0l[ks], oh[ks], ol[ks], p0);      // dA^T[key][q] = V dO^T (V permuted, dO in layout R)
-                        p1 = mma<SPLIT>(v1h[ks], v1l[ks], oh[ks], ol[ks], p1);
-                    }
-                    BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
-                    BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
-                }
-                // the dQ product's K operand (transposed reads): first batch requested before the element-wise phase that hides it
-                constexpr int JB = SPLIT ? 2 : 4;
-                bf8 bh[JB], bl[JB];
-#pragma unroll
-                for (int jt = 0; jt < JB; ++jt) {
-                    bh[jt] = trF(0, jt, 0);
-                    bl[jt] = SPLIT ? trF(0, jt, 1) : bh[jt];
-                }
-                float x[8];
-                // per score: the key mask is an ADDITIVE bias in the exponent (0 / -inf: kb), 1 / sum sits in m', the query's validity
-                // and the dropout scale are one factor, 1 / sqrt(d) is applied to dQ behind the loop; the causal compare exists only
-                // in the code of the pair that holds the diagonal tile (the last one: a wave-uniform branch picks the body):
-                // fma, add, exp2, the keep test (add, xor-shift, multiply, compare, select), fma, mul
+                // the additive key bias of the pair's two tiles (the same for every head)
                 const float4 b40 = *reinterpret_cast<const float4*>(smem + (vkb + 128 * kp));
                 const float4 b41 = *reinterpret_cast<const float4*>(smem + (vkb + 128 * kp) + 64);
-                auto finish = [&](auto diag_c, int kt, const float4& b4, const f32x4& s, const f32x4& p, int xo) {
-                    constexpr bool DIAG = decltype(diag_c)::value;
-                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                // a head: its 32 columns are one k-step of the score products and two feature tiles of dQ (HD = 1: both k-steps, four tiles)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pn = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mrow) + bb[r]);
-                        if (DIAG) pn = (16 * kt + 4 * lg + r <= q) ? pn : 0.0f;                 // causal (kt == qt)
-                        const float w = (cr_mix(xrow + (uint32_t)(16 * kt + r) * CR_PHI) >= dc.thresh) ? qvs : 0.0f;
-                        x[xo + r] = pn * (p[r] * w - delta);                              // dS (1 / sqrt(d): behind the loop)
+                for (int h = 0; h < HD; ++h) {
+                    const int ks_lo = HD == 2 ? h : 0, ks_hi = HD == 2 ? h + 1 : 2;
+                    constexpr int NKS = HD == 2 ? 1 : 2;
+                    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                    {
+                        bf8 a0h[2], a0l[2], a1h[2], a1l[2];
+#pragma unroll
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                            a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                            a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                        }
+#pragma unroll
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                            s0 = mma<SPLIT>(a0h[ks], a0l[ks], qh[ks], ql[ks], s0);      // S^T[key][q] = K Q^T
+                            s1 = mma<SPLIT>(a1h[ks], a1l[ks], qh[ks], ql[ks], s1);
+                        }
+                        BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                        BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
                     }
-                };
-                if (k1 > hi) {                                                            // the diagonal pair, second tile beyond it (or absent)
-                    finish(std::true_type{}, k0, b40, s0, p0, 0);
-                    x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
-                } else if (k1 == hi) {                                                    // the diagonal pair
-                    finish(std::false_type{}, k0, b40, s0, p0, 0);
-                    finish(std::true_type{}, k1, b41, s1, p1, 4);
-                } else {                                                                  // (a tile below `lo` holds masked keys only: bias -inf)
-                    finish(std::false_type{}, k0, b40, s0, p0, 0);
-                    finish(std::false_type{}, k1, b41, s1, p1, 4);
-                }
-                bf8 ah, al;
-                split8<SPLIT>(x, ah, al);
-                // dQ^T += K^T dS^T: the transposed-read fragment as A, dS as B -> D[feature 16 jt + 4 lg + r][query li] = layout R
+                    {
+                        bf8 v0h[2], v0l[2], v1h[2], v1l[2];
 #pragma unroll
-                for (int jt = 0; jt < JB; ++jt) dq[jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[jt]);
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                            v0h[ks] = rfF(L::MATB, ks, 0, 0); v1h[ks] = rfF(L::MATB, ks, 1, 0);
+                            v0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : v0h[ks]; v1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : v1h[ks];
+                        }
 #pragma unroll
-                for (int j0 = JB; j0 < 4; j0 += JB) {
+                        for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                            p0 = mma<SPLIT>(v0h[ks], v0l[ks], oh[ks], ol[ks], p0);      // dA^T[key][q] = V dO^T (V permuted, dO in layout R)
+                            p1 = mma<SPLIT>(v1h[ks], v1l[ks], oh[ks], ol[ks], p1);
+                        }
+                        BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                        BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                    }
+                    // the dQ product's K operand (transposed reads): first batch requested before the element-wise phase that hides it
+                    constexpr int JB = (SPLIT || HD == 2) ? 2 : 4;
+                    const int jbase = HD == 2 ? 2 * h : 0;
+                    bf8 bh[JB], bl[JB];
 #pragma unroll
                     for (int jt = 0; jt < JB; ++jt) {
-                        bh[jt] = trF(0, j0 + jt, 0);
-                        bl[jt] = SPLIT ? trF(0, j0 + jt, 1) : bh[jt];
+                        bh[jt] = trF(0, jbase + jt, 0);
+                        bl[jt] = SPLIT ? trF(0, jbase + jt, 1) : bh[jt];
                     }
+                    float x[8];
+                    // per score: the key mask is an ADDITIVE bias in the exponent (0 / -inf: kb), 1 / sum sits in m', the query's validity
+                    // and the dropout scale are one factor, 1 / sqrt(d) is applied to dQ behind the loop; the causal compare exists only
+                    // in the code of the pair that holds the diagonal tile (the last one: a wave-uniform branch picks the body):
+                    // fma, add, exp2, the keep test (add, xor-shift, multiply, compare, select), fma, mul
+                    const float mrow_h = mrow[h], delta_h = delta[h];
+                    const uint32_t xrow_h = xrow[h];
+                    auto finish = [&](auto diag_c, int kt, const float4& b4, const f32x4& s, const f32x4& p, int xo) {
+                        constexpr bool DIAG = decltype(diag_c)::value;
+                        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[j0 + jt]);
-                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
-                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                        for (int r = 0; r < 4; ++r) {
+                            float pn = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mrow_h) + bb[r]);
+                            if (DIAG) pn = (16 * kt + 4 * lg + r <= q) ? pn : 0.0f;                 // causal (kt == qt)
+                            const float w = (cr_mix(xrow_h + (uint32_t)(16 * kt + r) * CR_PHI) >= dc.thresh) ? qvs : 0.0f;
+                            x[xo + r] = pn * (p[r] * w - delta_h);                            // dS (1 / sqrt(d): behind the loop)
+                        }
+                    };
+                    if (k1 > hi) {                                                            // the diagonal pair, second tile beyond it (or absent)
+                        finish(std::true_type{}, k0, b40, s0, p0, 0);
+                        x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
+                    } else if (k1 == hi) {                                                    // the diagonal pair
+                        finish(std::false_type{}, k0, b40, s0, p0, 0);
+                        finish(std::true_type{}, k1, b41, s1, p1, 4);
+                    } else {                                                                  // (a tile below `lo` holds masked keys only: bias -inf)
+                        finish(std::false_type{}, k0, b40, s0, p0, 0);
+                        finish(std::false_type{}, k1, b41, s1, p1, 4);
+                    }
+                    bf8 ah, al;
+                    split8<SPLIT>(x, ah, al);
+                    // dQ^T += K^T dS^T: the transposed-read fragment as A, dS as B -> D[feature 16 jt + 4 lg + r][query li] = layout R
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dq[jbase + jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[jbase + jt]);
+                    if (HD == 1) {
+#pragma unroll
+                        for (int j0 = JB; j0 < 4; j0 += JB) {
+#pragma unroll
+                            for (int jt = 0; jt < JB; ++jt) {
+                                bh[jt] = trF(0, j0 + jt, 0);
+                                bl[jt] = SPLIT ? trF(0, j0 + jt, 1) : bh[jt];
+                            }
+#pragma unroll
+                            for (int jt = 0; jt < JB; ++jt) dq[j0 + jt] = mma<SPLIT>(bh[jt], bl[jt], ah, al, dq[j0 + jt]);
+                            BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                            BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                        }
+                    }
                 }
             }
         }
@@ -821,10 +853,10 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     }
     __syncthreads();
     B1_TS(16);
-    wgrad_accum<SPLIT, false, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);      // dWq (+ dbq) += q_in^T dQ
+    wgrad_accum<SPLIT, BIAS, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);       // dWq (+ dbq) += q_in^T dQ (nob: the bias sums at D = 64)
     B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    b1_wstore(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, D, it, jt0, add);
+    b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
     b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
     B1_TS(18);
     if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part + partF: 8 x 224 list entries)
@@ -836,8 +868,9 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 // =====================================================================================================
 // K side, phases 2 and 3: key-owner pass (dK, dV), K / V projections backward, dWk dWv
 // =====================================================================================================
-template <bool SPLIT, int DS>
+template <bool SPLIT, int DS, int HD>
 __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A) {
+    constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -862,7 +895,9 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         WRegs<2, SB_NT> w;
         w_issue<2, SB_NT>(w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
         const int t = threadIdx.x, tc = min(t, T - 1);
-        const f4s st = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)base_row + tc) * 4);
+        f4s st[HD];
+#pragma unroll
+        for (int h = 0; h < HD; ++h) st[h] = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)h * d.B * T + base_row + tc) * 4);   // [head][sequence][row]
         const float qv = d.q_valid[base_row + tc];
         {
             // dgamma2 dbeta2 (+ the final LayerNorm's sums) of this side's phase 1: every wave WRITES its slots (its accumulators cover all
@@ -878,11 +913,14 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
         // stored so that the inner loop is branch-free: A[q][key] = valid * exp2(s c - smx) + (key < T ? suni : 0);
         // normal row: suni = 0; uniform row: suni = 1/T; dead row: neither (smx = 1e30 wherever the row is not normal)
-        const float flag = t < T ? st.z : 2.0f;
+        const float flag = t < T ? st[0].z : 2.0f;          // (normal / uniform / dead is the same in every head: the masks are)
         const bool normal = flag == 0.0f;
         if (t < T16 + ((a.nkt & 1) ? 16 : 0)) {             // (an odd tile count: the absent tile of the last pair reads as dead rows)
-            smx[t] = normal ? st.x - __log2f(st.y) : 1e30f;      // 1 / sum inside the exponent: P = exp2(s c - m')
-            if (!normal || t >= T16) sdel[t] = 0.0f;
+#pragma unroll
+            for (int h = 0; h < HD; ++h) {
+                smx[h * B1_ROWS + t] = normal ? st[h].x - __log2f(st[h].y) : 1e30f;      // 1 / sum inside the exponent: P = exp2(s c - m')
+                if (!normal || t >= T16) sdel[h * B1_ROWS + t] = 0.0f;
+            }
             suni[t] = (flag == 1.0f) ? a.invT : 0.0f;
             sqv[t] = t < T ? qv * dc.scale : 0.0f;               // query validity x 1 / (1 - rate): the kept scores' factor
         }
@@ -959,6 +997,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         // x = idx * PHI + key of attention_weights[n, 4 lg, key]: a query tile adds 16 T PHI, a row T PHI (scalars)
         const uint32_t xbase = (drop_base + (uint32_t)(4 * lg) * (uint32_t)T) * CR_PHI + dc.key;
         const uint32_t xT = (uint32_t)T * CR_PHI;
+        const uint32_t xhead = (uint32_t)d.batch_global * (uint32_t)T * (uint32_t)T * CR_PHI;      // a head further in attention_weights (attn_row_idx)
         for (int qp = 0; 2 * qp < ntile; ++qp) {                         // pairs of query tiles 2 qp, 2 qp + 1
             const int l0 = 2 * qp, l1 = 2 * qp + 1;
             // nothing flows through dead query tiles; uniform rows see every key; else the causal / padding skip (scalar bit tests)
@@ -966,7 +1005,6 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             const bool w0 = (pairbits & 1u) && ((unibits & 1u) || (l0 >= kt && tile_has_key));
             const bool w1 = (pairbits & 2u) && ((unibits & 2u) || (l1 >= kt && tile_has_key));
             if (!w0 && !w1) continue;
-            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
             const int po = 4096 * qp;
             auto rfF = [&](int base, int ks, int second, int lo) {
                 return *reinterpret_cast<const bf8*>(smem + (base + po + (ks ? frk1 : frk0)) + 2048 * second + L::LOB * lo);
@@ -977,120 +1015,131 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
                 const bf4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(pa + 2048));
                 return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
             };
-            {
-                bf8 a0h[2], a0l[2], a1h[2], a1l[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
-                    a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
-                }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s0 = mma<SPLIT>(a0h[ks], a0l[ks], kh[ks], kl[ks], s0);      // S[q][key]
-                    s1 = mma<SPLIT>(a1h[ks], a1l[ks], kh[ks], kl[ks], s1);
-                }
-                BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
-                BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
-            }
-            {
-                bf8 o0h[2], o0l[2], o1h[2], o1l[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    o0h[ks] = rfF(L::MATB, ks, 0, 0); o1h[ks] = rfF(L::MATB, ks, 1, 0);
-                    o0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : o0h[ks]; o1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : o1h[ks];
-                }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    p0 = mma<SPLIT>(o0h[ks], o0l[ks], vh[ks], vl[ks], p0);      // dA[q][key] = dO V^T
-                    p1 = mma<SPLIT>(o1h[ks], o1l[ks], vh[ks], vl[ks], p1);
-                }
-                BF_SGB(0x100, (SPLIT ? 4 : 2) * 2, 0);
-                BF_SGB(0x008, (SPLIT ? 6 : 2) * 2, 0);
-            }
-            // the rows' vectors of both query tiles (m', delta, validity x dropout scale), in front of the transposed reads (LDS returns
-            // in order: they are there when the element-wise phase opens)
             const unsigned char* vq = smem + (vrow + 128 * qp);
-            float4 m4[2], d4[2], w4[2];
+            // a head: its 32 columns are one k-step of the score products and two feature tiles of dK / dV (HD = 1: both k-steps, four tiles)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                m4[h] = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SMX - L::SDEL));
-                d4[h] = *reinterpret_cast<const float4*>(vq + 64 * h);
-                w4[h] = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SQV - L::SDEL));
-            }
-            // dOut columns for the dV product: first batch requested before the element-wise phase that hides it
-            constexpr int JB = SPLIT ? 2 : 4;
-            bf8 oth[JB], otl[JB];
+            for (int h = 0; h < HD; ++h) {
+                const int ks_lo = HD == 2 ? h : 0, ks_hi = HD == 2 ? h + 1 : 2;
+                constexpr int NKS = HD == 2 ? 1 : 2;
+                f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                {
+                    bf8 a0h[2], a0l[2], a1h[2], a1l[2];
 #pragma unroll
-            for (int jt = 0; jt < JB; ++jt) {
-                oth[jt] = trF(L::MATB, jt, 0);
-                otl[jt] = SPLIT ? trF(L::MATB, jt, 1) : oth[jt];
-            }
-            float xa[8], xd[8];
-            // per score: the key's validity (this lane's key: loop-invariant) and "query tile above the key tile" are an ADDITIVE bias
-            // in the exponent (0 / -inf), 1 / sum sits in m' (smx), the query's validity and the dropout scale in one factor (sqv),
-            // 1 / sqrt(d) is applied to dK behind the loop; the causal compare exists only in the code of the one pair that holds
-            // the diagonal tile (DIAG: a wave-uniform branch picks the body), the uniform-row term only in tiles that hold such a
-            // row: 11 vector instructions per score.  (The absent second tile of an odd count reads as dead rows: m' = 1e30.)
-            auto finish = [&](auto diag_c, int h, int xo, const f32x4& s, const f32x4& p) {
-                constexpr bool DIAG = decltype(diag_c)::value;
-                const int lt = 2 * qp + h;
-                const float mm[4] = {m4[h].x, m4[h].y, m4[h].z, m4[h].w}, dd[4] = {d4[h].x, d4[h].y, d4[h].z, d4[h].w}, ww[4] = {w4[h].x, w4[h].y, w4[h].z, w4[h].w};
-                const uint32_t x0 = xbase + (uint32_t)lt * (16u * xT);       // counter of attention_weights[n, 16 lt + 4 lg, key]
-                const float bias = (lt < kt) ? -INFINITY : kbias;            // query tile above the key tile: causally masked as a whole
-                float pn[4], w[4];
+                    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                        a0h[ks] = rfF(0, ks, 0, 0); a1h[ks] = rfF(0, ks, 1, 0);
+                        a0l[ks] = SPLIT ? rfF(0, ks, 0, 1) : a0h[ks]; a1l[ks] = SPLIT ? rfF(0, ks, 1, 1) : a1h[ks];
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pn[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mm[r]) + bias);
-                    if (DIAG) pn[r] = (lt != kt || key <= 16 * lt + 4 * lg + r) ? pn[r] : 0.0f;        // causal
-                    w[r] = (cr_mix(x0 + (uint32_t)r * xT) >= dc.thresh) ? ww[r] : 0.0f;                // validity x keep / (1 - rate)
-                    xd[xo + r] = pn[r] * (p[r] * w[r] - dd[r]);              // dS (1 / sqrt(d): behind the loop)
+                    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                        s0 = mma<SPLIT>(a0h[ks], a0l[ks], kh[ks], kl[ks], s0);      // S[q][key]
+                        s1 = mma<SPLIT>(a1h[ks], a1l[ks], kh[ks], kl[ks], s1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
                 }
-                if ((uni_m >> lt) & 1u) {                                    // rows without a valid key: 1 / T on every key < T
-                    const float4 u4 = *reinterpret_cast<const float4*>(vq + 64 * h + 4 * (L::SUNI - L::SDEL));
-                    const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+                {
+                    bf8 o0h[2], o0l[2], o1h[2], o1l[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xa[xo + r] = (pn[r] + key_in_T * uu[r]) * w[r];
+                    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                        o0h[ks] = rfF(L::MATB, ks, 0, 0); o1h[ks] = rfF(L::MATB, ks, 1, 0);
+                        o0l[ks] = SPLIT ? rfF(L::MATB, ks, 0, 1) : o0h[ks]; o1l[ks] = SPLIT ? rfF(L::MATB, ks, 1, 1) : o1h[ks];
+                    }
+#pragma unroll
+                    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                        p0 = mma<SPLIT>(o0h[ks], o0l[ks], vh[ks], vl[ks], p0);      // dA[q][key] = dO V^T
+                        p1 = mma<SPLIT>(o1h[ks], o1l[ks], vh[ks], vl[ks], p1);
+                    }
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * NKS, 0);
+                    BF_SGB(0x008, (SPLIT ? 6 : 2) * NKS, 0);
+                }
+                // the rows' vectors of both query tiles (this head's m' and delta, validity x dropout scale), in front of the transposed
+                // reads (LDS returns in order: they are there when the element-wise phase opens)
+                float4 m4[2], d4[2], w4[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    m4[t2] = *reinterpret_cast<const float4*>(vq + 64 * t2 + 4 * (L::SMX - L::SDEL) + 4 * B1_ROWS * h);
+                    d4[t2] = *reinterpret_cast<const float4*>(vq + 64 * t2 + 4 * B1_ROWS * h);
+                    w4[t2] = *reinterpret_cast<const float4*>(vq + 64 * t2 + 4 * (L::SQV - L::SDEL));
+                }
+                // dOut columns for the dV product: first batch requested before the element-wise phase that hides it
+                constexpr int JB = (SPLIT || HD == 2) ? 2 : 4;
+                const int jbase = HD == 2 ? 2 * h : 0;
+                bf8 oth[JB], otl[JB];
+#pragma unroll
+                for (int jt = 0; jt < JB; ++jt) {
+                    oth[jt] = trF(L::MATB, jbase + jt, 0);
+                    otl[jt] = SPLIT ? trF(L::MATB, jbase + jt, 1) : oth[jt];
+                }
+                float xa[8], xd[8];
+                // per score: the key's validity (this lane's key: loop-invariant) and "query tile above the key tile" are an ADDITIVE bias
+                // in the exponent (0 / -inf), 1 / sum sits in m' (smx), the query's validity and the dropout scale in one factor (sqv),
+                // 1 / sqrt(d) is applied to dK behind the loop; the causal compare exists only in the code of the one pair that holds
+                // the diagonal tile (DIAG: a wave-uniform branch picks the body), the uniform-row term only in tiles that hold such a
+                // row: 11 vector instructions per score.  (The absent second tile of an odd count reads as dead rows: m' = 1e30.)
+                const uint32_t xb_h = xbase + (uint32_t)h * xhead;
+                auto finish = [&](auto diag_c, int t2, int xo, const f32x4& s, const f32x4& p) {
+                    constexpr bool DIAG = decltype(diag_c)::value;
+                    const int lt = 2 * qp + t2;
+                    const float mm[4] = {m4[t2].x, m4[t2].y, m4[t2].z, m4[t2].w}, dd[4] = {d4[t2].x, d4[t2].y, d4[t2].z, d4[t2].w}, ww[4] = {w4[t2].x, w4[t2].y, w4[t2].z, w4[t2].w};
+                    const uint32_t x0 = xb_h + (uint32_t)lt * (16u * xT);        // counter of attention_weights[head, n, 16 lt + 4 lg, key]
+                    const float bias = (lt < kt) ? -INFINITY : kbias;            // query tile above the key tile: causally masked as a whole
+                    float pn[4], w[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pn[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.isd_log2e, -mm[r]) + bias);
+                        if (DIAG) pn[r] = (lt != kt || key <= 16 * lt + 4 * lg + r) ? pn[r] : 0.0f;        // causal
+                        w[r] = (cr_mix(x0 + (uint32_t)r * xT) >= dc.thresh) ? ww[r] : 0.0f;                // validity x keep / (1 - rate)
+                        xd[xo + r] = pn[r] * (p[r] * w[r] - dd[r]);              // dS (1 / sqrt(d): behind the loop)
+                    }
+                    if ((uni_m >> lt) & 1u) {                                    // rows without a valid key: 1 / T on every key < T
+                        const float4 u4 = *reinterpret_cast<const float4*>(vq + 64 * t2 + 4 * (L::SUNI - L::SDEL));
+                        const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xa[xo + r] = (pn[r] + key_in_T * uu[r]) * w[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xa[xo + r] = pn[r] * w[r];   // A after mask + dropout
+                    }
+                };
+                if (qp == (kt >> 1)) {
+                    finish(std::true_type{}, 0, 0, s0, p0);
+                    finish(std::true_type{}, 1, 4, s1, p1);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xa[xo + r] = pn[r] * w[r];   // A after mask + dropout
+                    finish(std::false_type{}, 0, 0, s0, p0);
+                    finish(std::false_type{}, 1, 4, s1, p1);
                 }
-            };
-            if (qp == (kt >> 1)) {
-                finish(std::true_type{}, 0, 0, s0, p0);
-                finish(std::true_type{}, 1, 4, s1, p1);
-            } else {
-                finish(std::false_type{}, 0, 0, s0, p0);
-                finish(std::false_type{}, 1, 4, s1, p1);
-            }
-            bf8 ah, al, dh, dl;
-            split8<SPLIT>(xa, ah, al);
-            split8<SPLIT>(xd, dh, dl);
-            // dV^T += dO^T A, dK^T += Q^T dS: the transposed-read fragment as A, the coefficients as B -> layout R
+                bf8 ah, al, dh, dl;
+                split8<SPLIT>(xa, ah, al);
+                split8<SPLIT>(xd, dh, dl);
+                // dV^T += dO^T A, dK^T += Q^T dS: the transposed-read fragment as A, the coefficients as B -> layout R
 #pragma unroll
-            for (int jt = 0; jt < JB; ++jt) dv[jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[jt]);
+                for (int jt = 0; jt < JB; ++jt) dv[jbase + jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[jbase + jt]);
+                if (HD == 1) {
 #pragma unroll
-            for (int j0 = JB; j0 < 4; j0 += JB) {
+                    for (int j0 = JB; j0 < 4; j0 += JB) {
 #pragma unroll
-                for (int jt = 0; jt < JB; ++jt) {
-                    oth[jt] = trF(L::MATB, j0 + jt, 0);
-                    otl[jt] = SPLIT ? trF(L::MATB, j0 + jt, 1) : oth[jt];
-                }
+                        for (int jt = 0; jt < JB; ++jt) {
+                            oth[jt] = trF(L::MATB, j0 + jt, 0);
+                            otl[jt] = SPLIT ? trF(L::MATB, j0 + jt, 1) : oth[jt];
+                        }
 #pragma unroll
-                for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[j0 + jt]);
-                BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
-                BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
-            }
-#pragma unroll
-            for (int j0 = 0; j0 < 4; j0 += JB) {
-#pragma unroll
-                for (int jt = 0; jt < JB; ++jt) {
-                    oth[jt] = trF(0, j0 + jt, 0);
-                    otl[jt] = SPLIT ? trF(0, j0 + jt, 1) : oth[jt];
+                        for (int jt = 0; jt < JB; ++jt) dv[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], ah, al, dv[j0 + jt]);
+                        BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                        BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                    }
                 }
 #pragma unroll
-                for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], dh, dl, dk[j0 + jt]);
-                BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
-                BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                for (int j0 = jbase; j0 < (HD == 2 ? jbase + 2 : 4); j0 += JB) {
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) {
+                        oth[jt] = trF(0, j0 + jt, 0);
+                        otl[jt] = SPLIT ? trF(0, j0 + jt, 1) : oth[jt];
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JB; ++jt) dk[j0 + jt] = mma<SPLIT>(oth[jt], otl[jt], dh, dl, dk[j0 + jt]);
+                    BF_SGB(0x100, (SPLIT ? 4 : 2) * JB, 0);
+                    BF_SGB(0x008, (SPLIT ? 3 : 1) * JB, 0);
+                }
             }
         }
 #pragma unroll
@@ -1121,9 +1170,9 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     __syncthreads();                                      // every pass is done: the Q / dOut images are dead, dK / dV rows are visible
     B1_TS(7);
     // ---- phase 3: dWk dbk dWv dbv from images of x, dK, dV; then the scatter of this side's partial ----
-    f32x4 awk[2], awv[2], nob[2];
+    f32x4 awk[2], awv[2], awkb[2], awvb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; nob[j] = awk[j]; }
+    for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; awkb[j] = awk[j]; awvb[j] = awk[j]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
     const int R = a.nkt > SB_TPR ? 2 : 1;
     // a round's rows (x, dK, dV of the wave's tile) are requested one round ahead: the second round's fly under the first round's products
@@ -1154,22 +1203,22 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         issue3(rd + 1);
         __syncthreads();
         if (rd == 0) B1_TS(16);
-        wgrad_accum<SPLIT, false>(awk, nob, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
-        wgrad_accum<SPLIT, false>(awv, nob, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
+        wgrad_accum<SPLIT, BIAS>(awk, awkb, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
+        wgrad_accum<SPLIT, BIAS>(awv, awvb, Im, Im + SB_IMG, Im + 2 * IST, Im + 2 * IST + SB_IMG, ntr, it, jt0);        // dWv (+ dbv) += x^T dV
         __syncthreads();
         if (rd == 0) B1_TS(19);
     }
     B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
-    b1_wstore(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, D, it, jt0, add);
-    b1_wstore(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, D, it, jt0, add);
+    b1_wstore<BIAS>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, awkb, D, it, jt0, add);
+    b1_wstore<BIAS>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, awvb, D, it, jt0, add);
     B1_TS(18);
     if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
 
-template <bool SPLIT, int DS>
+template <bool SPLIT, int DS, int HD>
 __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     B1_TS(0);
@@ -1181,14 +1230,14 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     const int n = a.n0 + (int)blockIdx.x;
     if (blockIdx.y == 0) {
         B1Acc acc;
-        b1_phase1<SPLIT, DS, false>(a, smem_raw, n, acc, [] {});
-        b1_k_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc);
+        b1_phase1<SPLIT, DS, false, HD>(a, smem_raw, n, acc, [] {});
+        b1_k_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc);
     } else {
         B1Acc acc;
         B1Stage st;
         WRegs<1, SB_NT> w;
-        b1_phase1<SPLIT, DS, true>(a, smem_raw, n, acc, [&] { b1_q_stage_issue<DS>(a, n, st, w); });
-        b1_q_side<SPLIT, DS>(a, smem_raw, n, a.add != 0, acc, st, w);
+        b1_phase1<SPLIT, DS, true, HD>(a, smem_raw, n, acc, [&] { b1_q_stage_issue<DS>(a, n, st, w); });
+        b1_q_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc, st, w);
     }
     B1_TS(31);
 }
@@ -1228,13 +1277,15 @@ static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
 static const char* b1_unsupported(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, int B, int T, int precision) {
     if (!bd || !ad) return "NULL description";
     const cr_block_desc& d = bd->f;
-    if (d.D < 8 || d.D >= 64) return "hidden size 8..63";
+    const bool two_heads = d.D == 64 && ad->H == 2 && ad->d == 32;   // (C3's shape: the bias gradients come from an all-ones product there)
+    if (!two_heads && (d.D < 8 || d.D >= 64)) return "hidden size 8..63 (one head), or 64 with two heads of 32";
     if (precision != CR_PREC_BF16X3 && precision != CR_PREC_BF16) return "bf16 arithmetic (precision) only";
     if (B < 1 || T < 1 || d.M != B * T) return "M = B T";
     if ((T + 15) / 16 > 2 * SB_TPR) return "T <= 224 (two rounds of 7 row tiles)";
     if ((size_t)d.M * d.D * 4 >= ((size_t)1 << 32)) return "activations of 4 GiB or more (32-bit row offsets)";
     if (bd->n_slabs < 1) return "n_slabs";
-    if (ad->H != 1 || ad->d != d.D || ad->B != B || ad->T != T) return "one head of d = D, the block's B and T";
+    if (!two_heads && (ad->H != 1 || ad->d != d.D)) return "one head of d = D (or two heads of 32 at D = 64)";
+    if (ad->B != B || ad->T != T) return "the block's B and T";
     if (ad->ld != d.D || ad->Q != d.qkv || ad->K != d.qkv + (size_t)d.M * d.D || ad->V != d.qkv + 2 * (size_t)d.M * d.D) return "Q / K / V = the parts of the block's qkv";
     if (ad->residual != d.q_in || ad->out != d.o || ad->k_valid != d.k_valid || ad->q_valid != d.q_valid) return "the attention call of this block (residual = q_in, out = o, masks)";
     if (!ad->row_stats) return "row_stats (saved by the forward)";
@@ -1245,15 +1296,15 @@ extern "C" int cr_stack_block_bwd_supported(const cr_block_bwd_desc* bd, const c
     return b1_unsupported(bd, ad, B, T, precision) == nullptr;
 }
 
-template <bool SPLIT, int DS>
+template <bool SPLIT, int DS, int HD = 1>
 static int launch_b1(B1Args& a, int nwg, hipStream_t s) {
     static cr_devmask attr = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_block_bwd<SPLIT, DS>), &attr);
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_block_bwd<SPLIT, DS, HD>), &attr);
     if (rc) return rc;
     for (int n0 = 0; n0 < a.B; n0 += nwg) {               // more sequences than slabs: further launches add to the slabs
         a.n0 = n0;
         a.add = n0 > 0;
-        hipLaunchKernelGGL((k_stack_block_bwd<SPLIT, DS>), dim3(a.B - n0 < nwg ? a.B - n0 : nwg, 2), dim3(SB_NT), B1Lds<SPLIT>::BYTES, s, a);
+        hipLaunchKernelGGL((k_stack_block_bwd<SPLIT, DS, HD>), dim3(a.B - n0 < nwg ? a.B - n0 : nwg, 2), dim3(SB_NT), B1Lds<SPLIT>::BYTES, s, a);
     }
     return cr_check_launch("cr_stack_block_bwd");
 }
@@ -1329,6 +1380,7 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     // the hidden size as a compile-time constant where it is a common one (column-tile predicates fold: 240 .. 255 registers, no
     // scratch); any other size runs the generic instantiation (live predicates: it spills -- see DESIGN.md section 4)
     switch (d->D) {
+    case 64: return split ? launch_b1<true, 64, 2>(a, nwg, s) : launch_b1<false, 64, 2>(a, nwg, s);      // two heads of 32 columns
     case 50: return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
     case 32: return split ? launch_b1<true, 32>(a, nwg, s) : launch_b1<false, 32>(a, nwg, s);
     case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);

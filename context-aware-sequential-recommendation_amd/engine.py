@@ -749,7 +749,7 @@ class Engine:
             rows_bf = bool(self.fuse_stack_bwd and bf and not one_pass and L.lib.cr_stack_bwd_supported(C.byref(bbd), B, T, prec))
             # ... and where the whole block fits one launch (cr_stack_bwd1.hip: one head, D < 64): ffn_bwd -> attn_bwd -> qkv_bwd per
             # sequence on a pair of workgroups; the input gradient leaves as two partials (dx, dx2)
-            if (rows_bf and self.fuse_block_bwd and H == 1
+            if (rows_bf and self.fuse_block_bwd and (H == 1 or (H == 2 and D == 64))
                     and L.lib.cr_stack_block_bwd_supported(C.byref(bbd), C.byref(abd.f), B, T, prec)):
                 dx2 = self.buf(pfx + "dx2", D)
                 dy2 = self._second_grad(y)
