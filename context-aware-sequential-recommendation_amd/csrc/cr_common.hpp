@@ -88,18 +88,23 @@ struct DropCtx {
     float scale;
     bool on;
 };
-__device__ __forceinline__ DropCtx drop_ctx(const cr_rng& r) {
+// stepv: the value of *r.step.  A kernel whose prologue is on its critical path requests it at its very start (cr_step_request)
+// and builds the contexts where they are first needed: `*r.step` at the point of use is a vector load and a full vmcnt(0) wait there
+// (0.6-0.7 us at the head of the block backward, tools/b1_ts.py; again in front of each side's attention loop).
+__device__ __forceinline__ DropCtx drop_ctx(const cr_rng& r, uint32_t stepv) {
     DropCtx c;
     c.on = r.rate > 0.0f;
     c.key = 0; c.thresh = 0; c.scale = 1.0f;
     if (c.on) {
-        c.key = cr_site_key(r.seed, *r.step, r.site);
+        c.key = cr_site_key(r.seed, stepv, r.site);
         double t = (double)r.rate * 4294967296.0;
         c.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
         c.scale = 1.0f / (1.0f - r.rate);
     }
     return c;
 }
+__device__ __forceinline__ uint32_t cr_step_request(const cr_rng& r) { return r.rate > 0.0f ? *r.step : 0u; }
+__device__ __forceinline__ DropCtx drop_ctx(const cr_rng& r) { return drop_ctx(r, cr_step_request(r)); }
 __device__ __forceinline__ float drop_apply(const DropCtx& c, uint32_t idx, float v) {
     return c.on ? (cr_keep(c.key, idx, c.thresh) ? v * c.scale : 0.0f) : v;
 }

@@ -141,6 +141,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             if (a.e.addend) r_issue(xd, a.e.addend, (u32)(base_row + t) * (u32)(4 * a.e.ld_add), dcx);
         }
     };
+    // the step counter behind the embedding dropout's key: requested first, used in phase A (see drop_ctx)
+    const uint32_t sv_e = a.gather ? cr_step_request(a.e.drop) : 0u;
     {
         const cr_block_desc& d = a.blk[0].bd;
         w_issue<2, NT>(wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         const cr_block_desc& d = a.blk[b].bd;
         const cr_attn_desc& ad = a.blk[b].ad;
         const bool last = b == a.nb - 1;
+        // (the block's step counters: requested here, used behind barrier B2)
+        const uint32_t sv_a = cr_step_request(ad.drop), sv_1 = cr_step_request(d.drop_ffn1), sv_2 = cr_step_request(d.drop_ffn2);
         {
             w_put<2, NT, SPLIT>(Wi, wa, D, d.wqkv, 3 * D, D, d.wqkv, 3 * D, 2 * D, d.wqkv, 3 * D, 2 * D);
             vec_put<NT>(vec, vv);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                 for (int ct = 0; ct < 4; ++ct) { pv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; av[ct] = pv[ct]; }
                 if (e.pos_table) r_finish(pv, xp, dcx);
                 if (e.addend) r_finish(av, xd, dcx);
-                const DropCtx dce = drop_ctx(e.drop);
+                const DropCtx dce = drop_ctx(e.drop, (uint32_t)__builtin_amdgcn_readfirstlane(sv_e));
                 const uint32_t eb = ((e.drop.row_offset + (uint32_t)m) * (uint32_t)D + (uint32_t)(4 * lg)) * CR_PHI + dce.key;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
@@ -251,8 +255,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         SK_TS(5 + 10 * b);
         const int fvk = first_valid_key_lds(kb, a.T16, T);
         const int kt_first = min(fvk >> 4, NKT - 1);      // tiles below hold no valid key: probabilities exactly 0
-        const DropCtx dc = drop_ctx(ad.drop);
-        const DropCtx d1 = drop_ctx(d.drop_ffn1), d2 = drop_ctx(d.drop_ffn2);
+        const DropCtx dc = drop_ctx(ad.drop, (uint32_t)__builtin_amdgcn_readfirstlane(sv_a));
+        const DropCtx d1 = drop_ctx(d.drop_ffn1, (uint32_t)__builtin_amdgcn_readfirstlane(sv_1)), d2 = drop_ctx(d.drop_ffn2, (uint32_t)__builtin_amdgcn_readfirstlane(sv_2));
         // ---- phase B + C per tile: LN1, Q, attention core, then LN2 + feed-forward on the rows in registers -----
 #pragma unroll 1
         for (int i = 0; i < nB; ++i) {

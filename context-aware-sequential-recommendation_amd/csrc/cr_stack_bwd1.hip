@@ -125,30 +125,66 @@ __device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, 
         if (BIAS && it == 0 && lg == 0 && col < D) bias_dst[col] = add ? bias_dst[col] + accb[j][0] : accb[j][0];
     }
 }
-// LayerNorm column sums: per-lane partials -> sums over the wave's 16 rows -> the wave's LDS slot (+=: a wave folds once per
-// tile); b1_ln_flush adds the eight slots in wave order
-// SET: the wave's only fold -- the slot is written, not added to (no zeroing pass, no barrier in front)
-template <bool SET = false>
+// LayerNorm column sums: per-lane partials (the lane's row, 16 columns, two arrays) -> sums over the wave's 16 rows -> the wave's LDS
+// slot; b1_ln_flush adds the slots in a fixed order.  The 32 values of a lane are reduced over the 16 lanes of its DPP row by a
+// TRANSPOSING butterfly: every step halves the values a lane carries (it keeps one half and adds the partner's copy of that half), so
+// the four steps cost 32 + 16 + 12 + 6 vector instructions instead of 32 full row sums of four DPP adds each, and every lane ends
+// with two adjacent columns' totals: one 8-byte LDS write per lane, no lane predicate.  (The first form -- 32 row sums, 32 single-lane
+// read-modify-writes of the slot -- took 1.4-2.2 us per tile on the query side's row chain: tools/b1_ts.py.)
+//   step 1: partner 15 - i (row_mirror), kept by bit 3 of the lane: the sums with xhat (ag) / the plain sums (ab)
+//   step 2: partner 7 - i of the half (row_half_mirror), kept by bit 2: column tiles 0, 1 / 2, 3
+//   steps 3, 4: partner 3 - i, then i ^ 1 of the quad, kept by bits 1, 0: the column tile of the two, registers 0, 1 / 2, 3
+// Steps 1 and 2 are `v_add_f32_dpp` with a bank mask (banks = the row's four quads: exactly bits 3 / 2 of the lane), in place; the
+// compiler does not form masked DPP adds, hence the assembly (s_nop 1: a DPP source written by the previous instruction needs two
+// wait states, and the hazard recogniser does not look inside an asm statement).
+// Every (wave, tile-of-the-wave) has a slot of its own: slots are WRITTEN (no zeroing pass in front, no read-modify-write); a slot that
+// no fold reaches must have been zeroed by the caller.
 __device__ __forceinline__ void b1_ln_fold(float* part, const f32x4 (&ag)[4], const f32x4 (&ab)[4]) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
+    const int lane = lane_now(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lg = lane >> 4;
+    float u[16];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sg = cr_row16_sum(ag[ct][r]), sb = cr_row16_sum(ab[ct][r]);
-            if (li == 0) {
-                float* pg = part + wave * 64 + 16 * ct + 4 * lg + r;
-                float* pb = part + (SB_WAVES + wave) * 64 + 16 * ct + 4 * lg + r;
-                *pg = SET ? sg : *pg + sg;
-                *pb = SET ? sb : *pb + sb;
-            }
+            float x = ag[ct][r];
+            asm volatile("s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+                         "v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc"
+                         : "+v"(x) : "v"(ab[ct][r]));
+            u[4 * ct + r] = x;
         }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa"
+                     : "+v"(u[j]) : "v"(u[8 + j]));
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float w[4], z[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b1 ? u[4 + j] : u[j], send = b1 ? u[j] : u[4 + j];
+        w[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x1B, 0xF, 0xF, false));     // quad_perm [3,2,1,0]
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b0 ? w[2 + j] : w[j], send = b0 ? w[j] : w[2 + j];
+        z[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    }
+    // the lane's two totals: array = bit 3, column 16 (2 bit2 + bit1) + 4 lg + 2 bit0 (+ 1)
+    const int col = 16 * (((lane >> 2) & 1) * 2 + ((lane >> 1) & 1)) + 4 * lg + 2 * (lane & 1);
+    float* dst = part + ((lane & 8) ? SB_WAVES * 64 : 0) + wave * 64 + col;
+    *reinterpret_cast<float2*>(dst) = make_float2(z[0], z[1]);
 }
+// NSET slot sets ([2][SB_WAVES][64] floats each, one behind the other)
+template <int NSET = 1>
 __device__ __forceinline__ void b1_ln_flush(const float* part, float* dg, float* db, int D, bool add) {
     for (int c = threadIdx.x; c < D; c += SB_NT) {
         float g = 0.0f, b = 0.0f;
 #pragma unroll
-        for (int w = 0; w < SB_WAVES; ++w) { g += part[w * 64 + c]; b += part[(SB_WAVES + w) * 64 + c]; }
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+            for (int w = 0; w < SB_WAVES; ++w) { g += part[(2 * s * SB_WAVES + w) * 64 + c]; b += part[((2 * s + 1) * SB_WAVES + w) * 64 + c]; }
         dg[c] = add ? dg[c] + g : g;
         db[c] = add ? db[c] + b : b;
     }
@@ -157,12 +193,14 @@ __device__ __forceinline__ void b1_ln_flush(const float* part, float* dg, float*
 // =====================================================================================================
 // phase 1: LN2 + feed-forward backward of every tile of sequence n (both sides)
 // =====================================================================================================
+// the step counter behind each dropout site's key (wave-uniform; requested at the kernel's start, see drop_ctx)
+struct B1Steps { uint32_t ffn2, attn, emb; };
 struct B1Acc { f32x4 aw1[2], aw2[2], aw1b[2], aw2b[2], ag[4], ab[4], agF[4], abF[4]; };   // Q side: what phase 1 leaves in registers (aw?b: bias sums at D = 64)
 
 // before_last_products: called by the query side in its last round between the chain and the barrier in front of the round's weight
 // gradients (the phase-2 staging's loads go out there: their latency passes under the products)
 template <bool SPLIT, int DS, bool QSIDE, int HD, class F>
-__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, F&& before_last_products) {
+__device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, B1Steps& steps, F&& before_last_products) {
     constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
@@ -175,11 +213,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     const int D = DS > 0 ? DS : d.D, T = a.T;
     const DCtx dcx = d_ctx(D);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const DropCtx d2 = drop_ctx(d.drop_ffn2);
+    // the step counters: requested first of all, used behind the barrier that opens the phase
+    uint32_t sv_ffn2 = cr_step_request(d.drop_ffn2), sv_attn = cr_step_request(a.ad.drop), sv_emb = a.scatter ? cr_step_request(a.sc.f.drop) : 0u;
     const float scale1 = (d.drop_ffn1.rate > 0.0f) ? 1.0f / (1.0f - d.drop_ffn1.rate) : 1.0f;
-#ifdef CR_TIMELINE
-    asm volatile("" :: "v"(scale1), "s"(d2.key));
-#endif
     B1_TS(13);
     f32x4 (&aw1)[2] = A.aw1; f32x4 (&aw2)[2] = A.aw2; f32x4 (&ag)[4] = A.ag; f32x4 (&ab)[4] = A.ab; f32x4 (&agF)[4] = A.agF; f32x4 (&abF)[4] = A.abF;
     f32x4 (&aw1b)[2] = A.aw1b; f32x4 (&aw2b)[2] = A.aw2b;
@@ -249,6 +285,8 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     __syncthreads();
     B1_TS(1);
     issue_b(0);                                                    // ... the second half behind it, under the chain's first product
+    steps.ffn2 = __builtin_amdgcn_readfirstlane(sv_ffn2); steps.attn = __builtin_amdgcn_readfirstlane(sv_attn); steps.emb = __builtin_amdgcn_readfirstlane(sv_emb);
+    const DropCtx d2 = drop_ctx(d.drop_ffn2, steps.ffn2);
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
         const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);          // tiles of this round (wave-uniform)
@@ -358,21 +396,30 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             }
         }
         if (rd + 1 < R) {
+            B1_TS(24);
+            // (the next round's rows are requested in FRONT of the barrier: a CU's 7 x 35 requests are 1.6 us of its address pipeline and
+            //  block the issuing wave wherever they stand; here the waves that end their chains first issue while the others compute.
+            //  Behind the barrier -- all waves at once -- the round came out 0.6 us longer: tools/b1_ts.py.)
             issue(rd + 1);
             if (QSIDE) {
                 __syncthreads();
+                B1_TS(25);
                 wgrad_accum<SPLIT, BIAS>(aw2, aw2b, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                          // dW2 (+ db2) += hid^T g2
                 wgrad_accum<SPLIT, BIAS>(aw1, aw1b, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);  // dW1 (+ db1) += f_in^T g1
+                B1_TS(26);
                 __syncthreads();
+                B1_TS(27);
             }
         }
     }
     // the last round's products stand behind the loop: what the caller requests in front of them (the query side: phase 2's K / V
     // rows and Wq) has its addresses formed HERE, not hoisted in front of the round loop and carried through the chains
+    B1_TS(28);
     before_last_products();
     if (QSIDE) {
         const int ntr = min(SB_TPR, a.nkt - (R - 1) * SB_TPR);
         __syncthreads();
+        B1_TS(10);
         wgrad_accum<SPLIT, BIAS>(aw2, aw2b, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);
         wgrad_accum<SPLIT, BIAS>(aw1, aw1b, Im + 2 * IST, Im + 2 * IST + SB_IMG, Im + 3 * IST, Im + 3 * IST + SB_IMG, ntr, it, jt0);
         __syncthreads();
@@ -388,9 +435,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
 
 // ---- the embedding backward of a partial of dx, phase-2 half: g = partial * mask * keep / (1 - rate) in the registers ----
 // (cr_embed_bwd's recipe; the rows then wait in `buf` -- d_addend where the graph has one, else the dx buffer -- for phase 3)
-__device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4], int m, bool rok, int D) {
+__device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4], int m, bool rok, int D, uint32_t step_emb) {
     const cr_embed_desc& e = a.sc.f;
-    const DropCtx dce = drop_ctx(e.drop);
+    const DropCtx dce = drop_ctx(e.drop, step_emb);
     const int lg = lane_now() >> 4;
     const int mk = e.mask_ids ? e.mask_ids[m] : 1;
     const float kf = (rok && mk != 0) ? 1.0f : 0.0f;
@@ -558,7 +605,7 @@ __device__ __forceinline__ void b1_q_stage_issue(const B1Args& a, int n, B1Stage
 }
 
 template <bool SPLIT, int DS, int HD>
-__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, B1Stage& stg, WRegs<1, SB_NT>& w) {
+__device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, const B1Steps& steps, B1Stage& stg, WRegs<1, SB_NT>& w) {
     constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
@@ -591,13 +638,13 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         b1_stage_kv_put<SPLIT>(stg, smem, kb, a, base_row, T16, D, M);
         w_put_perm<1, SB_NT, SPLIT>(Wi, w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
         if (threadIdx.x < 64) gam[threadIdx.x] = gv;      // (gamma2 is dead behind phase 1's last barrier)
-        for (int i = threadIdx.x; i < 2 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;
+        for (int i = threadIdx.x; i < 4 * SB_WAVES * 64; i += SB_NT) part[i] = 0.0f;      // (PART and PARTF: the folds of a wave's first / second tile)
         (void)partF;
     }
     __syncthreads();
     B1_TS(3);
-    const int kt_first = first_valid_key_lds(kb, T16, T) >> 4;
-    const DropCtx dc = drop_ctx(d.drop);
+    const int kt_first = __builtin_amdgcn_readfirstlane(first_valid_key_lds(kb, T16, T) >> 4);     // (a scalar: the pair loop's counter and its branches are)
+    const DropCtx dc = drop_ctx(d.drop, steps.attn);
     // per-lane byte offsets of the operand reads at tile 0 of an image (img_off: the swizzle term (row & 6) does not depend on
     // the tile, so a tile adds 2048 bytes)
     const int frk0 = 2 * img_off<2>(li, lg), frk1 = 2 * img_off<2>(li, lg + 4);
@@ -801,7 +848,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         // columns of dx differ between runs of the same step (tools/diag_repro.py) -- not understood, not kept
         if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));
         r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
-        b1_ln_fold(part, ag, ab);
+        b1_ln_fold(part + ti * (2 * SB_WAVES * 64), ag, ab);       // (the wave's first tile: PART, its second: PARTF)
         if (ar.bd.dx_accumulate) {
             f32x4 old[4];
             r_finish(old, rdx, dcx);
@@ -809,7 +856,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
             for (int ct = 0; ct < 4; ++ct) dxl[ct] += old[ct];
         }
         if (ar.scatter) {
-            b1_scatter_prep(ar, dxl, m, rok, D);
+            b1_scatter_prep(ar, dxl, m, rok, D, steps.emb);
             r_store(ar.sbuf, mo, dxl, rok, dcx);
         } else {
             r_store(ar.bd.dx, mo, dxl, rok, dcx);
@@ -857,7 +904,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
-    b1_ln_flush(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
+    b1_ln_flush<2>(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
     B1_TS(18);
     if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part + partF: 8 x 224 list entries)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
@@ -869,7 +916,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 // K side, phases 2 and 3: key-owner pass (dK, dV), K / V projections backward, dWk dWv
 // =====================================================================================================
 template <bool SPLIT, int DS, int HD>
-__device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A) {
+__device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, const B1Steps& steps) {
     constexpr bool BIAS = DS == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
@@ -890,7 +937,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     float* dVg = const_cast<float*>(bd.dqkv) + 2 * MD;
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
     // ---- phase 2 staging: row statistics of every query row; Wk, Wv over W1, W2 ----
-    const DropCtx dc = drop_ctx(d.drop);
+    const DropCtx dc = drop_ctx(d.drop, steps.attn);
     {
         WRegs<2, SB_NT> w;
         w_issue<2, SB_NT>(w, D, bk.wqkv, 3 * D, D, bk.wqkv, 3 * D, 2 * D, bk.wqkv, 3 * D, 2 * D);
@@ -903,8 +950,8 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             // dgamma2 dbeta2 (+ the final LayerNorm's sums) of this side's phase 1: every wave WRITES its slots (its accumulators cover all
             // its tiles; a wave without a tile writes zeros), one barrier, flush
             float* part = fl + L::PART; float* partF = fl + L::PARTF;
-            b1_ln_fold<true>(part, A.ag, A.ab);
-            if (a.has_ln) b1_ln_fold<true>(partF, A.agF, A.abF);
+            b1_ln_fold(part, A.ag, A.ab);
+            if (a.has_ln) b1_ln_fold(partF, A.agF, A.abF);
             __syncthreads();                              // phase 1 is over in every wave: W1 / W2 are dead, sdel is complete, the folds are visible
             const size_t so = (size_t)blockIdx.x * bd.slab_stride;
             b1_ln_flush(part, bd.g_ln2_g + so, bd.g_ln2_b + so, D, add);
@@ -1159,7 +1206,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             r_gemm_t<SPLIT, true>(dxp, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
         }
         if (ar.scatter) {
-            b1_scatter_prep(ar, dxp, m, rok, D);
+            b1_scatter_prep(ar, dxp, m, rok, D, steps.emb);
             r_store(ar.sbuf2, mo, dxp, rok, dcx);
         } else {
             r_store(ar.dx2, mo, dxp, rok, dcx);
@@ -1230,14 +1277,16 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
     const int n = a.n0 + (int)blockIdx.x;
     if (blockIdx.y == 0) {
         B1Acc acc;
-        b1_phase1<SPLIT, DS, false, HD>(a, smem_raw, n, acc, [] {});
-        b1_k_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc);
+        B1Steps steps;
+        b1_phase1<SPLIT, DS, false, HD>(a, smem_raw, n, acc, steps, [] {});
+        b1_k_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc, steps);
     } else {
         B1Acc acc;
         B1Stage st;
         WRegs<1, SB_NT> w;
-        b1_phase1<SPLIT, DS, true, HD>(a, smem_raw, n, acc, [&] { b1_q_stage_issue<DS>(a, n, st, w); });
-        b1_q_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc, st, w);
+        B1Steps steps;
+        b1_phase1<SPLIT, DS, true, HD>(a, smem_raw, n, acc, steps, [&] { b1_q_stage_issue<DS>(a, n, st, w); });
+        b1_q_side<SPLIT, DS, HD>(a, smem_raw, n, a.add != 0, acc, steps, st, w);
     }
     B1_TS(31);
 }

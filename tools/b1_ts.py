@@ -50,11 +50,22 @@ for side, sname in ((0, "K side (blockIdx.y = 0)"), (1, "Q side (blockIdx.y = 1)
     for wave in range(8):
         rel = lambda k: np.median((tt[full, wave, k] - tt[full, wave, 30])) / mhz
         print("     wave %d: %5.2f | %5.2f | %5.2f | %5.2f" % (wave, rel(11), rel(12), rel(1), rel(2)))
+    print("   phase 1 per wave, us from the phase's opening barrier: first chain done | barrier passed | products done | barrier | last chain done | barrier | products done")
+    for wave in range(8):
+        rel1 = lambda k: np.median((tt[full, wave, k] - tt[full, wave, 1])) / mhz
+        print("     wave %d: " % wave + " | ".join("%5.2f" % rel1(k) for k in ((24, 25, 26, 27, 28, 10, 2) if side == 1 else (24, 28, 2))))
+    print("   attention phase per wave, us from the staging's last barrier: first loop done | first chain done | second tile done | barrier passed")
+    for wave in range(8):
+        def rel3(k):
+            v = tt[full, wave, k] - tt[full, wave, 3]
+            v = v[tt[full, wave, k] > 0]
+            return np.median(v) / mhz if len(v) else float("nan")
+        print("     wave %d: " % wave + " | ".join("%5.2f" % rel3(k) for k in (6, 8, 4, 7)))
     for wave in (0, 3, 7):
         print(" -- wave %d, full-length sequences" % wave)
         prev = tt[full, wave, 0] * 0 + np.nan
-        order = [30, 15, 13, 14, 11, 12, 1, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 20, 21, 22, 23, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 20, 21, 22, 23, 5, 29]
-        names[29] = "end (scatter issue)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table: slab written)"; names[20] = "small table: ids requested, barrier"; names[21] = "small table: image zeroed, lists, barrier"; names[22] = "small table: rows added"; names[23] = "small table: barrier"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
+        order = [30, 15, 13, 14, 11, 12, 1, 24, 25, 26, 27, 28, 10, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 20, 21, 22, 23, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 24, 28, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 20, 21, 22, 23, 5, 29]
+        names[29] = "end (scatter issue)"; names[24] = "phase 1: first round's chain"; names[25] = "phase 1: next rows requested, barrier"; names[26] = "phase 1: first round's weight-gradient products"; names[27] = "phase 1: barrier"; names[28] = "phase 1: last round's chain"; names[10] = "phase 1: phase-2 loads requested, barrier"; names[2] = "phase 1: last products (+ barrier, query side)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table: slab written)"; names[20] = "small table: ids requested, barrier"; names[21] = "small table: image zeroed, lists, barrier"; names[22] = "small table: rows added"; names[23] = "small table: barrier"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
         base = None
         for k in order:
             cur = tt[full, wave, k]

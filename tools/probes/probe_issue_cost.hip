@@ -1,0 +1,49 @@
+// Issue cost of single vector instructions on gfx950 (one wave per SIMD, and two): cycles per instruction of a long run of
+// independent instances.  Question behind it (round 4): what the 32-bit integer multiply of the dropout hash costs beside the
+// plain VALU instructions around it.   build: hipcc --offload-arch=gfx950 -O2 -o probe_issue_cost probe_issue_cost.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define REP16(x) x x x x x x x x x x x x x x x x
+#define BODY(name, ins)                                                                                          \
+    __global__ void name(unsigned long long* out, int iters) {                                                  \
+        unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 0x9E3779B9u + threadIdx.x;          \
+        float f0 = a0, f1 = a1, f2 = a2, f3 = a3;                                                                \
+        asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));                                               \
+        const unsigned long long t0 = clock64();                                                                \
+        for (int i = 0; i < iters; ++i) {                                                                        \
+            asm volatile(REP16(ins) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(b)); \
+        }                                                                                                        \
+        const unsigned long long t1 = clock64();                                                                \
+        if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;          \
+        if (a0 + a1 + a2 + a3 == 0x12345u && f0 + f1 + f2 + f3 == 1.5f) out[0] = 0;                              \
+    }
+BODY(k_add, "v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n")
+BODY(k_mullo, "v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n")
+BODY(k_mul24, "v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n")
+BODY(k_mad24, "v_mad_u32_u24 %0, %0, %8, %1\n v_mad_u32_u24 %1, %1, %8, %2\n v_mad_u32_u24 %2, %2, %8, %3\n v_mad_u32_u24 %3, %3, %8, %0\n")
+BODY(k_exp, "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n")
+BODY(k_fma, "v_fma_f32 %4, %4, %5, %6\n v_fma_f32 %5, %5, %6, %7\n v_fma_f32 %6, %6, %7, %4\n v_fma_f32 %7, %7, %4, %5\n")
+BODY(k_bfe, "v_bfe_i32 %0, %8, 3, 1\n v_bfe_i32 %1, %8, 4, 1\n v_bfe_i32 %2, %8, 5, 1\n v_bfe_i32 %3, %8, 6, 1\n")
+BODY(k_cmpsel, "v_cmp_ge_u32 vcc, %0, %8\n v_cndmask_b32 %4, 0, %5, vcc\n v_cmp_ge_u32 vcc, %1, %8\n v_cndmask_b32 %6, 0, %7, vcc\n")
+BODY(k_xorshift, "v_lshrrev_b32 %1, 16, %0\n v_xor_b32 %0, %0, %1\n v_lshrrev_b32 %3, 16, %2\n v_xor_b32 %2, %2, %3\n")
+BODY(k_mulhi, "v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n")
+BODY(k_cvtpk, "v_cvt_pk_bf16_f32 %0, %4, %5\n v_cvt_pk_bf16_f32 %1, %5, %6\n v_cvt_pk_bf16_f32 %2, %6, %7\n v_cvt_pk_bf16_f32 %3, %7, %4\n")
+BODY(k_dpp, "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n")
+typedef void (*K)(unsigned long long*, int);
+int main() {
+    unsigned long long* out; (void)hipMalloc(&out, 4096 * 8);
+    struct { const char* n; K k; } ks[] = {{"v_add_u32", k_add}, {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_u32_u24", k_mul24}, {"v_mad_u32_u24", k_mad24},
+        {"v_exp_f32", k_exp}, {"v_fma_f32", k_fma}, {"v_bfe_i32", k_bfe}, {"v_cmp + v_cndmask (pair)", k_cmpsel}, {"v_lshrrev + v_xor (pair)", k_xorshift},
+        {"v_cvt_pk_bf16_f32", k_cvtpk}, {"v_add_f32_dpp", k_dpp}};
+    const int iters = 2000;
+    for (auto& e : ks)
+        for (int nt : {256, 512}) {       // one wave per SIMD, two waves per SIMD (one workgroup per CU: 64 workgroups)
+            hipLaunchKernelGGL(e.k, dim3(64), dim3(nt), 0, 0, out, iters);
+            hipLaunchKernelGGL(e.k, dim3(64), dim3(nt), 0, 0, out, iters);
+            (void)hipDeviceSynchronize();
+            unsigned long long h[8]; (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+            printf("%-28s %d waves/SIMD: %.2f clock64 ticks per instruction per wave\n", e.n, nt / 256, (double)h[1] / (iters * 64.0));
+        }
+    printf("(clock64 = s_memtime: 100 MHz on this part? compare with v_add_u32 = 4 shader cycles alone)\n");
+    return 0;
+}
