@@ -477,56 +477,119 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
     }
 }
 
-// Small-table form of the scatter (context tables of 8 .. 201 rows: cr_embed_bwd's small-table mode, its contract): thousands of
-// rows land in a handful of table rows, so float atomics would serialise on hot rows.  Each side reduces the waiting rows of
-// its partial into an LDS image of the table -- every table row has ONE owner wave (id mod 8): a wave scans the ids of 64
-// rows at a time, requests up to 16 of the rows it owns together (lane = column) and adds them with plain read-add-write --
-// and writes the image as its slab: slab blockIdx.x (Q side) or gridDim.x + blockIdx.x (K side).  Runs last: the image area is free.
-__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* lst, const float* buf, int n, int D, bool add) {
+// Small-table form of the scatter (context tables of 8 .. 256 rows: cr_embed_bwd's small-table mode, its contract): thousands of
+// rows land in a handful of table rows, so float atomics would serialise on hot rows.  Each side forms its partial's table
+// gradient as ONE matrix product, tab = OneHot^T G: G = the waiting rows of the sequence ([T][D], bf16 hi + lo images in layout W,
+// read transposed as the B operand), OneHot[row][id] = (ids[row] == id) built in registers from the ids in LDS as the A operand
+// (exact in bf16), k = the sequence's rows.  Wave w owns table rows 16 w .. and 16 (w + 8) ..; the accumulators go straight to the
+// side's slab: slab blockIdx.x (Q side) or gridDim.x + blockIdx.x (K side).  Runs last: the image area is free.
+// (The first form -- every table row owned by one wave, which added its rows to an LDS image of the table by read-add-write, then
+//  the image copied to the slab -- cost 9 us of the launch: 4.4 of them the serial chain of LDS updates; ds_add_f32 was slower
+//  still, ~1100 clocks per atomic.  G in two bf16 terms: 2^-17 relative per element, the arithmetic class of the weight gradients.)
+template <bool SPLIT>
+__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* ids_lds, const float* buf, int n, int D, bool add) {
     const cr_embed_desc& e = a.sc.f;
-    float* tab = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T;
-    const int nt = e.V * D;
-    // ids of all rows of the sequence (T <= 224: four per lane), requested before the image is zeroed
-    int id4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) id4[j] = (lane + 64 * j < T) ? e.ids[n * T + lane + 64 * j] : 0;
+    __bf16* Gh = reinterpret_cast<__bf16*>(smem);
+    __bf16* Gl = Gh + B1_FSTR;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T, nkt = a.nkt;
+    const DCtx dcx = d_ctx(D);
+    // the wave's rows (tiles w and w + 8, as in phase 3) and the thread's id, requested before the barrier
+    RRaw r0, r1;
+    const int tt0 = wave, tt1 = wave + SB_WAVES;
+    {
+        const int li = lane_now() & 15;
+        if (tt0 < nkt) r_issue(r0, buf, (u32)(n * T + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt0 + li < T);
+        if (tt1 < nkt) r_issue(r1, buf, (u32)(n * T + min(16 * tt1 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt1 + li < T);
+    }
+    const int t = threadIdx.x;
+    const int my_id = (t < T) ? e.ids[n * T + t] : -1;
     __syncthreads();                                      // the weight-gradient images are dead
     B1_TS(20);
-    for (int i = threadIdx.x; i < (nt + 3) >> 2; i += SB_NT) *reinterpret_cast<float4*>(tab + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the rows this wave owns (table row id mod 8 == wave), compacted into the wave's list: entry = row | id << 8
-    int* mine_lst = lst + wave * B1_ROWS;
-    int count = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = lane + 64 * j, id = id4[j];
-        const bool mine = row < T && !(e.zero_pad && id == 0) && ((id & (SB_WAVES - 1)) == wave);
-        const unsigned long long mk = __ballot(mine ? 1 : 0);
-        if (mine) mine_lst[count + __popcll(mk & ((1ull << lane) - 1ull))] = row | (id << 8);
-        count += __popcll(mk);
-    }
-    __syncthreads();                                      // the image is zero everywhere
-    B1_TS(21);
-    constexpr int U = 32;
-    const bool col = lane < D;
-    for (int k0 = 0; k0 < count; k0 += U) {               // (wave-uniform) up to 32 rows in flight: one memory round trip for the ~T / 8 rows of a wave
-        float g[U];
-        int ent[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            ent[k] = (k0 + k < count) ? mine_lst[k0 + k] : 0;
-            g[k] = (k0 + k < count && col) ? buf[(size_t)(n * T + (ent[k] & 255)) * D + lane] : 0.0f;
+    if (t < B1_ROWS) ids_lds[t] = my_id;                  // rows beyond T: no table row
+    {
+        f32x4 g[4];
+        // (tiles beyond the sequence's last one, up to the 14 the k loop may touch, are written as zeros: 0 x NaN is NaN in the matrix pipe)
+        if (tt0 < 2 * SB_TPR) {
+            if (tt0 < nkt) r_finish(g, r0, dcx);
+            else { for (int ct = 0; ct < 4; ++ct) g[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            img_put<SPLIT>(Gh, Gl, 16 * tt0, g);
         }
+        if (tt1 < 2 * SB_TPR) {
+            if (tt1 < nkt) r_finish(g, r1, dcx);
+            else { for (int ct = 0; ct < 4; ++ct) g[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            img_put<SPLIT>(Gh, Gl, 16 * tt1, g);
+        }
+    }
+    __syncthreads();
+    B1_TS(21);
+    const int lane = lane_now(), li = lane & 15, lg = lane >> 4;
+    const int nit = (e.V + 15) >> 4;                      // table-row tiles (<= 16)
+    f32x4 acc[2][4];
 #pragma unroll
-        for (int k = 0; k < U; ++k)
-            if (k0 + k < count && col) tab[(ent[k] >> 8) * D + lane] += g[k] * e.scale;   // (ds_add_f32 instead of this read-add-write chain:
-                                                                                        //  12.8 us for the batch against 3.3 -- LDS float atomics run ~1100 clocks each)
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the lane's table row per tile; the padding row takes nothing (cr_embed_bwd: zero_pad)
+    int target[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        target[i] = 16 * (wave + SB_WAVES * i) + li;
+        if (e.zero_pad && target[i] == 0) target[i] = -2;
+    }
+    if (wave < nit) {
+        const int nks = (nkt + 1) >> 1;                   // k-steps of 32 rows
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            // k slot j of lane group lg: row 32 ks + 4 lg + j (j < 4), row 32 ks + 16 + 4 lg + (j - 4) -- the order of the transposed reads
+            const int4 ia = *reinterpret_cast<const int4*>(ids_lds + 32 * ks + 4 * lg);
+            const int4 ib = *reinterpret_cast<const int4*>(ids_lds + 32 * ks + 16 + 4 * lg);
+            const int idv[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+            bf8 bh[4], bl[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const bf4 h0 = tr4(Gh, 32 * ks, ct, lane), h1 = tr4(Gh, 32 * ks + 16, ct, lane);
+                bh[ct] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (SPLIT) {
+                    const bf4 l0 = tr4(Gl, 32 * ks, ct, lane), l1 = tr4(Gl, 32 * ks + 16, ct, lane);
+                    bl[ct] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (wave + SB_WAVES * i < nit) {          // (wave-uniform)
+                    bf8 oh;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) oh[j] = (idv[j] == target[i]) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        if (SPLIT) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh, bl[ct], acc[i][ct], 0, 0, 0);
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh, bh[ct], acc[i][ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
     }
     B1_TS(22);
-    __syncthreads();
     B1_TS(23);
+    // D[table row 16 it + 4 lg + r][column 16 ct + li] -> the slab ([V][D], every entry written: rows without an occurrence get 0)
     float* slab = a.sc.table_grad + (size_t)((blockIdx.y == 0 ? gridDim.x : 0) + blockIdx.x) * a.sc.slab_stride;
-    for (int i = threadIdx.x; i < nt; i += SB_NT) slab[i] = add ? slab[i] + tab[i] : tab[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = wave + SB_WAVES * i;
+        if (it < nit) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * it + 4 * lg + r, col = 16 * ct + li;
+                    if (row < e.V && col < D) {
+                        float* p = slab + (size_t)row * D + col;
+                        const float v = acc[i][ct][r] * e.scale;
+                        *p = add ? *p + v : v;
+                    }
+                }
+        }
+    }
 }
 
 // =====================================================================================================
@@ -906,7 +969,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
     b1_ln_flush<2>(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part + partF: 8 x 224 list entries)
+    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part: the sequence's ids)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
@@ -1260,7 +1323,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, awkb, D, it, jt0, add);
     b1_wstore<BIAS>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, awvb, D, it, jt0, add);
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
+    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
@@ -1394,8 +1457,8 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
         if (sc->n_slabs > 0) {
             // small-table mode (cr_embed_bwd's contract: every slab in use written, their sum is the gradient): two slabs per pair
             const int nw = B < bd->n_slabs ? B : bd->n_slabs;
-            CR_REQUIRE(sc->table_grad && !sc->pos_grad && (long long)e->V * d->D <= 12288 && sc->n_slabs >= 2 * nw,
-                       "cr_stack_block_bwd: small-table scatter needs table_grad, no pos_grad, V * D <= 12288 and n_slabs >= 2 * min(B, n_slabs of the block)");
+            CR_REQUIRE(sc->table_grad && !sc->pos_grad && e->V <= 256 && sc->n_slabs >= 2 * nw,
+                       "cr_stack_block_bwd: small-table scatter needs table_grad, no pos_grad, V <= 256 and n_slabs >= 2 * min(B, n_slabs of the block)");
             a.small = 1;
         }
         CR_REQUIRE(sc->d_addend == nullptr || (e->ld_add == d->D && x->d_addend2 != nullptr), "cr_stack_block_bwd: d_addend must be dense [M, D] and come with d_addend2");

@@ -372,7 +372,7 @@ class Engine:
         # (a small context table: only cr_stack_block_bwd takes it -- reduced in LDS, written as slabs -- and only with two slabs
         #  per sequence pair to write to)
         if (out.data_ptr() in self._pending_embed and (addend is None or addend[0].shape[1] == D)
-                and (not small or (V * D <= 12288 and D <= 64 and pos is None and self.n_slabs >= 2 * min(self.B, self.n_slabs)))):
+                and (not small or (V <= 256 and D <= 64 and pos is None and self.n_slabs >= 2 * min(self.B, self.n_slabs)))):
             self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None, small, table)
 
         def factory():
