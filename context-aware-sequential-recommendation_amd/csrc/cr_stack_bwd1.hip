@@ -486,23 +486,28 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
 // (The first form -- every table row owned by one wave, which added its rows to an LDS image of the table by read-add-write, then
 //  the image copied to the slab -- cost 9 us of the launch: 4.4 of them the serial chain of LDS updates; ds_add_f32 was slower
 //  still, ~1100 clocks per atomic.  G in two bf16 terms: 2^-17 relative per element, the arithmetic class of the weight gradients.)
+// (The rows and ids are requested by b1_small_issue in front of phase 3's products: they are the side's own partial, complete and
+//  visible behind the barrier that ends the attention loops.)
+struct B1Small { RRaw r0, r1; int my_id; };
+__device__ __forceinline__ void b1_small_issue(B1Small& q, const B1Args& a, const float* buf, int n, int D) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T, li = lane_now() & 15;
+    const DCtx dcx = d_ctx(D);
+    const int tt0 = wave, tt1 = wave + SB_WAVES;          // the wave's rows: tiles w and w + 8
+    if (tt0 < a.nkt) r_issue(q.r0, buf, (u32)(n * T + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt0 + li < T);
+    if (tt1 < a.nkt) r_issue(q.r1, buf, (u32)(n * T + min(16 * tt1 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt1 + li < T);
+    q.my_id = ((int)threadIdx.x < T) ? a.sc.f.ids[n * T + threadIdx.x] : -1;
+}
 template <bool SPLIT>
-__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* ids_lds, const float* buf, int n, int D, bool add) {
+__device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* ids_lds, B1Small& q, int n, int D, bool add) {
     const cr_embed_desc& e = a.sc.f;
     __bf16* Gh = reinterpret_cast<__bf16*>(smem);
     __bf16* Gl = Gh + B1_FSTR;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T, nkt = a.nkt;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nkt = a.nkt;
     const DCtx dcx = d_ctx(D);
-    // the wave's rows (tiles w and w + 8, as in phase 3) and the thread's id, requested before the barrier
-    RRaw r0, r1;
+    RRaw& r0 = q.r0; RRaw& r1 = q.r1;
     const int tt0 = wave, tt1 = wave + SB_WAVES;
-    {
-        const int li = lane_now() & 15;
-        if (tt0 < nkt) r_issue(r0, buf, (u32)(n * T + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt0 + li < T);
-        if (tt1 < nkt) r_issue(r1, buf, (u32)(n * T + min(16 * tt1 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt1 + li < T);
-    }
     const int t = threadIdx.x;
-    const int my_id = (t < T) ? e.ids[n * T + t] : -1;
+    const int my_id = q.my_id;
     __syncthreads();                                      // the weight-gradient images are dead
     B1_TS(20);
     if (t < B1_ROWS) ids_lds[t] = my_id;                  // rows beyond T: no table row
@@ -538,8 +543,9 @@ __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* s
     }
     if (wave < nit) {
         const int nks = (nkt + 1) >> 1;                   // k-steps of 32 rows
-#pragma unroll 1
-        for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+        for (int ks = 0; ks < SB_TPR; ++ks) {             // (unrolled under a wave-uniform guard: several steps' reads in flight)
+            if (ks >= nks) break;
             // k slot j of lane group lg: row 32 ks + 4 lg + j (j < 4), row 32 ks + 16 + 4 lg + (j - 4) -- the order of the transposed reads
             const int4 ia = *reinterpret_cast<const int4*>(ids_lds + 32 * ks + 4 * lg);
             const int4 ib = *reinterpret_cast<const int4*>(ids_lds + 32 * ks + 16 + 4 * lg);
@@ -561,9 +567,9 @@ __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* s
 #pragma unroll
                     for (int j = 0; j < 8; ++j) oh[j] = (idv[j] == target[i]) ? (__bf16)1.0f : (__bf16)0.0f;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        if (SPLIT) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh, bl[ct], acc[i][ct], 0, 0, 0);
-                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh, bh[ct], acc[i][ct], 0, 0, 0);
+                    for (int ct = 0; ct < 4; ++ct) {              // tab^T tile: D[column 16 ct + 4 lg + r][table row 16 it + li] = layout R of the table's rows
+                        if (SPLIT) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ct], oh, acc[i][ct], 0, 0, 0);
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ct], oh, acc[i][ct], 0, 0, 0);
                     }
                 }
             }
@@ -571,25 +577,31 @@ __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* s
     }
     B1_TS(22);
     B1_TS(23);
-    // D[table row 16 it + 4 lg + r][column 16 ct + li] -> the slab ([V][D], every entry written: rows without an occurrence get 0)
+    // the accumulators are the table's rows in layout R (lane = table row 16 it + li): the slab ([V][D], every entry written: rows
+    // without an occurrence get 0) is stored like a tile of rows
     float* slab = a.sc.table_grad + (size_t)((blockIdx.y == 0 ? gridDim.x : 0) + blockIdx.x) * a.sc.slab_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int it = wave + SB_WAVES * i;
         if (it < nit) {
+            const int row = 16 * it + li;
+            const bool rok = row < e.V;
+            const u32 ro = (u32)min(row, e.V - 1) * (u32)(4 * D);
+            if (add) {
+                RRaw ro_;
+                f32x4 old[4];
+                r_issue(ro_, slab, ro, dcx, rok);
+                r_finish(old, ro_, dcx);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+                for (int ct = 0; ct < 4; ++ct) acc[i][ct] = old[ct] + acc[i][ct] * e.scale;
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * it + 4 * lg + r, col = 16 * ct + li;
-                    if (row < e.V && col < D) {
-                        float* p = slab + (size_t)row * D + col;
-                        const float v = acc[i][ct][r] * e.scale;
-                        *p = add ? *p + v : v;
-                    }
-                }
+                for (int ct = 0; ct < 4; ++ct) acc[i][ct] *= e.scale;
+            }
+            r_store(slab, ro, acc[i], rok, dcx);
         }
     }
+    (void)lg;
 }
 
 // =====================================================================================================
@@ -961,6 +973,8 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         r_finish(dQ, rg1, dcx);
         img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt1, dQ);
     }
+    B1Small small;
+    if (a.scatter && a.small) b1_small_issue(small, a, a.sbuf, n, D);
     __syncthreads();
     B1_TS(16);
     wgrad_accum<SPLIT, BIAS, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);       // dWq (+ dbq) += q_in^T dQ (nob: the bias sums at D = 64)
@@ -969,7 +983,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
     b1_ln_flush<2>(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(part), a.sbuf, n, D, add);   // (part: the sequence's ids)
+    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(part), small, n, D, add);   // (part: the sequence's ids)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
@@ -1297,6 +1311,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         }
     };
     issue3(0);
+    B1Small small;
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
         const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
@@ -1311,6 +1326,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, g);
         }
         issue3(rd + 1);
+        if (rd == R - 1 && a.scatter && a.small) b1_small_issue(small, a, a.sbuf2, n, D);     // (the small table's rows: under the last products)
         __syncthreads();
         if (rd == 0) B1_TS(16);
         wgrad_accum<SPLIT, BIAS>(awk, awkb, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
@@ -1323,7 +1339,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, awkb, D, it, jt0, add);
     b1_wstore<BIAS>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, awvb, D, it, jt0, add);
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(fl + L::PART), a.sbuf2, n, D, add);
+    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(fl + L::PART), small, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
