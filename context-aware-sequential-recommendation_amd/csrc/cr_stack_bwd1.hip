@@ -564,8 +564,11 @@ __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* s
             for (int i = 0; i < 2; ++i) {
                 if (wave + SB_WAVES * i < nit) {          // (wave-uniform)
                     bf8 oh;
+                    bool hit = false;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) oh[j] = (idv[j] == target[i]) ? (__bf16)1.0f : (__bf16)0.0f;
+                    for (int j = 0; j < 8; ++j) { const bool e1 = idv[j] == target[i]; hit |= e1; oh[j] = e1 ? (__bf16)1.0f : (__bf16)0.0f; }
+                    // (32 rows hold at most 32 ids: most of the 13 table-row tiles meet none of them -- an all-zero operand adds exactly nothing)
+                    if (__any(hit ? 1 : 0) == 0) continue;
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {              // tab^T tile: D[column 16 ct + 4 lg + r][table row 16 it + li] = layout R of the table's rows
                         if (SPLIT) acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ct], oh, acc[i][ct], 0, 0, 0);

@@ -346,13 +346,15 @@ int cr_stack_qkv_bwd_scatter(const cr_block_bwd_desc* d, const cr_embed_bwd_desc
  *     (or, with the final LayerNorm `lnf` as in cr_stack_ffn_bwd_ln: lnf->dy + x->lnf_dy2);
  *   - with `sc` (the embedding backward of the block input, as cr_stack_qkv_bwd_scatter): each side applies it to its partial:
  *     table / positional gradients by float atomics, the addend's gradient as sc->d_addend + x->d_addend2 (their sum); a
- *     small-table recipe (sc->n_slabs > 0, cr_embed_bwd's small-table mode) is reduced in LDS instead and leaves as slabs:
+ *     small-table recipe (sc->n_slabs > 0, cr_embed_bwd's small-table mode; here: V <= 256) is formed on chip instead -- one matrix
+ *     product per side, one-hot(ids)^T x the side's rows as bf16 hi + lo (2^-17 relative per element) -- and leaves as slabs:
  *     pair p writes slabs p and min(B, n_slabs) + p of sc->table_grad (sc->n_slabs >= 2 min(B, n_slabs) required);
  *   - d->d_o, d->dqkv ([3, M, D]) are workspaces here; d->attn_delta is not used (delta stays on chip);
  *   - ONE slab per sequence pair: workgroup pair p writes slab p (p < min(B, n_slabs)) and adds its later sequences to it;
  *     slabs >= min(B, n_slabs) are not written by this call.
  * `ad` is the block's attention call exactly as given to cr_attn_fwd / cr_stack_fwd (row_stats required).
- * Shapes (cr_stack_block_bwd_supported): one head, 8 <= D < 64, T <= 224, CR_PREC_BF16X3 or CR_PREC_BF16. */
+ * Shapes (cr_stack_block_bwd_supported): one head of d = D, 8 <= D < 64, or two heads of 32 columns at D = 64 (round 4; the bias
+ * gradients then come from an all-ones product); T <= 224; CR_PREC_BF16X3 or CR_PREC_BF16. */
 typedef struct {
     const float* dy2;                          /* optional [M,D] */
     float* dx2;                                /* [M,D] (may be NULL with `sc` when sc->d_addend is set) */

@@ -638,6 +638,15 @@ def test_graph_replay_equals_eager(E):
     assert la[0] == pytest.approx(lb[0], rel=1e-3) and b.step_number() == 5
 
 
+def same_loss_auc(a, b, pos, rel=2e-3):
+    """Loss to `rel`; the AUC (the fraction of target rows with pos logit > neg logit, sasrec.py:113-115) of two runs whose table
+    gradients were summed by float atomics in different orders may differ by ONE row whose two logits all but tie: 1 / n_targets."""
+    (la, aa), (lb, ab) = a.loss_auc(), b.loss_auc()
+    n_t = max(int((pos != 0).sum()), 1)
+    return la == pytest.approx(lb, rel=rel) and abs(aa - ab) <= 1.01 / n_t + rel * abs(ab)
+
+
+
 @pytest.mark.parametrize("lazy,graph", [(False, False), (False, True), (True, True), (None, True)])
 def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
     """Engine.use_id_ring: the batch of step k sits in ring slot k mod n_slots and the step before moves it into the static id
@@ -667,7 +676,7 @@ def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
     assert b.step_number() == first + 2 * NS + 1
     assert torch.equal(b.ids_all.cpu(), ring[b.step_number() % NS].cpu())       # the coming step's batch is in place
     nt = a.layout.n_table
-    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=2e-3)
+    assert same_run(a, b) and same_loss_auc(a, b, batches[(first + 2 * NS) % NS][1])
     b.P.copy_(a.P); b.Mom.copy_(a.Mom); b.Vel.copy_(a.Vel)
     b.use_id_ring(None)                                             # ... and back to a batch per call
     batch = make_batch(rs, B, T, itemnum, 20)
@@ -710,7 +719,7 @@ def test_fed_batches_train_like_batches_set_per_step(E, graph, n_slots):
     b.feed(*next(it)); b.train_fed()
     torch.cuda.synchronize()
     assert next(it, None) is None and b.step_number() == a.step_number() == 13
-    assert same_run(a, b) and a.loss_auc() == pytest.approx(b.loss_auc(), rel=2e-3)
+    assert same_run(a, b) and same_loss_auc(a, b, batches[-1][1])
     bad = list(batches[0]); bad[0] = bad[0].copy(); bad[0][1, -1] = itemnum + 1
     with pytest.raises(ValueError):
         b.feed(*bad)
