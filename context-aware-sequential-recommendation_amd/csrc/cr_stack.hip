@@ -252,6 +252,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         __syncthreads();                                  // B1: K / V / kb complete; Wk Wv no longer read
         w_put<3, NT, SPLIT>(Wi, wb, D, d.wqkv, 3 * D, 0, d.w1, D, 0, d.w2, D, 0);
         __syncthreads();                                  // B2
+        // (s_setprio 1 for the second-dispatched half of the waves, as in the block backward's attention loops: +4 us per step HERE -- the
+        //  heaviest tiles sit in waves 0-3, whose chains set the launch's length; tools/probes/run_ab.sh, round 4)
         SK_TS(5 + 10 * b);
         const int fvk = first_valid_key_lds(kb, a.T16, T);
         const int kt_first = min(fvk >> 4, NKT - 1);      // tiles below hold no valid key: probabilities exactly 0

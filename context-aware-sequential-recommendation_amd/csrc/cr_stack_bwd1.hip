@@ -737,6 +737,9 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     int vkb = L::F_OFF_BYTES + 4 * (L::KB + 4 * lg);
     asm volatile("" : "+v"(vkb));
     const unsigned tpk = a.qpk[wave];
+    // the second-dispatched half of the waves loses every arbitration to its SIMD partner (MI355X_MICROARCH.md, two waves per SIMD: a
+    // wave of that half ran its two tiles in 15.9 us where a first-half wave took 12.3): raised for the attention loops
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
     // a tile's inputs (Q fragment in operand layout, d_o in layout R, the forward's row statistics); the NEXT tile's are
     // requested behind the current tile's loop, under its row chain
@@ -941,6 +944,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(4);
+    __builtin_amdgcn_s_setprio(0);
     // phase 3's rows: wave w images tiles w and w + 8.  Their q_in rows (the forward's: nothing here writes them) are requested in
     // front of the drain, their dQ rows right behind the barrier, all before the first image is built: one exposed round trip
     RRaw rq0, rq1, rg0, rg1;
@@ -1088,6 +1092,9 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     int vrow = L::F_OFF_BYTES + 4 * (L::SDEL + 4 * lg);
     asm volatile("" : "+v"(vrow));
     const unsigned tpk = a.kpk[wave];
+    // the second-dispatched half of the waves loses every arbitration to its SIMD partner (MI355X_MICROARCH.md, two waves per SIMD: a
+    // wave of that half ran its two tiles in 15.9 us where a first-half wave took 12.3): raised for the attention loops
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     // a tile's own K / V rows (operand layout, from memory); the NEXT tile's are requested behind the current tile's loop
     GFrag<2> kn, vn;
     float kvn = 0.0f;
@@ -1293,6 +1300,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         }
     }
     B1_TS(4);
+    __builtin_amdgcn_s_setprio(0);
     B1_DRAIN();
     __syncthreads();                                      // every pass is done: the Q / dOut images are dead, dK / dV rows are visible
     B1_TS(7);
@@ -1390,19 +1398,23 @@ static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
     }
     for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
         for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
-    for (int i = 0; i < nkt; ++i) {
-        const int t = order[i];
-        int best = -1;
-        for (int s4 = 0; s4 < 4; ++s4) {
-            if (cnt[s4] >= 2 && cnt[s4 + 4] >= 2) continue;
-            if (best < 0 || load[s4] + load[s4 + 4] < load[best] + load[best + 4]) best = s4;
+    {
+        for (int i = 0; i < nkt; ++i) {
+            const int t = order[i];
+            int best = -1;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (cnt[s4] >= 2 && cnt[s4 + 4] >= 2) continue;
+                if (best < 0 || load[s4] + load[s4 + 4] < load[best] + load[best + 4]) best = s4;
+            }
+            int w = best;
+            if (cnt[w] >= 2 || (cnt[w + 4] < 2 && load[w + 4] < load[w])) w = best + 4;
+            pk[w] = (pk[w] & ~(31u << (5 * cnt[w]))) | ((unsigned)t << (5 * cnt[w]));
+            ++cnt[w];
+            load[w] += cost[t];
         }
-        int w = best;
-        if (cnt[w] >= 2 || (cnt[w + 4] < 2 && load[w + 4] < load[w])) w = best + 4;
-        pk[w] = (pk[w] & ~(31u << (5 * cnt[w]))) | ((unsigned)t << (5 * cnt[w]));
-        ++cnt[w];
-        load[w] += cost[t];
     }
+    // (Tried, round 4: eight bins of at most two tiles dealt so that the four heaviest go to the waves that win their SIMD's
+    //  arbitration -- the first-dispatched half, or the half raised by s_setprio: within the run-to-run spread of the step, +-0.5 %.)
 }
 
 static const char* b1_unsupported(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, int B, int T, int precision) {
