@@ -109,16 +109,47 @@ __device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + wimg_off(row0 + 4 * lg + q, 4 * jt + p)));
 }
 // acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1).
+// Two tiles per k-step: v_mfma_f32_16x16x16_bf16 holds the matrix pipe for the same 16 cycles as the 16x16x32 shape
+// (tools/probes/probe_issue_cost.hip: 6.9 ns per instruction either way, and the pipe is shared by the SIMD's waves), so a product
+// over 16 rows wastes half of it.  Both operands take tile t's four rows in k slots 0..3 and tile t + 1's in 4..7 (two transposed
+// reads each); an odd last tile goes through the K = 16 shape.
 // BIAS (D == 64: no spare column for the ones trick): the waves with it == 0 also form accb[j] += 1^T g, the column sums
 // of g (an all-ones A operand: every row of the result is the bias gradient).
 template <bool SPLIT, bool BIAS, int TMAX = SB_TPR>
 __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], const __bf16* Ah, const __bf16* Al, const __bf16* Gh, const __bf16* Gl,
                                             int ntr, int it, int jt0) {
     const int lane = lane_now();
-    const bf4 ones = (bf4){(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+    const __bf16 one = (__bf16)1.0f;
+    const bf4 ones4 = (bf4){one, one, one, one};
+    const bf8 ones8 = (bf8){one, one, one, one, one, one, one, one};
+    auto cat = [](const bf4& x, const bf4& y) { return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7); };
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {                     // unrolled, wave-uniform guard: several tiles' reads in flight
-        if (t < ntr) {
+    for (int t = 0; t < TMAX; t += 2) {                  // unrolled, wave-uniform guards: several tiles' reads in flight
+        if (t + 1 < ntr) {
+            const bf8 ah = cat(tr4(Ah, 16 * t, it, lane), tr4(Ah, 16 * t + 16, it, lane));
+            const bf8 al = SPLIT ? cat(tr4(Al, 16 * t, it, lane), tr4(Al, 16 * t + 16, it, lane)) : ah;
+            bf8 gh[2], gl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                gh[j] = cat(tr4(Gh, 16 * t, jt0 + j, lane), tr4(Gh, 16 * t + 16, jt0 + j, lane));
+                gl[j] = SPLIT ? cat(tr4(Gl, 16 * t, jt0 + j, lane), tr4(Gl, 16 * t + 16, jt0 + j, lane)) : gh[j];
+            }
+            if (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl[j], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh[j], acc[j], 0, 0, 0);
+            if (BIAS && it == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, gl[j], accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, gh[j], accb[j], 0, 0, 0);
+                }
+            }
+        } else if (t < ntr) {
             const bf4 ah = tr4(Ah, 16 * t, it, lane);
             const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;
             bf4 gh[2], gl[2];
@@ -138,8 +169,8 @@ __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], c
             if (BIAS && it == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, gl[j], accb[j], 0, 0, 0);
-                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, gh[j], accb[j], 0, 0, 0);
+                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones4, gl[j], accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones4, gh[j], accb[j], 0, 0, 0);
                 }
             }
         }

@@ -29,20 +29,51 @@ BODY(k_xorshift, "v_lshrrev_b32 %1, 16, %0\n v_xor_b32 %0, %0, %1\n v_lshrrev_b3
 BODY(k_mulhi, "v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n")
 BODY(k_cvtpk, "v_cvt_pk_bf16_f32 %0, %4, %5\n v_cvt_pk_bf16_f32 %1, %5, %6\n v_cvt_pk_bf16_f32 %2, %6, %7\n v_cvt_pk_bf16_f32 %3, %7, %4\n")
 BODY(k_dpp, "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n")
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+// matrix pipe: back-to-back MFMAs on four independent accumulators, K = 16 (the pre-gfx950 shape) against K = 32
+template <int K32>
+__global__ void k_mfma(unsigned long long* out, int iters) {
+    f4v c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    bf8v a8; bf4v a4;
+    for (int i = 0; i < 8; ++i) a8[i] = (__bf16)(float)(threadIdx.x & 3);
+    for (int i = 0; i < 4; ++i) a4[i] = (__bf16)(float)(threadIdx.x & 3);
+    const unsigned long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (K32) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, a8, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, a8, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, a8, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, a8, c3, 0, 0, 0);
+            } else {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, a4, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, a4, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, a4, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, a4, c3, 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = clock64();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 1.2345f) out[0] = 0;
+}
 typedef void (*K)(unsigned long long*, int);
 int main() {
     unsigned long long* out; (void)hipMalloc(&out, 4096 * 8);
     struct { const char* n; K k; } ks[] = {{"v_add_u32", k_add}, {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_u32_u24", k_mul24}, {"v_mad_u32_u24", k_mad24},
         {"v_exp_f32", k_exp}, {"v_fma_f32", k_fma}, {"v_bfe_i32", k_bfe}, {"v_cmp + v_cndmask (pair)", k_cmpsel}, {"v_lshrrev + v_xor (pair)", k_xorshift},
-        {"v_cvt_pk_bf16_f32", k_cvtpk}, {"v_add_f32_dpp", k_dpp}};
+        {"v_cvt_pk_bf16_f32", k_cvtpk}, {"v_add_f32_dpp", k_dpp}, {"v_mfma_f32_16x16x16_bf16", k_mfma<0>}, {"v_mfma_f32_16x16x32_bf16", k_mfma<1>}};
     const int iters = 2000;
     for (auto& e : ks)
-        for (int nt : {256, 512}) {       // one wave per SIMD, two waves per SIMD (one workgroup per CU: 64 workgroups)
+        for (int nt : {256, 512, 1024}) {       // one, two, four waves per SIMD (one workgroup per CU: 64 workgroups)
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             hipLaunchKernelGGL(e.k, dim3(64), dim3(nt), 0, 0, out, iters);
+            (void)hipEventRecord(e0, 0);
             hipLaunchKernelGGL(e.k, dim3(64), dim3(nt), 0, 0, out, iters);
+            (void)hipEventRecord(e1, 0);
             (void)hipDeviceSynchronize();
+            float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
             unsigned long long h[8]; (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-            printf("%-28s %d waves/SIMD: %.2f clock64 ticks per instruction per wave\n", e.n, nt / 256, (double)h[1] / (iters * 64.0));
+            printf("%-28s %d waves/SIMD: %.2f clock64 ticks per instruction per wave; kernel %.1f us = %.2f ns per instruction of a wave\n", e.n, nt / 256, (double)h[1] / (iters * 64.0), ms * 1e3, ms * 1e6 / (iters * 64.0));
         }
     printf("(clock64 = s_memtime: 100 MHz on this part? compare with v_add_u32 = 4 shader cycles alone)\n");
     return 0;
