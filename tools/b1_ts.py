@@ -65,7 +65,7 @@ for side, sname in ((0, "K side (blockIdx.y = 0)"), (1, "Q side (blockIdx.y = 1)
         print(" -- wave %d, full-length sequences" % wave)
         prev = tt[full, wave, 0] * 0 + np.nan
         order = [30, 15, 13, 14, 11, 12, 1, 24, 25, 26, 27, 28, 10, 2, 9, 3, 6, 8, 4, 7, 16, 17, 18, 20, 21, 22, 23, 5, 29] if side == 1 else [30, 15, 13, 14, 11, 12, 1, 24, 28, 2, 3, 6, 8, 4, 7, 16, 19, 17, 18, 20, 21, 22, 23, 5, 29]
-        names[29] = "end (scatter issue)"; names[24] = "phase 1: first round's chain"; names[25] = "phase 1: next rows requested, barrier"; names[26] = "phase 1: first round's weight-gradient products"; names[27] = "phase 1: barrier"; names[28] = "phase 1: last round's chain"; names[10] = "phase 1: phase-2 loads requested, barrier"; names[2] = "phase 1: last products (+ barrier, query side)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter / small table: slab written)"; names[20] = "small table: ids requested, barrier"; names[21] = "small table: image zeroed, lists, barrier"; names[22] = "small table: rows added"; names[23] = "small table: barrier"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
+        names[29] = "end (scatter issue)"; names[24] = "phase 1: first round's chain"; names[25] = "phase 1: next rows requested, barrier"; names[26] = "phase 1: first round's weight-gradient products"; names[27] = "phase 1: barrier"; names[28] = "phase 1: last round's chain"; names[10] = "phase 1: phase-2 loads requested, barrier"; names[2] = "phase 1: last products (+ barrier, query side)"; names[16] = "phase 3: first images up (loads, puts, barrier)"; names[19] = "phase 3: first round's products + barrier"; names[17] = "phase 3: products done"; names[18] = "phase 3: weight-gradient stores issued"; names[5] = "phase 3: embedding backward (scatter issued / small table: slab stored)"; names[20] = "small table: barrier (phase 3's images dead)"; names[21] = "small table: ids + row images up, barrier"; names[22] = "small table: one-hot products"; names[23] = "small table: (unused stamp)"; names[15] = "prologue: argument lines arrived"; names[13] = "prologue: dropout keys"; names[14] = "prologue: weight loads issued"; names[11] = "prologue: tile loads issued"; names[12] = "prologue: weights arrived and staged"
         base = None
         for k in order:
             cur = tt[full, wave, k]
