@@ -471,6 +471,7 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9,
     worst = worst_grad_error(got, G, prec)
     assert worst[0] < 2 * worst[2], worst
     assert rel(eng.seq_emb, out["seq_emb"].reshape(B * T, -1)) < tol["act"]     # forward parity (north-star bound 1e-3)
+    return eng
 
 
 def test_config_c1_exact_shape(E):
@@ -570,9 +571,24 @@ def test_every_cast_graph_at_the_headline_shape(E, model):
     _other_shapes(E, model, 50, 1, 200, 2, B=3, prec="bf16x3", itemnum=300, max_bins=200)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,D,H,T,max_bins", [("cast_1", 50, 1, 200, 255), ("cast_1", 64, 2, 40, 255), ("cast_1", 40, 1, 72, 16),
+                                                    ("cast_1", 48, 1, 120, 100), ("cast_1", 16, 1, 24, 9)])
+def test_small_tables_through_the_one_hot_product(E, model, D, H, T, max_bins):
+    """cr_stack_block_bwd's small-table backward = one-hot(ids)^T x rows on the matrix pipe (round 4): tables of 256 rows (all
+    sixteen table-row tiles, both tiles of every wave), of fewer rows than one tile, the two-head instantiation at D = 64, an odd
+    and an even count of row tiles, the generic and the constant hidden sizes.  Gradients of the table against the oracle like every
+    other parameter (the product takes the rows as bf16 hi + lo: inside the tolerance of the arithmetic)."""
+    eng = _other_shapes(E, model, D, H, T, 1, B=3, prec="bf16x3", max_bins=max_bins, n_slabs=8)
+    names = [n for n, _, _ in eng.bwd]
+    # the time table's backward is inside the context stack's block backward (two slabs per sequence pair: 8 >= 2 x 3)
+    assert names.count("cr_stack_block_bwd") == 2 and "cr_embed_bwd" not in names, names
+
+
 def test_context_tables_too_large_for_one_lds_image(E):
-    """time_emb at --max_bins 200 and hidden 64 is 201 x 64 floats > the 12 288 the small-table backward keeps in
-    LDS: it must fall back to the large-table scatter (same slab contract), fused and unfused (D = 128) alike."""
+    """time_emb at --max_bins 200 and hidden 64 (one head: not a shape of the one-launch block backward) is 201 x 64 floats > the
+    12 288 cr_embed_bwd's small-table mode keeps in LDS: it must fall back to the large-table scatter (same slab contract), fused and
+    unfused (D = 128) alike."""
     _other_shapes(E, "cast_1", 64, 1, 40, 1, B=3, prec="f32", max_bins=200)
     _other_shapes(E, "cast_3", 128, 2, 24, 1, B=3, prec="f32", max_bins=200)
 
