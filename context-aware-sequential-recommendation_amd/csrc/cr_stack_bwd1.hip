@@ -455,6 +455,9 @@ __device__ __forceinline__ void b1_scatter_prep(const B1Args& a, f32x4 (&dxl)[4]
 // A wave takes 16 rows at a time: their ids and gradient rows are requested together, then the atomics go out back to back
 // and the wave ends with them in flight (nothing in the kernel waits behind them: placed in front of phase 3 they held its
 // loads back for the ~3000 clocks an atomic stays in the memory queue: +17 us on the block that scatters).
+// Round 4, measured on the launch that carries it (49.6 us; 43.7 with this function returning at once): the 6 us are the atomics
+// themselves -- 1.28 M per side at about one dword per L2 channel and clock -- not this function's two dependent round trips (ids and
+// rows requested in front of phase 3's last products: 50.9 us) and not their place (sent in front of those products: no change).
 __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* buf, int n, int D) {
     if (!a.sc.table_grad && !a.sc.pos_grad) return;
     const cr_embed_desc& e = a.sc.f;
