@@ -253,7 +253,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             int m; bool rok;
             tile_rows(rd, m, rok);
             const u32 mo = (u32)m * (u32)(4 * D);
-            r_issue(rfin, QSIDE ? d.f_in : d.qkv, mo, dcx);
+            if (QSIDE || HD == 1) r_issue(rfin, QSIDE ? d.f_in : d.qkv, mo, dcx);     // (key side, two heads: requested inside the chain, below)
             r_issue(ro, d.o, mo, dcx);
             r_issue(rq, d.q_in, mo, dcx);
         }
@@ -336,6 +336,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (modules.py:300-304)
             bf8 gh[2], gl[2];
             f32x4 g1[4];
+            // (the tile's Q rows, key side with two heads: held from the round's start they did not fit -- two of their four pieces went to
+            //  scratch with a full wait each; requested here they fly under the first product)
+            if (!QSIDE && HD == 2) r_issue(rfin, d.qkv, mo, dcx);
             r_split<SPLIT>(g2, gh, gl);
             r_gemm_t<SPLIT, false>(g1, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
 #pragma unroll
