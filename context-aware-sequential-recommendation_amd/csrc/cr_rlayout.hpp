@@ -76,22 +76,34 @@ __device__ __forceinline__ void r_finish(f32x4 (&x)[4], const RRaw& w, const DCt
             }
     }
 }
+// NT: a streaming store (written once here, read by a LATER launch -- saved activations, gradient slabs): it does not stay in the
+// L2 as a dirty line that the next launch's first loads wait behind
+template <bool NT = false>
 __device__ __forceinline__ void r_store(float* base, u32 rowb, const f32x4 (&x)[4], bool rok, const DCtx& dc) {
     const int lgb = (lane_now() >> 4) * 4;
     char* b = reinterpret_cast<char*>(base);
     const u32 ob = rowb + 4u * (u32)lgb;
+    auto st4 = [](char* p, const f32x4& v) {
+        const f4u t = (f4u){v[0], v[1], v[2], v[3]};
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f4u*>(p));
+        else *reinterpret_cast<f4u*>(p) = t;
+    };
+    auto st1 = [](float* p, float v) {
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
     if (rok) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             if (ct < dc.nfull) {
-                *reinterpret_cast<f4u*>(b + (ob + 64u * ct)) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
+                st4(b + (ob + 64u * ct), x[ct]);
             } else if (ct == dc.nfull) {
-                if (lgb + 4 <= dc.rem) *reinterpret_cast<f4u*>(b + (ob + 64u * ct)) = (f4u){x[ct][0], x[ct][1], x[ct][2], x[ct][3]};
+                if (lgb + 4 <= dc.rem) st4(b + (ob + 64u * ct), x[ct]);
                 if (dc.np && lgb < dc.rem && lgb + 4 > dc.rem) {
                     float* q = reinterpret_cast<float*>(b + (ob + 64u * ct));
-                    q[0] = x[ct][0];
-                    if (dc.np > 1) q[1] = x[ct][1];
-                    if (dc.np > 2) q[2] = x[ct][2];
+                    st1(q, x[ct][0]);
+                    if (dc.np > 1) st1(q + 1, x[ct][1]);
+                    if (dc.np > 2) st1(q + 2, x[ct][2]);
                 }
             }
         }

@@ -119,7 +119,7 @@ __device__ __forceinline__ void b1_wstore(float* dst, int ldw, float* bias_dst, 
             const int k = 16 * it + 4 * lg + r;
             if (col < D && (BIAS ? k < D : k <= D)) {
                 float* p = (k < D) ? dst + (size_t)k * ldw + col : bias_dst + col;
-                *p = add ? *p + acc[j][r] : acc[j][r];
+                __builtin_nontemporal_store(add ? *p + acc[j][r] : acc[j][r], p);    // (a streaming store: the slab is read by Adam, launches later)
             }
         }
         if (BIAS && it == 0 && lg == 0 && col < D) bias_dst[col] = add ? bias_dst[col] + accb[j][0] : accb[j][0];
@@ -607,7 +607,7 @@ __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* s
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) acc[i][ct] *= e.scale;
             }
-            r_store(slab, ro, acc[i], rok, dcx);
+            r_store(slab, ro, acc[i], rok, dcx);               // (NOT a streaming store: Adam reads this slab right behind the launch)
         }
     }
     (void)lg;
