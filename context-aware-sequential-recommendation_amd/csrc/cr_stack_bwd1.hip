@@ -202,6 +202,7 @@ struct B1Acc { f32x4 aw1[2], aw2[2], aw1b[2], aw2b[2], ag[4], ab[4], agF[4], abF
 template <bool SPLIT, int DS, bool QSIDE, int HD, class F>
 __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, B1Steps& steps, F&& before_last_products) {
     constexpr bool BIAS = DS == 64;
+    constexpr bool LATE_Q = !QSIDE && (HD == 2 || DS > 50 || DS == 0);       // key side: the tile's Q rows are requested late (registers)
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -253,7 +254,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             int m; bool rok;
             tile_rows(rd, m, rok);
             const u32 mo = (u32)m * (u32)(4 * D);
-            if (QSIDE || HD == 1) r_issue(rfin, QSIDE ? d.f_in : d.qkv, mo, dcx);     // (key side, two heads: requested inside the chain, below)
+            if (!LATE_Q) r_issue(rfin, QSIDE ? d.f_in : d.qkv, mo, dcx);     // (LATE_Q: requested inside the chain, below)
             r_issue(ro, d.o, mo, dcx);
             r_issue(rq, d.q_in, mo, dcx);
         }
@@ -336,9 +337,9 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             // dhid = g2 W2^T, gated by the stored post-dropout ReLU output -> g1 (modules.py:300-304)
             bf8 gh[2], gl[2];
             f32x4 g1[4];
-            // (the tile's Q rows, key side with two heads: held from the round's start they did not fit -- two of their four pieces went to
-            //  scratch with a full wait each; requested here they fly under the first product)
-            if (!QSIDE && HD == 2) r_issue(rfin, d.qkv, mo, dcx);
+            // (the tile's Q rows, key side at the widest shapes: held from the round's start they did not fit -- two of their four pieces
+            //  went to scratch with a full wait each; requested here they fly under the first product)
+            if (LATE_Q) r_issue(rfin, d.qkv, mo, dcx);
             r_split<SPLIT>(g2, gh, gl);
             r_gemm_t<SPLIT, false>(g1, Wi + WST, Wi + WST + ST_WIMG, gh, gl);
 #pragma unroll
@@ -1535,6 +1536,9 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);
     case 48: return split ? launch_b1<true, 48>(a, nwg, s) : launch_b1<false, 48>(a, nwg, s);
     case 16: return split ? launch_b1<true, 16>(a, nwg, s) : launch_b1<false, 16>(a, nwg, s);
+    case 8: return split ? launch_b1<true, 8>(a, nwg, s) : launch_b1<false, 8>(a, nwg, s);
+    case 24: return split ? launch_b1<true, 24>(a, nwg, s) : launch_b1<false, 24>(a, nwg, s);
+    case 56: return split ? launch_b1<true, 56>(a, nwg, s) : launch_b1<false, 56>(a, nwg, s);
     default: return split ? launch_b1<true, 0>(a, nwg, s) : launch_b1<false, 0>(a, nwg, s);
     }
 }

@@ -259,6 +259,9 @@ def test_other_baseline_shapes_match_oracle(E, model, D, H, T, L, prec):
                                              ("cast_3", 13, 1, 24, 1, 3),
                                              ("cast_1", 33, 1, 50, 1, 2),
                                              ("sasrec", 47, 1, 70, 2, 2),
+                                             ("cast_1", 8, 1, 40, 1, 3),      # hidden sizes the block backward has as constants: 8 ..
+                                             ("sasrec", 24, 1, 100, 2, 2),
+                                             ("cast_1", 56, 1, 200, 1, 2),    # .. 56 (key side: the tile's Q rows requested late)
                                              ("cast_8", 63, 3, 31, 1, 3),     # head dim 21, odd everything
                                              ("sasrec", 60, 4, 129, 1, 2),    # head dim 15, T = 8*16 + 1
                                              ("cast_1", 64, 1, 255, 1, 1),    # upper edge of the LDS-resident envelope
