@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_test_logits(const float* seq_emb, int l
 // The same for hidden sizes that are multiples of 4 (16-byte rows): a read-only row gather, the form the HBM-read
 // roofline of the item table is measured on (bench.py "gather" block).  16 lanes own a candidate row (float4 per lane
 // per 64 columns), a wave keeps 4 rows x NR rounds in flight, the row sum is four DPP adds.  NV = D / 64 rounded up.
-template <int NV, int NR>
+template <int NV, int NR, bool STREAM>
 __global__ __launch_bounds__(256) void k_test_logits_v4(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                                                         int B, int T, int D, int n_cand, float* logits) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, grp = (threadIdx.x >> 4);   // 16 groups per block
@@ -390,7 +390,14 @@ __global__ __launch_bounds__(256) void k_test_logits_v4(const float* seq_emb, in
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * li + 64 * i;
-                rv[r][i] = *reinterpret_cast<const float4*>(table + (size_t)id[r] * D + (c < D ? c : 0));
+                // STREAM (a table larger than the Infinity Cache: a row is not read again before it has left every cache): streaming loads --
+                // 76.7 -> 69.2 us for 425 MB of fresh rows at config C5's table, 69 -> 77 % of the 8 TB/s peak (bench.py gather block).  NOT in
+                // cr_embed_fwd, the training-path gather, which writes as many bytes as it reads: there streaming loads cost 5 %, and with
+                // both kernels streaming this one's gain was gone as well (tools/probes/run_gather.sh: CASTREC_GATHER_STREAM)
+                typedef float f4n __attribute__((ext_vector_type(4)));
+                const f4n* src = reinterpret_cast<const f4n*>(table + (size_t)id[r] * D + (c < D ? c : 0));
+                const f4n t4 = STREAM ? __builtin_nontemporal_load(src) : *src;
+                rv[r][i] = make_float4(t4.x, t4.y, t4.z, t4.w);
             }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -417,12 +424,20 @@ extern "C" int cr_test_logits(const float* seq_emb, int ld, const float* table, 
         // (16 groups x 7): 68.2 % / 68.7 % / 70.0 % / 71.1 % of the 8 TB/s HBM peak for 1 / 2 / 4 / 7 at config C5's table
         // (tools/gather_sweep.py, a fresh row set per launch)
         static const int nr = getenv("CASTREC_TL_NR") ? atoi(getenv("CASTREC_TL_NR")) : 7;
-        if (D <= 64) hipLaunchKernelGGL((k_test_logits_v4<1, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else if (D <= 128) hipLaunchKernelGGL((k_test_logits_v4<2, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else if (nr == 4) hipLaunchKernelGGL((k_test_logits_v4<4, 4>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else if (nr == 1) hipLaunchKernelGGL((k_test_logits_v4<4, 1>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else if (nr == 7) hipLaunchKernelGGL((k_test_logits_v4<4, 7>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
-        else hipLaunchKernelGGL((k_test_logits_v4<4, 2>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
+        static const char* gs = getenv("CASTREC_GATHER_STREAM");            // (measurement override: 0 / 1)
+        const bool big = gs ? atoi(gs) != 0 : (size_t)V * D * 4 >= ((size_t)256 << 20);       // streaming row loads: see k_test_logits_v4
+#define TL_LAUNCH(NV, NRR)                                                                                                                    \
+    do {                                                                                                                                      \
+        if (big) hipLaunchKernelGGL((k_test_logits_v4<NV, NRR, true>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);   \
+        else hipLaunchKernelGGL((k_test_logits_v4<NV, NRR, false>), dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);     \
+    } while (0)
+        if (D <= 64) TL_LAUNCH(1, 2);
+        else if (D <= 128) TL_LAUNCH(2, 2);
+        else if (nr == 4) TL_LAUNCH(4, 4);
+        else if (nr == 1) TL_LAUNCH(4, 1);
+        else if (nr == 7) TL_LAUNCH(4, 7);
+        else TL_LAUNCH(4, 2);
+#undef TL_LAUNCH
         return cr_check_launch("cr_test_logits");
     }
     hipLaunchKernelGGL(k_test_logits, dim3(B), dim3(256), 0, st, seq_emb, ld, table, cand, B, T, D, n_cand, logits);
