@@ -41,6 +41,9 @@
 // workgroup barrier; __syncthreads() itself only drains the LDS counter on this target (s_waitcnt lgkmcnt(0); s_barrier), so the
 // writing wave drains its vector-memory counter explicitly first
 #define B1_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// dQ / dK / dV rows (a workspace: written in phase 2, read back once in phase 3, dead behind the launch) leave as streaming stores: they do
+// not stay behind as dirty L2 lines for the next launch to wait on (-1.1 us per step, A/B)
+#define B1_NT_WS true
 #define B1_ROWS 224                       // rows of an attention image (14 tiles of 16)
 #define B1_FSTR (B1_ROWS * 64)            // bf16 elements of one image half
 
@@ -373,7 +376,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
             r_finish(o, ro, dcx);
             r_ln_bwd(dout, o, df, gam, ag, ab, dcx);
             if (QSIDE) {
-                r_store(bd.d_o, mo, dout, rok, dcx);
+                r_store(bd.d_o, mo, dout, rok, dcx);                       // (a plain store: other waves read it back within microseconds; streaming: +0.5 us)
             } else {
                 if (!rok) {
 #pragma unroll
@@ -918,7 +921,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         const B1Args& ar = b1_args_again();                               // (this chain's pointers: not carried across the loop)
         RRaw rdx;
         if (ar.bd.dx_accumulate) r_issue(rdx, ar.bd.dx, mo, dcx, rok);
-        r_store(const_cast<float*>(ar.bd.dqkv), mo, dq, rok, dcx);        // dQ, for the weight-gradient images of phase 3
+        r_store<B1_NT_WS>(const_cast<float*>(ar.bd.dqkv), mo, dq, rok, dcx);        // dQ, for the weight-gradient images of phase 3
         f32x4 dqin[4];
         {
             bf8 gh[2], gl[2];
@@ -1289,8 +1292,8 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));   // the next tile's K / V rows, under this tile's row chain
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
         const B1Args& ar = b1_args_again();                               // (this chain's pointers: not carried across the loop)
-        r_store(const_cast<float*>(ar.bd.dqkv) + MD, mo, dk, rok, dcx);   // dK, dV: for the weight-gradient images of phase 3
-        r_store(const_cast<float*>(ar.bd.dqkv) + 2 * MD, mo, dv, rok, dcx);
+        r_store<B1_NT_WS>(const_cast<float*>(ar.bd.dqkv) + MD, mo, dk, rok, dcx);   // dK, dV: for the weight-gradient images of phase 3
+        r_store<B1_NT_WS>(const_cast<float*>(ar.bd.dqkv) + 2 * MD, mo, dv, rok, dcx);
         f32x4 dxp[4];
         {
             bf8 gh[2], gl[2];
