@@ -518,9 +518,13 @@ def main():
                 # (dist.DataParallel._replayed_step_agrees), else the three-graph form runs; CASTREC_DP_ONE_GRAPH=0 forces that form
                 whole = dp.capture_step() if os.environ.get("CASTREC_DP_ONE_GRAPH") != "0" else False
                 eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
+        # steps per graph launch, as the fed training path runs them (models.Model.steps_per_launch: 4 where four batches wait in the id ring):
+        # the device idles 5-9 us between two graph launches; here the batches of all steps are resident, so every launch is a full one
+        spg = max(1, int(os.environ.get("CASTREC_STEPS_PER_GRAPH", "4"))) if (ring and dist is None and use_graph and not args.lazy_adam) else 1
+        run.spg = spg
         if dist is None and use_graph:
             eng.ids_all.copy_(staged[0])
-            eng.capture()
+            eng.capture(n_steps=spg)
             eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
         if ring:
             eng.ids_all.copy_(staged[eng.step_number() % NB])
@@ -567,8 +571,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
+        if spg > 1:
+            # EXACTLY `steps` steps: whole graphs of spg steps, the rest one step per launch
+            for _ in range(steps // spg):
+                eng.graph_multi.launch()
+            for i in range(steps % spg):
+                step(warmup + i)
+        else:
+            for i in range(steps):
+                step(warmup + i)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -635,7 +646,7 @@ def main():
                            "num_heads=%d dropout=%.2f, batch %d/GPU (global %d), fwd+bwd+%s TF-Adam per step"
                            % (args.corpus, corpus.usernum, corpus.itemnum, args.model, T, args.hidden_units, args.num_blocks, args.num_heads,
                               args.dropout_rate, B, Bg, "row-sparse (lazy)" if args.lazy_adam else "dense"),
-               "parallelism": "dp%d" % world, "hip_graph": use_graph, "launches_per_step": eng.n_kernel_launches(), "abi_calls_per_step": eng.n_launches(),
+               "parallelism": "dp%d" % world, "hip_graph": use_graph, "steps_per_graph_launch": getattr(run, "spg", 1), "launches_per_step": eng.n_kernel_launches(), "abi_calls_per_step": eng.n_launches(),
                "attn_precision": prec, "final_loss": round(loss, 5), "final_auc": round(auc, 5)}
         if dist is not None:
             cfg["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),

@@ -1171,7 +1171,7 @@ class Engine:
                 ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr()
 
     # ---- host batches fed AHEAD of the steps that use them --------------------------------------
-    def enable_feed(self, n_slots=8):
+    def enable_feed(self, n_slots=8, steps_per_graph=1):
         """Turns on the pipelined input path of a training engine: feed() packs a host batch into a pinned buffer and sends
         it -- ONE copy over PCIe, on a copy stream, while earlier steps run -- into a slot of a device ring; train_fed() runs the
         step of the oldest waiting batch, whose tail moves the following batch into the static id buffers (use_id_ring).  With
@@ -1190,7 +1190,10 @@ class Engine:
         recapture = self.graph is not None
         self.use_id_ring(self._feed_ring)
         if recapture:
-            self.capture()                           # (the ring's address travels in the Adam launch's arguments)
+            # (the ring's address travels in the Adam launch's arguments).  steps_per_graph > 1: train_fed() runs that many steps per
+            # graph launch whenever as many batches wait (capture()); the ring must hold them beside the slots being refilled
+            assert steps_per_graph == 1 or n_slots >= 2 * steps_per_graph + 4, "ring too small for %d steps per launch" % steps_per_graph
+            self.capture(n_steps=steps_per_graph if not self.lazy_adam else 1)
         self._feed_next, self._feed_have, self._feed_started = self.step_number(), 0, False
         self._feed_first = self._feed_next           # steps before it did not read the ring
         used = {"seq", "pos", "neg"} | ({"time"} if "time_emb" in self.layout.entries else set()) \
@@ -1235,31 +1238,40 @@ class Engine:
         self._feed_next += 1
         self._feed_have += 1
 
-    def train_fed(self):
-        """Runs the step of the oldest fed batch."""
+    def train_fed(self, max_steps=None):
+        """Runs the step of the oldest fed batch -- or, where capture(n_steps=G) has made a graph of G steps and at least G batches
+        wait (and max_steps allows it), those G steps in one launch.  Returns the number of steps run."""
         if self._feed_have < 1:
             raise RuntimeError("train_fed(): no batch has been fed")
         n = self._feed_ring.shape[0]
         k = self._feed_next - self._feed_have
+        G = self.graph_steps if (getattr(self, "graph_multi", None) is not None and self.graph is not None) else 1
+        if self._feed_have < G or (max_steps is not None and max_steps < G):
+            G = 1
         cur = torch.cuda.current_stream()
         if not self._feed_started:
             # nobody moved this batch into the static buffers (first step, or the step before ran with no batch fed ahead)
             self._feed_h2d[k % n].synchronize()
             self.ids_all.copy_(self._feed_ring[k % n])
-        if self._feed_have >= 2:
-            self._feed_h2d[(k + 1) % n].synchronize()        # this step's tail moves batch k + 1 (fed a step ago: long there)
-        self._feed_started = self._feed_have >= 2
-        if self.graph is not None:
+        # the tail of step k + j - 1 moves batch k + j: those that are fed (a step or more ago: long there) must have arrived
+        for j in range(1, min(G, self._feed_have - 1) + 1):
+            self._feed_h2d[(k + j) % n].synchronize()
+        self._feed_started = self._feed_have >= G + 1
+        if G > 1:
+            self.graph_multi.launch()
+        elif self.graph is not None:
             self.graph.launch()
         else:
             self.launch_step()
-        if k % self._feed_every == 0:
+        last = k + G - 1
+        if G > 1 or k % self._feed_every == 0:
             ev = torch.cuda.Event()
             ev.record(cur)
-            self._feed_done[k] = ev
-            for old in [j for j in self._feed_done if j < k - n]:
+            self._feed_done[last] = ev
+            for old in [j for j in self._feed_done if j < last - n]:
                 del self._feed_done[old]
-        self._feed_have -= 1
+        self._feed_have -= G
+        return G
 
     # ---- data-parallel pieces (castrec_amd.dist drives them around an RCCL all-reduce) ----------
     def launch_backward_to_flat(self):
@@ -1294,11 +1306,15 @@ class Engine:
         self.dp_graphs, self.dp_progs, self._graph_stream = graphs, progs, side
         return graphs
 
-    def capture(self, dp=False):
-        """Captures launch_step() into a HIP graph (inputs are read from the static id buffers)."""
-        g = O.Graph()
+    def capture(self, dp=False, n_steps=1):
+        """Captures launch_step() into a HIP graph (inputs are read from the static id buffers).
+        n_steps > 1 (with use_id_ring(): every step's tail moves the next step's batch into the static buffers on the device) captures
+        that many consecutive steps into a second graph, `graph_multi`: between two launches of a graph the device idles for the
+        7-9 us the command processor needs to start the next one (rocprofv3: gaps of 0.2 us inside a step's graph, 8.7 us between two
+        steps); n steps per launch pay that once."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        g = O.Graph()
         with torch.cuda.stream(side):
             g.begin()
             if dp:
@@ -1306,6 +1322,16 @@ class Engine:
             else:
                 self.launch_step()
             g.end()
+        self.graph_multi, self.graph_steps = None, 1
+        if n_steps > 1:
+            assert not dp and self.training and self._id_ring is not None and not self.lazy_adam, "several steps per graph need the id ring (use_id_ring / enable_feed)"
+            gm = O.Graph()
+            with torch.cuda.stream(side):
+                gm.begin()
+                for _ in range(n_steps):
+                    self.launch_step()
+                gm.end()
+            self.graph_multi, self.graph_steps = gm, int(n_steps)
         torch.cuda.current_stream().wait_stream(side)
         self.graph, self._graph_stream = g, side
         return g

@@ -121,8 +121,41 @@ class _Model(object):
             self._fed.append((u, seq, pos, neg, time_seq, hours, days))     # data parallel: the batch waits on the host
             return
         if getattr(eng, "_feed_ring", None) is None:
-            eng.enable_feed()
+            g = self.steps_per_launch
+            eng.enable_feed(n_slots=16 if g > 1 else 8, steps_per_graph=g)
         eng.feed(seq, pos, neg, time_seq, hours, days)
+
+    @property
+    def steps_per_launch(self):
+        """Steps a graph launch of the fed training path runs when as many batches wait (Engine.capture(n_steps)): between two graph
+        launches the device idles for the 5-9 us the next launch takes to start, 1-2 % of a 0.33 ms step.  CASTREC_STEPS_PER_GRAPH
+        overrides the default of 4; 1 without HIP graphs, with row-sparse Adam, or data parallel."""
+        if not self._graph or getattr(self, "_dp", None) is not None or self._batch_global is not None or getattr(self, "_lazy_adam", False):
+            return 1
+        return max(1, int(os.environ.get("CASTREC_STEPS_PER_GRAPH", "4")))
+
+    @property
+    def feed_ahead(self):
+        """How many fed batches may wait for their steps (main.py keeps that many handed over): one more than steps_per_launch, so that
+        a launch's last step finds its successor's batch in place."""
+        g = self.steps_per_launch
+        return g + 1 if g > 1 else 1
+
+    def train_fed_many(self, max_steps=None):
+        """Runs the oldest waiting batch's step -- or steps_per_launch steps in one graph launch when as many batches wait and
+        max_steps allows it.  Returns the number of steps run; loss / auc of the last one: loss_auc()."""
+        if getattr(self, "_dp", None) is not None:
+            self.train_step(*self._fed.pop(0), fetch=False)
+            return 1
+        eng = self._train
+        if eng is None or getattr(eng, "_feed_ring", None) is None:
+            raise RuntimeError("train_fed_many(): feed() a batch first")
+        return eng.train_fed(max_steps=max_steps)
+
+    def loss_auc(self):
+        """(auc, loss) of the last step run, like train_step's fetch."""
+        loss, auc = self._train.loss_auc()
+        return auc, loss
 
     def train_fed(self, fetch=True):
         if getattr(self, "_dp", None) is not None:
@@ -130,7 +163,7 @@ class _Model(object):
         eng = self._train
         if eng is None or getattr(eng, "_feed_ring", None) is None:
             raise RuntimeError("train_fed(): feed() a batch first")
-        eng.train_fed()
+        eng.train_fed(max_steps=1)
         if fetch:
             loss, auc = eng.loss_auc()
             return auc, loss

@@ -139,15 +139,27 @@ def main(argv=None):
 
     try:
         total, done, out = args.num_epochs * num_batch, 0, None
+        # how many handed-over batches may wait: 1 (the step that runs now has its successor's batch in place), or -- a model whose
+        # graph launches run several steps each (Model.steps_per_launch) -- that many plus one
+        ahead = int(getattr(model, "feed_ahead", 1))
+        fed = 0
         if total > 0:
-            hand_over()
+            hand_over(); fed = 1
         for epoch in range(1, args.num_epochs + 1):
-            for step in range(num_batch):
-                done += 1
-                if done < total:
-                    hand_over()                                    # one batch ahead of the step that runs now
-                last = (step == num_batch - 1)
-                out = model.train_fed(fetch=last)
+            if ahead <= 1:
+                for step in range(num_batch):
+                    done += 1
+                    if done < total:
+                        hand_over(); fed += 1                      # one batch ahead of the step that runs now
+                    last = (step == num_batch - 1)
+                    out = model.train_fed(fetch=last)
+            else:
+                end = epoch * num_batch
+                while done < end:
+                    while fed < total and fed - done < ahead:
+                        hand_over(); fed += 1
+                    done += model.train_fed_many(max_steps=end - done)     # (never across the epoch's end: its last step's loss is logged)
+                out = model.loss_auc()
             if out is not None:
                 logger.info('epoch %d: TRAIN/loss %.5f TRAIN/auc %.5f' % (epoch, out[1], out[0]))
                 writer.add_scalars(epoch, {'TRAIN/loss': out[1], 'TRAIN/auc': out[0]})

@@ -30,10 +30,41 @@ class Recorder:
         return path
 
 
-def test_main_feeds_one_batch_ahead_in_sampler_order(tmp_path, monkeypatch):
+class RecorderMany(Recorder):
+    """A model whose graph launches run up to four steps (Model.steps_per_launch = 4: feed_ahead = 5)."""
+    feed_ahead = 5
+
+    def __init__(self):
+        super().__init__()
+        self.launches = []
+
+    def feed(self, u, seq, pos, neg, time_seq=None, hours=None, days=None):
+        assert len(self.waiting) < self.feed_ahead, "at most feed_ahead batches wait"
+        self.waiting.append(np.asarray(seq).copy())
+        self.fed.append(np.asarray(seq).copy())
+
+    def train_fed(self, fetch=True):
+        raise AssertionError("the loop of a multi-step model calls train_fed_many")
+
+    def train_fed_many(self, max_steps=None):
+        n = 4 if (len(self.waiting) >= 4 and (max_steps is None or max_steps >= 4)) else 1
+        for _ in range(n):
+            self.ran.append(self.waiting.pop(0))
+        self.launches.append((n, max_steps))
+        return n
+
+    def loss_auc(self):
+        return (0.5, 1.0)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_main_feeds_one_batch_ahead_in_sampler_order(tmp_path, monkeypatch, many):
     import main as cli
     from castrec_amd.sampler import WarpSampler
-    rec = Recorder()
+    rec = RecorderMany() if many else Recorder()
     monkeypatch.setattr(cli, "build_model", lambda *a, **k: rec)
     monkeypatch.setattr(cli, "evaluate", lambda *a, **k: (0.1, 0.2))
     monkeypatch.setattr(cli, "evaluate_valid", lambda *a, **k: (0.3, 0.4))
@@ -56,6 +87,10 @@ def test_main_feeds_one_batch_ahead_in_sampler_order(tmp_path, monkeypatch):
     assert len(rec.ran) == 3 * num_batch == len(rec.fed) and not rec.waiting       # every fed batch ran, nothing drawn in vain
     for a, b in zip(rec.ran, want):
         np.testing.assert_array_equal(a, b)
+    if many:
+        # several steps per launch where enough batches wait, never across an epoch's end (max_steps = what the epoch has left)
+        assert sum(n for n, _ in rec.launches) == 3 * num_batch and all(n <= m for n, m in rec.launches)
+        assert any(n == 4 for n, _ in rec.launches) or num_batch < 4
     # the artefacts of the run directory: log.txt line and the TensorBoard scalars of the stand-in's numbers
     runs = os.listdir(tmp_path / "saved_models" / "synthetic_tiny")
     d = tmp_path / "saved_models" / "synthetic_tiny" / runs[0]

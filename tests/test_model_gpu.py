@@ -707,6 +707,40 @@ def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
     assert torch.equal(b.ids_all.cpu(), a.ids_all.cpu()) and torch.equal(a.P[nt:], b.P[nt:])
 
 
+def test_several_fed_steps_per_graph_launch(E):
+    """Engine.capture(n_steps = 4) / enable_feed(steps_per_graph = 4): train_fed() runs four steps in ONE graph launch whenever four
+    batches wait (each step's tail moves its successor's batch on the device), one step otherwise or where max_steps says so -- the
+    same batches in the same order as a step per call, whatever the pattern."""
+    rs = np.random.RandomState(19)
+    B, T, D, itemnum = 5, 32, 50, 80
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=20, seed=6)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b.P.copy_(a.P)
+    b.capture()
+    b.enable_feed(n_slots=16, steps_per_graph=4)
+    assert b.graph_multi is not None and b.graph_steps == 4
+    batches = [make_batch(rs, B, T, itemnum, 20) for _ in range(14)]       # (few steps: float-atomic table gradients let runs drift apart)
+    for bt in batches:
+        a.train_step(*bt)
+    it = iter(batches)
+    ran = []
+    for _ in range(5):
+        b.feed(*next(it))
+    ran.append(b.train_fed())                                      # five wait: four steps, the fifth batch moved by the last one's tail
+    ran.append(b.train_fed())                                      # one waits: one step
+    for _ in range(4):
+        b.feed(*next(it))
+    ran.append(b.train_fed())                                      # exactly four wait: four steps, nobody moves a successor
+    for _ in range(5):
+        b.feed(*next(it))
+    ran.append(b.train_fed(max_steps=3))                           # (an epoch's end in three steps): one step
+    ran.append(b.train_fed())                                      # four wait: four steps in one launch again
+    torch.cuda.synchronize()
+    assert ran == [4, 1, 4, 1, 4] and next(it, None) is None and b.step_number() == a.step_number() == 15
+    assert same_run(a, b) and same_loss_auc(a, b, batches[-1][1])
+
+
 @pytest.mark.parametrize("graph,n_slots", [(False, 4), (True, 4), (True, 8)])
 def test_fed_batches_train_like_batches_set_per_step(E, graph, n_slots):
     """Engine.enable_feed / feed / train_fed: pinned host batches sent ahead over a copy stream into the id ring.  Every
