@@ -564,22 +564,26 @@ def main():
             torch.cuda.synchronize()
             cond = {"steps": nc, "cold_ms_per_step": round((time.perf_counter() - tc) / nc * 1e3, 4)}
         conditioning.append(cond)
-        for i in range(warmup):
-            step(i)
+        def run_steps(n, i0):
+            # EXACTLY n steps: whole graphs of spg steps, the rest one step per launch
+            if spg > 1:
+                for _ in range(n // spg):
+                    eng.graph_multi.launch()
+                for i in range(n % spg):
+                    step(i0 + i)
+            else:
+                for i in range(n):
+                    step(i0 + i)
+
+        if spg > 1:
+            eng.graph_multi.launch()                         # (untimed: a graph's first launch uploads it)
+        run_steps(warmup, 0)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if spg > 1:
-            # EXACTLY `steps` steps: whole graphs of spg steps, the rest one step per launch
-            for _ in range(steps // spg):
-                eng.graph_multi.launch()
-            for i in range(steps % spg):
-                step(warmup + i)
-        else:
-            for i in range(steps):
-                step(warmup + i)
+        run_steps(steps, warmup)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
