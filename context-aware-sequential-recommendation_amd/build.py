@@ -2,7 +2,11 @@
 
     python -m castrec_amd.build        (or: import castrec_amd.build; castrec_amd.build.build())
 """
+import glob
+import hashlib
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -26,6 +30,119 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.jo
          "-fno-slp-vectorize"]
 
 
+# ---- the ISA check -----------------------------------------------------------------------------------------------------
+# The sources whose device code is scanned at build time (every register-layout kernel, the wide row kernels and the one file
+# that IS compiled with SLP vectorisation).  What is refused: a v_pk_fma_f32 that accumulates in place (destination pair ==
+# SrcC pair) on a register pair that one of the two preceding vector instructions wrote with a packed fp32 op -- the
+# pk_add -> pk_fma -> pk_mul chain on one pair that profiles/r04_flake/README.md pins the round-3 wrong-dx episodes to (47 of them
+# in an SLP build of cr_stack_bwd1.hip, none in production).  cr_common.hpp's cr_ln_bwd_tail keeps the source from forming it;
+# this keeps any other statement, flag or compiler version from forming it unseen.
+ISA_CHECKED = ["cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_attn_bf.hip"]
+SLP_PROTECTED = ("cr_stack", "cr_wide")          # file-name prefixes that may never be compiled with SLP vectorisation
+_PK_F32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
+_LABEL = re.compile(r"^([A-Za-z_$][\w$.]*):")
+_MODIFIER = re.compile(r"\s(op_sel|op_sel_hi|neg_lo|neg_hi|clamp|mul:|div:|quad_perm|row_|bank_mask|bound_ctrl|dst_sel|dst_unused|src\d_sel)")
+
+
+def _operands(rest):
+    m = _MODIFIER.search(" " + rest)
+    if m:
+        rest = (" " + rest)[:m.start()]
+    return [o.strip().lstrip("-").strip("|") for o in rest.split(",") if o.strip()]
+
+
+def scan_isa(text):
+    """Scans an AMDGPU assembly listing.  Returns dict(kernels, pk_fma, pk_add, pk_mul, in_place_any, violations) where a
+    violation is (function, line number, the chain's lines): see ISA_CHECKED."""
+    out = dict(kernels=0, pk_fma=0, pk_add=0, pk_mul=0, in_place_any=0, violations=[])
+    func, last = "?", []                                  # last: the two preceding vector instructions (mnemonic, dst, line)
+    for no, line in enumerate(text.splitlines(), 1):
+        if line and not line[0].isspace():
+            m = _LABEL.match(line)
+            if m and not line.startswith("."):            # a function's entry label (basic-block labels start with .LBB)
+                func, last = m.group(1), []
+                out["kernels"] += 1
+            continue
+        t = line.strip()
+        if not t.startswith("v_"):
+            continue
+        mn, _, rest = t.partition(" ")
+        ops = _operands(rest.split(";")[0])
+        dst = ops[0] if ops else ""
+        if mn in _PK_F32:
+            out[mn[2:-4]] += 1
+            if dst in ops[1:]:
+                out["in_place_any"] += 1
+            if mn == "v_pk_fma_f32" and len(ops) >= 4 and ops[3] == dst:
+                for pm, pd, pl in last:
+                    if pm in _PK_F32 and pd == dst:
+                        out["violations"].append((func, no, [pl, t]))
+                        break
+        last = (last + [(mn, dst, t)])[-2:]
+    return out
+
+
+def _source_digest(src, headers, flags):
+    h = hashlib.sha256()
+    for f in [src] + headers:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
+def isa_summary_path(source_name, timeline=False):
+    return os.path.join(CSRC, "build_tl" if timeline else "build", source_name + ".isa.json")
+
+
+def check_isa_file(source_name, flags, headers, hipcc=None, listing=None):
+    """Compiles one source to its gfx950 assembly with exactly `flags` (or reads `listing`), scans it, writes the summary beside
+    the objects and raises on a violation."""
+    src = os.path.join(CSRC, source_name)
+    if listing is None:
+        listing = os.path.join(CSRC, "build", source_name + ".s")
+        cmd = [hipcc or _hipcc()] + flags + ["-x", "hip", "-S", "--cuda-device-only", src, "-o", listing]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compile failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    with open(listing) as fh:
+        res = scan_isa(fh.read())
+    res["source"], res["digest"], res["flags"] = source_name, _source_digest(src, headers, flags), flags
+    with open(isa_summary_path(source_name), "w") as fh:
+        json.dump(res, fh, indent=1)
+    if res["violations"]:
+        f, no, chain = res["violations"][0]
+        raise RuntimeError("%s: %d in-place packed fp32 chains in the device code (first: %s, line %d: %s) -- see build.py ISA_CHECKED"
+                           % (source_name, len(res["violations"]), f, no, " ; ".join(chain)))
+    return res
+
+
+def isa_is_current(source_name, flags, headers):
+    """True when the ISA summary beside the objects was made from the present source, headers and flags, and is clean."""
+    try:
+        with open(isa_summary_path(source_name)) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return False
+    return d.get("digest") == _source_digest(os.path.join(CSRC, source_name), headers, flags) and not d.get("violations")
+
+
+def file_flags(source_name, timeline=False):
+    """The exact compile flags of one source (what build() uses and what the ISA check repeats)."""
+    extra = os.environ.get("CASTREC_EXTRA_FLAGS", "").split()
+    slp_ok = os.environ.get("CASTREC_SLP_FILES", "cr_attn_bf.hip").split()
+    # correctness of the register-layout kernels must not hang on an environment variable: SLP vectorisation cannot be switched
+    # back on for them, neither per file nor through the extra flags
+    bad = [f for f in slp_ok if f.startswith(SLP_PROTECTED)]
+    if bad:
+        raise RuntimeError("CASTREC_SLP_FILES names %s: these sources are never compiled with SLP vectorisation "
+                           "(profiles/r04_flake/README.md)" % bad)
+    if any(f in ("-fslp-vectorize", "-fvectorize-slp") or f.startswith("-fslp-vectorize") for f in extra):
+        raise RuntimeError("CASTREC_EXTRA_FLAGS may not re-enable SLP vectorisation (profiles/r04_flake/README.md)")
+    flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else []) + extra
+    return [f for f in flags if not (f == "-fno-slp-vectorize" and source_name in slp_ok)]
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -46,12 +163,10 @@ def build(force=False, verbose=False, timeline=False):
     hipcc = _hipcc()
     bdir = "build_tl" if timeline else "build"
     lib = LIB_TL if timeline else LIB
-    flags = FLAGS + (["-DCR_TIMELINE=1"] if timeline else []) + os.environ.get("CASTREC_EXTRA_FLAGS", "").split()
-    # sources compiled WITH SLP vectorisation all the same: cr_attn_bf.hip -- its head-dim-32 forward is 37 % slower without the
-    # packed fp32 arithmetic (config C4: 29.6 -> 40.6 us per launch); its 392 compiler-made v_pk_fma_f32 are all out-of-place (the
-    # failing form above is the in-place chain: 47 of them in the SLP build of cr_stack_bwd1.hip, none here), and 4 000 replays of a
-    # D = 128 / 4-head step hold the same bits (tools/diag_repro2.py, profiles/r04_flake/reproducibility_runs.json)
-    slp_ok = os.environ.get("CASTREC_SLP_FILES", "cr_attn_bf.hip").split()
+    # (sources compiled WITH SLP vectorisation all the same -- file_flags: cr_attn_bf.hip.  Its head-dim-32 forward is 37 % slower
+    # without the packed fp32 arithmetic (config C4: 29.6 -> 40.6 us per launch); its compiler-made v_pk_fma_f32 never accumulate in
+    # place behind a packed write of the same pair -- checked on every build, below -- and 4 000 replays of a D = 128 / 4-head step
+    # hold the same bits: tools/diag_repro2.py, profiles/r04_flake/reproducibility_runs.json)
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
     headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"), os.path.join(CSRC, "cr_rbwd.hpp"),
                os.path.join(ROOT, "include", "castrec.h")]
@@ -60,22 +175,38 @@ def build(force=False, verbose=False, timeline=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, bdir, s + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            fl = [f for f in flags if not (f == "-fno-slp-vectorize" and s in slp_ok)]
-            cmd = [hipcc] + fl + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
-            jobs.append(cmd)
+        fl = file_flags(s, timeline)
+        checked = s in ISA_CHECKED and not timeline
+        if checked and not force and not _stale(obj, [src] + headers) and not isa_is_current(s, fl, headers):
+            force_this = True                              # an object without a current ISA summary (older build, other flags)
+        else:
+            force_this = False
+        if force or force_this or _stale(obj, [src] + headers):
+            cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            jobs.append((cmd, s if checked else None, fl))
 
-    def run(cmd):
+    def run(job):
+        cmd, checked_src, fl = job if isinstance(job, tuple) else (job, None, None)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        if checked_src:
+            # the device listing -save-temps left beside the object: scanned (a violation fails the build), then the temporaries go
+            stem = checked_src[:-4]
+            bd = os.path.join(CSRC, bdir)
+            try:
+                check_isa_file(checked_src, fl, headers, listing=os.path.join(bd, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+            finally:
+                for f in glob.glob(os.path.join(bd, stem + "-hip-amdgcn-*")) + glob.glob(os.path.join(bd, stem + "-host-*")) \
+                        + glob.glob(os.path.join(bd, stem + ".hip-hip-*")):
+                    os.remove(f)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"])
+        run(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"], None, None))
     return lib
 
 

@@ -127,6 +127,24 @@ __device__ __forceinline__ float cr_row16_sum(float v) {
     return v;
 }
 
+// rstd * (dg - c1 - xhat * c2): the last statement of a LayerNorm backward, as THREE SCALAR instructions the compiler cannot
+// re-form.  Written in C++ it is, per element pair, what hipcc's SLP vectoriser turns into the in-place chain
+// v_pk_add_f32 t ; v_pk_fma_f32 t, xhat, c2, t ; v_pk_mul_f32 out, rstd, t  on ONE register pair -- the form whose middle
+// instruction's contribution went missing in 111 recorded replays of the one-launch block backward (profiles/r04_flake/README.md:
+// the trigger inside the kernel was never isolated, the necessary condition -- that chain -- was).  Inline assembly is opaque to
+// every IR pass, so no flag (CASTREC_EXTRA_FLAGS, a future default) can bring the packed chain back for these elements; the
+// build also scans the ISA of the register-layout kernels for the pattern (castrec_amd/build.py: check_isa, tests/test_isa.py).
+// Same arithmetic as the contracted C++ form: sub, fma with a negated product, mul -- each rounded once.
+__device__ __forceinline__ float cr_ln_bwd_tail(float dg, float c1, float xhat, float c2, float rstd) {
+    float t;
+    asm("v_sub_f32 %0, %1, %2\n\t"
+        "v_fma_f32 %0, -%3, %4, %0\n\t"
+        "v_mul_f32 %0, %5, %0"
+        : "=&v"(t)
+        : "v"(dg), "v"(c1), "v"(xhat), "v"(c2), "v"(rstd));
+    return t;
+}
+
 static inline int cr_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised, and that

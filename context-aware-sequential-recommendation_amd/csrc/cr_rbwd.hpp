@@ -250,11 +250,11 @@ __device__ __forceinline__ void r_ln_bwd(f32x4 (&dx)[4], const f32x4 (&x)[4], co
     for (int ct = 0; ct < 4; ++ct) {
         if (ct < dc.nfull) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dx[ct][r] = rstd * (dx[ct][r] - c1 - xc[ct][r] * c2);
+            for (int r = 0; r < 4; ++r) dx[ct][r] = cr_ln_bwd_tail(dx[ct][r], c1, xc[ct][r], c2, rstd);     // three scalar instructions, see there
         } else if (ct == dc.nfull) {
             const int lgb = (lane_now() >> 4) * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dx[ct][r] = (lgb + r < dc.rem) ? rstd * (dx[ct][r] - c1 - xc[ct][r] * c2) : 0.0f;
+            for (int r = 0; r < 4; ++r) dx[ct][r] = (lgb + r < dc.rem) ? cr_ln_bwd_tail(dx[ct][r], c1, xc[ct][r], c2, rstd) : 0.0f;
         } else {
             dx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }

@@ -734,7 +734,7 @@ __device__ __forceinline__ void wr_ln_bwd(f32x4 (&g)[NCT], f32x4 (&x)[NCT], cons
             for (int r = 0; r < 4; ++r) {
                 const float h = (x[4 * p + ct][r] - mean) * rs;
                 const float go = g[4 * p + ct][r];
-                g[4 * p + ct][r] = rs * (go * gm[ct][r] - c1 - h * c2);
+                g[4 * p + ct][r] = cr_ln_bwd_tail(go * gm[ct][r], c1, h, c2, rs);             // three scalar instructions (cr_common.hpp)
                 x[4 * p + ct][r] = go * h;
             }
     }

@@ -147,12 +147,22 @@ class DataParallel:
             import torch.distributed as dist
             dist.broadcast(replica.param_vector(), 0, group=process_group)       # same start everywhere
 
+    def request_capture(self, validate=True):
+        """Asks for the whole-step graph (capture_step).  The capture -- and the one rehearsed and one replayed step that validate
+        it -- run inside the next step(), once that step's batch sits in the replica's static id buffers: a capture made before
+        any batch exists would rehearse an all-padding batch, whose step moves no parameter and whose replicas agree trivially."""
+        self._capture_pending = bool(validate) if validate else None
+        self._capture_wanted = True
+
     def step(self, batch_global):
         """batch_global: tuple of [B_global, T] int arrays (seq, pos, neg, time, hours, days)."""
         lo, hi = shard_rows(len(batch_global[0]), self.rank, self.world)
         shard = tuple(a[lo:hi] for a in batch_global)
         if getattr(self.replica, "has_phases", False):
             self.replica.set_batch(shard)
+            if getattr(self, "_capture_wanted", False):
+                self._capture_wanted = False
+                self.capture_step(validate=self._capture_pending is not None)
             self.step_phases()
             return
         bucket = self.replica.backward_to_flat(shard)
@@ -196,60 +206,102 @@ class DataParallel:
     def capture_step(self, validate=True):
         """Tries to capture the WHOLE step -- the three phases and the collectives between them -- into one HIP graph (the
         collectives of torch.distributed's RCCL backend are stream-ordered and capturable; the sparse exchange's tag is a device
-        word).  One graph launch per step instead of three plus the host side of two collectives.  Returns False (and keeps the
-        three-graph form) when the capture is refused -- or, with more than one rank and `validate`, when one replayed step
-        leaves the replicas apart (_replayed_step_agrees)."""
+        word).  One graph launch per step instead of three plus the host side of two collectives.
+
+        Must run with a REAL batch in the replica's static id buffers (request_capture() defers it into the next step()).  The
+        replica's state (parameters, Adam moments, step counter, gradient bucket) is saved first and put back at the end, so the
+        rehearsals leave no trace: (1) one eager step on that batch -- every lazy initialisation (communicator, RowExchange
+        buffers) happens here -- whose parameters are the reference; (2) the capture; (3) with `validate`, ONE replayed step from
+        the same state, which must reproduce (1) and leave the replicas identical (_replayed_step_agrees).  Returns False, and
+        keeps the three-graph form, when the capture is refused or the replay does not agree; `step_form` / `step_form_why` say
+        which form runs, and why."""
         rep = self.replica
+        self.step_form, self.step_form_why = "three graphs", "no phases to capture"
         if not getattr(rep, "has_phases", False) or not hasattr(rep, "capture"):
             return False
-        captured = True
+        snap = rep.snapshot() if hasattr(rep, "snapshot") else None
+        captured, ref = True, None
         try:
-            self.step_phases(eager=True)                 # every lazy initialisation (communicator, RowExchange buffers) happens here
-            torch.cuda.synchronize()
+            self.step_phases(eager=True)
+            if rep.param_vector().is_cuda:
+                torch.cuda.synchronize()
+            ref = rep.param_vector().clone()
+            if snap is not None:
+                rep.restore(snap)
             self._step_graph = rep.capture(lambda: self.step_phases(eager=True))
-        except Exception:
+        except Exception as e:                           # noqa: BLE001 -- whatever refuses the capture: the other form runs
             self._step_graph = None
             captured = False
+            self.step_form_why = "capture refused: %s" % e
         if self.world > 1:
             # one verdict for all ranks: a rank alone on the other form would leave the rest waiting in a collective
             import torch.distributed as dist
             flag = torch.tensor([1.0 if captured else 0.0], device=self.replica.param_vector().device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
             captured = bool(flag.item() > 0.5)
-        if not captured:
+        ok = captured
+        if ok and validate:
+            if snap is not None:
+                rep.restore(snap)
+            ok = self._replayed_step_agrees(ref)
+        if snap is not None:
+            rep.restore(snap)
+        if not ok:
             self._step_graph = None
-            return False
-        if self.world > 1 and validate and not self._replayed_step_agrees():
-            self._step_graph = None                      # captured collectives that do not replay as they ran: the three-graph form
-            return False
-        return True
+            if captured:
+                self.step_form_why = "the replayed step did not agree: %s" % getattr(self, "_replay_report", "?")
+        else:
+            self.step_form, self.step_form_why = "one graph", ("validated by one replayed step" if validate else "not validated")
+        if os.environ.get("CASTREC_DP_VERBOSE", "1") != "0" and self.rank == 0:
+            import sys
+            print("[castrec_amd.dist] data-parallel step: %s (%s)" % (self.step_form, self.step_form_why), file=sys.stderr)
+        return ok
 
-    def _replayed_step_agrees(self):
-        """One REPLAYED step of the whole-step graph on every rank, then the replicas' parameter vectors compared over the ranks
-        (sum and sum of squares, finite and equal everywhere): a captured collective that did nothing, or reduced stale buffers,
-        leaves the replicas apart after one Adam step on different shards.  The parameters are put back afterwards (broadcast of
-        rank 0's) whatever the outcome, so the caller's state is one and the same on every rank."""
-        import torch.distributed as dist
+    def _replayed_step_agrees(self, ref=None, bitwise=None):
+        """One REPLAYED step of the whole-step graph on every rank, from the state the caller restored.  It must (a) move the
+        parameters, (b) leave them finite, (c) reproduce `ref` -- the parameters one eager step on the same batch and state gave:
+        bit for bit where the replica's step is reproducible (`bitwise`; default: the replica's own `bitwise_reproducible`), else
+        in all but a few elements (float atomics reorder the table gradient's last bits, and Adam's first steps turn a sign flip
+        of a ~0 gradient into a move of 2 lr; a collective that did not run or reduced a stale buffer moves nearly EVERY
+        element) -- and (d) leave the replicas identical over the ranks (sum and sum of squares all-gathered and compared).
+        The collective sequence is the same on every rank whatever happens locally: a launch that raises contributes NaN, then
+        all_gather and the verdict's all_reduce run all the same (a rank that skipped one would hang its peers)."""
         p = self.replica.param_vector()
         before = p.clone()
-        ok = True
+        launched = True
         try:
             self._step_graph.launch() if hasattr(self._step_graph, "launch") else self._step_graph.replay()
             if p.is_cuda:
                 torch.cuda.synchronize()
-            chk = torch.stack([p.double().sum(), (p.double() ** 2).sum()])
+        except Exception:                                # noqa: BLE001
+            launched = False
+        report = {}
+        report["launched"] = launched
+        report["moved"] = launched and bool((p != before).any())
+        report["finite"] = launched and bool(torch.isfinite(p).all())
+        if ref is not None and launched:
+            if bitwise is None:
+                bitwise = bool(getattr(self.replica, "bitwise_reproducible", False))
+            if bitwise:
+                report["matches_eager"] = bool(torch.equal(p, ref))
+            else:
+                scale = float(ref.abs().max()) + 1e-30
+                report["off_fraction"] = float(((p - ref).abs() > 1e-6 * max(scale, 1.0)).double().mean())
+                report["matches_eager"] = report["off_fraction"] < 1e-3
+        ok = all(v for k, v in report.items() if isinstance(v, bool))
+        chk = torch.stack([p.double().sum(), (p.double() ** 2).sum()]) if launched else torch.full((2,), float("nan"), dtype=torch.float64, device=p.device)
+        if self.world > 1:
+            import torch.distributed as dist
             got = [torch.empty_like(chk) for _ in range(self.world)]
             dist.all_gather(got, chk, group=self.pg)
-            ok = all(bool(torch.isfinite(g).all()) and bool(torch.equal(g, got[0])) for g in got)
-            moved = bool((p != before).any())
-            ok = ok and moved
-        except Exception:
-            ok = False
-        p.copy_(before)
-        dist.broadcast(p, 0, group=self.pg)
-        flag = torch.tensor([1.0 if ok else 0.0], device=p.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)      # one verdict for all ranks (a rank alone on the other form would hang the rest)
-        return bool(flag.item() > 0.5)
+            report["replicas_identical"] = all(bool(torch.isfinite(g).all()) and bool(torch.equal(g, got[0])) for g in got)
+            ok = ok and report["replicas_identical"]
+            flag = torch.tensor([1.0 if ok else 0.0], device=p.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)      # one verdict for all ranks (a rank alone on the other form would hang the rest)
+            ok = bool(flag.item() > 0.5)
+        self._replay_report = report
+        p.copy_(before)                                  # (callers with a snapshot restore everything; this covers the others)
+        return ok
 
     def exchange(self, bucket):
         """Sums `bucket` ([item table grads | small part]) over the ranks, in place."""
@@ -308,6 +360,24 @@ class EngineReplica:
 
     def param_vector(self):
         return self.e.P
+
+    def snapshot(self):
+        """Everything a step changes (parameters, Adam moments, the state block with the step counter and the loss sums, the
+        gradient bucket, row-sparse Adam's claim flags): capture_step's rehearsals are undone with restore()."""
+        e = self.e
+        snap = dict(P=e.P.clone(), Mom=e.Mom.clone(), Vel=e.Vel.clone(), state=e.state.clone(), Gflat=e.Gflat.clone())
+        if getattr(e, "lazy_flags", None) is not None:
+            snap["lazy_flags"] = e.lazy_flags.clone()
+        return snap
+
+    def restore(self, snap):
+        e = self.e
+        for k, v in snap.items():
+            getattr(e, k).copy_(v)
+
+    @property
+    def bitwise_reproducible(self):
+        return bool(getattr(self.e, "bitwise_reproducible", False))
 
     def backward_to_flat(self, shard):
         self.e.set_batch(*shard)

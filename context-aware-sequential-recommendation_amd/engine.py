@@ -1227,9 +1227,14 @@ class Engine:
         # k - n's own copy into the static buffers -- the new copy waits for the launch of step k - n
         # (a HOST wait, like the two in train_fed: step k - n ended long ago, while a device-side wait between two streams
         # costs ~10 us of the waiting stream's time on this stack -- measured as 17 us per step for a forked graph branch)
-        behind = [j for j in self._feed_done if j >= k - n]
-        if behind and k - n >= self._feed_first:
-            self._feed_done[min(behind)].synchronize()
+        if k - n >= self._feed_first:
+            behind = [j for j in self._feed_done if j >= k - n]
+            if behind:
+                self._feed_done[min(behind)].synchronize()
+            else:
+                # no recorded step at or behind the slot's last reader (cannot happen while train_fed records what it says it
+                # records; never skip the wait silently): the compute stream itself
+                torch.cuda.current_stream().synchronize()
         with torch.cuda.stream(self._feed_stream):
             self._feed_ring[slot].copy_(self._feed_host[slot], non_blocking=True)
             ev = torch.cuda.Event()
@@ -1264,10 +1269,17 @@ class Engine:
         else:
             self.launch_step()
         last = k + G - 1
-        if G > 1 or k % self._feed_every == 0:
+        # an event behind every step number that is a multiple of _feed_every -- feed()'s admission bound counts on one in every
+        # window of that many steps.  A launch of G steps records ONE event at its end and files it under every such step it
+        # covers (an upper bound for each of them) and under its last step.
+        marks = [j for j in range(k, last + 1) if j % self._feed_every == 0]
+        if G > 1 and last not in marks:
+            marks.append(last)
+        if marks:
             ev = torch.cuda.Event()
             ev.record(cur)
-            self._feed_done[last] = ev
+            for j in marks:
+                self._feed_done[j] = ev
             for old in [j for j in self._feed_done if j < last - n]:
                 del self._feed_done[old]
         self._feed_have -= G

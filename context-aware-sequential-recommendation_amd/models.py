@@ -68,9 +68,10 @@ class _Model(object):
                 if bounce:
                     rep.adopt_params()
                 if self._graph and not bounce and os.environ.get("CASTREC_DP_ONE_GRAPH") != "0":
-                    p0 = self._train.P.clone()                              # (the capture rehearses one eager step: undo its update)
-                    self._dp.capture_step()                                 # the whole step incl. the collectives as one HIP graph; validated by
-                    self._train.P.copy_(p0)                                 # one replayed step, else the three-graph form (dist.capture_step)
+                    # the whole step incl. the collectives as one HIP graph: captured and validated inside the FIRST train_step,
+                    # on that step's batch (an all-padding batch -- the static id buffers before any set_batch -- moves nothing
+                    # and validates nothing); else the three-graph form.  dist.DataParallel.step_form says which one runs.
+                    self._dp.request_capture()
                 if self._graph:
                     self._train.set_step(1); self._train.Mom.zero_(); self._train.Vel.zero_(); self._train.Gflat.zero_()
                 if self._pending_opt is not None:
@@ -130,7 +131,11 @@ class _Model(object):
         """Steps a graph launch of the fed training path runs when as many batches wait (Engine.capture(n_steps)): between two graph
         launches the device idles for the 5-9 us the next launch takes to start, 1-2 % of a 0.33 ms step.  CASTREC_STEPS_PER_GRAPH
         overrides the default of 4; 1 without HIP graphs, with row-sparse Adam, or data parallel."""
-        if not self._graph or getattr(self, "_dp", None) is not None or self._batch_global is not None or getattr(self, "_lazy_adam", False):
+        dp_cfg = getattr(self, "_dp_cfg", None)
+        data_parallel = getattr(self, "_dp", None) is not None or (dp_cfg is not None and dp_cfg[1] > 1)
+        # (row-sparse Adam: the engine's own setting once it exists, before that what it will read -- Engine.__init__)
+        lazy = self._train.lazy_adam if self._train is not None else bool(int(os.environ.get("CASTREC_LAZY_ADAM", "0")))
+        if not self._graph or data_parallel or self._batch_global is not None or lazy:
             return 1
         return max(1, int(os.environ.get("CASTREC_STEPS_PER_GRAPH", "4")))
 

@@ -98,3 +98,33 @@ def test_main_feeds_one_batch_ahead_in_sampler_order(tmp_path, monkeypatch, many
     from castrec_amd.tb_events import read_events
     ev = read_events(str(d / [x for x in os.listdir(d) if x.startswith("events.out.tfevents.")][0]))
     assert [s for s, _ in ev] == [1, 2, 3, 3] and ev[0][1]["TRAIN/loss"] == 1.0 and abs(ev[3][1]["TEST/HR@10"] - 0.2) < 1e-7
+
+
+def test_steps_per_launch_is_one_for_data_parallel_and_row_sparse_adam(monkeypatch):
+    """Model.steps_per_launch / feed_ahead before the first feed() (main.py reads feed_ahead there): 1 under data parallelism (from
+    the configuration data_parallel() stored, the wrapper itself exists only after the first step) and with row-sparse Adam (the
+    engine's setting, or what it will read from the environment); 4 / 5 otherwise."""
+    import castrec_amd  # noqa: F401
+    from castrec_amd import models
+
+    def bare(**kw):
+        m = object.__new__(models.SASRec)
+        m._graph, m._train, m._batch_global = True, None, None
+        m.__dict__.update(kw)
+        return m
+
+    monkeypatch.delenv("CASTREC_LAZY_ADAM", raising=False)
+    monkeypatch.delenv("CASTREC_STEPS_PER_GRAPH", raising=False)
+    assert bare().steps_per_launch == 4 and bare().feed_ahead == 5
+    assert bare(_dp_cfg=(0, 2, None, None)).steps_per_launch == 1 and bare(_dp_cfg=(0, 2, None, None)).feed_ahead == 1
+    assert bare(_dp_cfg=(0, 1, None, None)).steps_per_launch == 4              # one rank: the plain step
+    assert bare(_graph=False).steps_per_launch == 1
+
+    class Eng:
+        lazy_adam = True
+    assert bare(_train=Eng()).steps_per_launch == 1
+    monkeypatch.setenv("CASTREC_LAZY_ADAM", "1")
+    assert bare().steps_per_launch == 1 and bare().feed_ahead == 1
+    monkeypatch.setenv("CASTREC_LAZY_ADAM", "0")
+    monkeypatch.setenv("CASTREC_STEPS_PER_GRAPH", "8")
+    assert bare().steps_per_launch == 8 and bare().feed_ahead == 9

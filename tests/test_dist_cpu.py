@@ -179,6 +179,89 @@ def test_whole_step_graph_is_validated_by_one_replayed_step():
         assert out[1] == (False, 0.0), (rank, out)
 
 
+class _PhasedReplica:
+    """A replica with phases and a "graph" (a closure that re-runs what was captured): what DataParallel.capture_step drives."""
+    has_phases = True
+
+    def __init__(self):
+        self.vec = torch.zeros(16, dtype=torch.float64)
+        self.buck = torch.zeros(20, dtype=torch.float64)
+        self.batch = None
+
+    def param_vector(self):
+        return self.vec
+
+    def set_batch(self, shard):
+        self.batch = shard
+
+    def bucket(self):
+        return self.buck
+
+    def sparse_spec(self):
+        return dict(n_item=8, D=4, n_slots=4, ids=lambda: torch.zeros(4, dtype=torch.int64))
+
+    def phase(self, i, eager=False):
+        if i == 0:
+            self.buck[:] = float(np.sum(self.batch[0]))      # this shard's "gradient": zero for an all-padding shard
+        elif i == 2:
+            self.vec -= 0.1 * self.buck[:16]
+
+    def capture(self, fn):
+        class _G:
+            def launch(self_):
+                fn()
+        return _G()
+
+    def snapshot(self):
+        return dict(vec=self.vec.clone(), buck=self.buck.clone())
+
+    def restore(self, snap):
+        self.vec.copy_(snap["vec"]); self.buck.copy_(snap["buck"])
+
+
+def _capture_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CASTREC_DP_VERBOSE="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for first in ("padding", "real"):
+        rep = _PhasedReplica()
+        dp = DataParallel(rep, rank, world, sparse=False)
+        dp.request_capture()
+        assert dp._step_graph is None                      # nothing is captured before a batch exists
+        B = 2 * world
+        ids = np.zeros((B, 4), np.int64) if first == "padding" else np.arange(1, 4 * B + 1).reshape(B, 4)
+        dp.step((ids,) * 6)
+        out.append((dp.step_form, dp.step_form_why, dp._step_graph is not None, rep.vec.clone().numpy()))
+        dp.step((np.arange(1, 4 * B + 1).reshape(B, 4),) * 6)
+        out[-1] += (rep.vec.clone().numpy(),)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_capture_waits_for_a_real_batch_and_says_which_form_runs():
+    """request_capture() defers the whole-step capture into the first step(): validated on THAT batch.  A first batch of padding
+    only moves no parameter, the validation refuses it and the three-graph form runs -- visibly (step_form / step_form_why), on every
+    rank alike; a real batch validates and the replayed graph gives the same parameters as the phases."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_capture_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in procs])
+    for p in procs:
+        p.join(timeout=30)
+    total = float(np.arange(1, 17).sum())                      # both shards' "gradients", all-reduced
+    for rank, out in res:
+        form, why, has_graph, v1, v2 = out[0]
+        assert form == "three graphs" and "'moved': False" in why and not has_graph, out[0][:3]
+        assert np.all(v1 == 0.0) and np.allclose(v2, -0.1 * total)          # the rehearsals left no trace; the next step is a plain one
+        form, why, has_graph, v1, v2 = out[1]
+        assert form == "one graph" and has_graph, out[1][:3]
+        assert np.allclose(v1, -0.1 * total) and np.allclose(v2, -0.2 * total)
+
+
 def test_exchange_picks_the_cheaper_form():
     from castrec_amd.dist import dense_allreduce_bytes, sparse_exchange_bytes
     # C3 (Beauty, V = 57 290, D = 64, B 128 x T 50 per rank, 8 ranks): dense 25.7 MB < sparse 34.9 MB

@@ -250,15 +250,19 @@ def test_graph_resident_step_with_the_collectives_on_one_rank(sparse, one_graph)
         rep = EngineReplica(b, use_graph=True)
         dp = DataParallel(rep, 0, 1, sparse=sparse, force_collectives=True)
         assert dp.sparse == sparse
-        if one_graph:                                          # the whole step, collectives included, as ONE HIP graph
-            assert dp.capture_step()
-            b.P.copy_(a.P)                                     # (the capture's eager rehearsal took an optimiser step)
         b.set_step(1); b.Mom.zero_(); b.Vel.zero_(); b.Gflat.zero_()
+        if one_graph:                                          # the whole step, collectives included, as ONE HIP graph
+            # captured and validated inside the first step, on that step's batch (an all-padding batch would move nothing and the
+            # validation -- one replayed step against one eager step from the same state -- would refuse it)
+            dp.request_capture()
         for st in range(STEPS):
             batch = make_batch(st, items)
             a.train_step(*batch)
             dp.step(batch)
         torch.cuda.synchronize()
+        if one_graph:
+            assert dp.step_form == "one graph", dp.step_form_why
+            assert dp._replay_report["moved"] and dp._replay_report["matches_eager"], dp._replay_report
         pa, pb = a.get_params(), b.get_params()
         for k in pa:
             if k.endswith(".bk"):

@@ -741,6 +741,48 @@ def test_several_fed_steps_per_graph_launch(E):
     assert same_run(a, b) and same_loss_auc(a, b, batches[-1][1])
 
 
+def test_deep_feeding_around_multi_step_launches_keeps_slot_reuse_ordered(E):
+    """Twelve batches fed ahead in the 16-slot ring (the Engine API's bound; main.py keeps five), single steps and four-step launches
+    mixed so that the ring wraps twice: every step number that is a multiple of four carries an event (a four-step launch files its
+    end-of-launch event under each such step it covers), so feed() always finds a recorded step at or behind a slot's last reader
+    before it overwrites the slot -- and the run equals a step per call."""
+    rs = np.random.RandomState(23)
+    B, T, D, itemnum = 5, 32, 50, 80
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=20, seed=6)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    b.P.copy_(a.P)
+    b.capture()
+    b.enable_feed(n_slots=16, steps_per_graph=4)
+    batches = [make_batch(rs, B, T, itemnum, 20) for _ in range(40)]
+    for bt in batches:
+        a.train_step(*bt)
+    it = iter(batches)
+    fed = ran = 0
+
+    def top_up(n):
+        nonlocal fed
+        while fed - ran < n and fed < len(batches):
+            b.feed(*next(it)); fed += 1
+    pattern = [1, 1, 1, 4, 1, 1, 1, 4, 4, 1, 4, 4, 1, 1, 1, 4, 1, 4]          # singles in front of multi-step launches, as ADVICE round 4 drew it
+    for want in pattern:
+        top_up(12)
+        got = b.train_fed(max_steps=None if want == 4 else 1)
+        assert got == want, (got, want)
+        ran += got
+        marks = [j for j in b._feed_done]
+        assert all(j % 4 == 0 or b._feed_done[j] is not None for j in marks)
+        # every window of four steps behind the last launched one holds a recorded step
+        last = b._feed_next - b._feed_have - 1
+        assert any(j in b._feed_done for j in range(max(last - 3, b._feed_first), last + 1)) or last < b._feed_first + 3, (last, sorted(b._feed_done))
+    while ran < len(batches):
+        top_up(12)
+        ran += b.train_fed()
+    torch.cuda.synchronize()
+    assert ran == len(batches) and b.step_number() == a.step_number()
+    assert same_run(a, b) and same_loss_auc(a, b, batches[-1][1])
+
+
 @pytest.mark.parametrize("graph,n_slots", [(False, 4), (True, 4), (True, 8)])
 def test_fed_batches_train_like_batches_set_per_step(E, graph, n_slots):
     """Engine.enable_feed / feed / train_fed: pinned host batches sent ahead over a copy stream into the id ring.  Every
