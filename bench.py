@@ -113,7 +113,20 @@ def algo_work(name, fnargs, eng):
         return None, (3.0 * M * D * 4 + M * 4), "hbm"             # grad read + row read-modify-write
     if name == "cr_head_fwd_bwd":
         return None, (2.0 * M * D * 4 + M * 8) + 2.0 * M * D * 4 + 2.0 * 2 * M * D * 4, "hbm"
+    if name == "cr_head_fwd_bwd_ln":
+        # the training-path pos / neg gather: two table rows per batch row + its ids, the sequence-embedding row and the final
+        # LayerNorm's input row read, the LayerNorm-backward row written; then either the two logit derivatives per row (occurrence
+        # index: the table gradient is gathered in cr_adam_step) or the scatter's read-modify-write of two table-gradient rows
+        scatter = 2.0 * 2 * M * D * 4 if fnargs[0]._obj.table_grad else 8.0 * M
+        return None, 2.0 * M * D * 4 + 8.0 * M + 2.0 * M * D * 4 + 1.0 * M * D * 4 + scatter, "hbm"
     if name == "cr_adam_step":
+        d = fnargs[0]._obj
+        if d.tg:
+            # occurrence index: p / m / v read and written for every parameter; the table gradient is never stored -- its rows are
+            # gathered: per occurrence one gradient row (seq: two partials) + the occurrence word, per pos / neg one coefficient
+            g = d.tg.contents
+            rows = (2.0 if g.rows2 else 1.0) * M + 2.0 * M + (M if g.lay.T_pos else 0)
+            return None, 6.0 * 4 * eng.layout.n_total + 4.0 * eng.layout.n_dense + rows * D * 4 + 4.0 * 4 * M, "hbm"
         return None, 7.0 * 4 * eng.layout.n_total, "hbm"
     # fused row-phase kernels: GEMM flops of the phases each one holds
     if name in ("cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather"):
@@ -163,7 +176,7 @@ def kernel_profile(eng, staged, n_steps=8):
     prog = eng.fwd + eng.bwd + [eng._adam]
     eng.Gflat.zero_()
     for it in range(n_steps + 2):
-        eng.ids_all.copy_(staged[it % staged.shape[0]])
+        eng.load_slot(staged[eng.step_number() % staged.shape[0]])        # (slot = step number mod slots: where Adam looks for the batch's occurrence index)
         torch.cuda._sleep(1_000_000)
         rec = []
         for name, fn, a in prog:
@@ -389,11 +402,38 @@ def gather_block(reps=24):
     us_b = timed(lambda k: O.test_logits(semb, D, table, cand[k], Bq, 1, D, logits))
     rd_a, wr_a = M * (D * 4 + 4), M * D * 4
     rd_b = Bq * nc * (D * 4 + 4)
+    # (c) the head kernel of the training step (cr_head_fwd_bwd_ln: sasrec.py:87-101 + the final LayerNorm's backward) at the same
+    # table: the pos / neg rows of one C5 step, fresh ids per launch; the table gradient goes through the occurrence index, so the
+    # kernel's table traffic is these two reads per batch row
+    import ctypes as C
+    from castrec_amd import lib as L
+    pn = torch.from_numpy(rs.randint(1, V, (NW + reps, 2, M)).astype(np.int32)).cuda()
+    semb_h, x_h, dx_h = torch.randn(M, D, device="cuda"), torch.randn(M, D, device="cuda"), torch.empty(M, D, device="cuda")
+    gam = torch.ones(D, device="cuda")
+    n_sl = 256
+    slabs = torch.zeros(n_sl, 2 * D, device="cuda")
+    coef = torch.empty(2, M, device="cuda")
+    hstate = torch.zeros(16, device="cuda")
+
+    def head(k):
+        hd = L.HeadDesc(semb_h.data_ptr(), D, table.data_ptr(), pn[k, 0].data_ptr(), pn[k, 1].data_ptr(), M, D, V, hstate.data_ptr(), None, 0,
+                        None, None, None, coef.data_ptr())
+        nd = L.LnBwdDesc(x_h.data_ptr(), D, gam.data_ptr(), None, 0, dx_h.data_ptr(), D, 0, slabs.data_ptr(), slabs.data_ptr() + 4 * D, 2 * D, n_sl, M, D, 1e-8)
+        L.call("cr_head_fwd_bwd_ln", C.byref(hd), C.byref(nd), torch.cuda.current_stream().cuda_stream)
+    us_c = timed(head)
+    rd_c_table = 2 * M * (D * 4 + 4)
+    all_c = rd_c_table + 2 * M * D * 4 + M * D * 4 + 8 * M
     res = dict(table="10M x 256 fp32 (10.24 GB), uniform rows, a fresh row set per launch", peak_GBps=8000.0, launches_timed=reps,
                embed_fwd=dict(rows=M, us=round(us_a, 1), read_GBps=round(rd_a / us_a / 1e3, 1), read_write_GBps=round((rd_a + wr_a) / us_a / 1e3, 1),
                               read_frac=round(rd_a / us_a / 1e3 / 8000.0, 4), read_write_frac=round((rd_a + wr_a) / us_a / 1e3 / 8000.0, 4)),
                read_only=dict(kernel="cr_test_logits", rows=Bq * nc, us=round(us_b, 1), read_GBps=round(rd_b / us_b / 1e3, 1),
                               read_frac=round(rd_b / us_b / 1e3 / 8000.0, 4)),
+               head_ln=dict(kernel="cr_head_fwd_bwd_ln", table_rows=2 * M, us=round(us_c, 1), table_read_GBps=round(rd_c_table / us_c / 1e3, 1),
+                            table_read_frac=round(rd_c_table / us_c / 1e3 / 8000.0, 4), all_bytes_GBps=round(all_c / us_c / 1e3, 1),
+                            all_bytes_frac=round(all_c / us_c / 1e3 / 8000.0, 4),
+                            note="the training step's pos / neg gather: per batch row two table rows (fresh: HBM) + the sequence-embedding row "
+                                 "and the LayerNorm input row (streamed) read, one gradient row written; all_bytes_frac is the number to hold "
+                                 "against the roof"),
                note="MI355X_MICROARCH.md: float4 copy ceiling 6.29 TB/s (79 % of the 8 TB/s spec); random whole-row gathers into "
                     "registers 5.5-5.8 TB/s.  embed_fwd (the training-path gather) writes as many bytes as it reads: read_write_frac is "
                     "its number to hold against the roof; the read-only form is the one to hold against the >= 70 % READ target")
@@ -403,7 +443,7 @@ def gather_block(reps=24):
     if prof:
         try:
             pj = json.load(open(prof[-1]))
-            for key, kern, nbytes in (("read_only", "k_test_logits", rd_b), ("embed_fwd", "k_embed_fwd", rd_a + wr_a)):
+            for key, kern, nbytes in (("read_only", "k_test_logits", rd_b), ("embed_fwd", "k_embed_fwd", rd_a + wr_a), ("head_ln", "k_head_ln", all_c)):
                 ent = [v for k, v in pj.items() if k.startswith(kern)]
                 if ent:
                     us = ent[0]["avg_ns"] / 1e3
@@ -489,7 +529,7 @@ def main():
         sl = slice(rank * B, (rank + 1) * B)
         host_batches.append((seq[sl], pos[sl], neg[sl], ts[sl], hrs[sl], dys[sl]))
     smp.close()
-    staged = torch.from_numpy(np.stack([np.stack([a.reshape(-1) for a in hb]) for hb in host_batches]).astype(np.int32)).cuda()
+    # (the batches are packed per engine: a slot = the six id rows + the batch's occurrence index, Engine.pack_slot)
 
     conditioning = []
 
@@ -498,6 +538,8 @@ def main():
                        batch_global=Bg, row_offset=rank * B * T, attn_precision=precision, lazy_adam=args.lazy_adam)
         dp = None
         use_graph = not args.no_graph
+        staged = torch.from_numpy(np.stack([eng.pack_slot(*hb) for hb in host_batches])).cuda()
+        run.staged = staged
         ring = (dist is None or not args.lazy_adam) and os.environ.get("CASTREC_NO_ID_RING") != "1"
         if ring:
             # the NB staged batches ARE the id ring: a step ends by moving the next step's batch (slot = step number mod NB) into
@@ -507,7 +549,7 @@ def main():
         if dist is not None:
             # data-parallel step: three HIP graphs (forward + backward up to the last table-gradient launch | rest of the backward
             # + slab collapse | Adam) around the collectives; the table's exchange runs beside the second graph (dist.step_phases)
-            eng.ids_all.copy_(staged[0])
+            eng.load_slot(staged[0])
             rep = D_.EngineReplica(eng, use_graph=use_graph)
             dp = D_.DataParallel(rep, rank, world, sparse={"auto": None, "on": True, "off": False}[args.sparse_exchange],
                                  force_collectives=force_dist)
@@ -523,15 +565,15 @@ def main():
         spg = max(1, int(os.environ.get("CASTREC_STEPS_PER_GRAPH", "4"))) if (ring and dist is None and use_graph and not args.lazy_adam) else 1
         run.spg = spg
         if dist is None and use_graph:
-            eng.ids_all.copy_(staged[0])
+            eng.load_slot(staged[0])
             eng.capture(n_steps=spg)
             eng.set_step(1); eng.Mom.zero_(); eng.Vel.zero_(); eng.Gflat.zero_()
         if ring:
-            eng.ids_all.copy_(staged[eng.step_number() % NB])
+            eng.load_slot(staged[eng.step_number() % NB])
 
         def step(i):
             if not ring:
-                eng.ids_all.copy_(staged[i % NB])
+                eng.load_slot(staged[i % NB])
             if dp is None:
                 if use_graph:
                     eng.graph.launch()
@@ -600,7 +642,7 @@ def main():
     prec = eng.attn_precision
 
     if rank == 0:
-        per_launch, by_name = kernel_profile(eng, staged)
+        per_launch, by_name = kernel_profile(eng, run.staged)
         dom = max(by_name.items(), key=lambda kv: kv[1]["us"])
         name, d = dom
         bound = d["bound"]

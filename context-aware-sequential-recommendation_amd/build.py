@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcastrec.so")
 LIB_TL = os.path.join(PKG, "libcastrec_tl.so")
 SOURCES = ["cr_base.hip", "cr_embed.hip", "cr_layernorm.hip", "cr_eltwise.hip", "cr_gemm.hip",
-           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_head.hip", "cr_adam.hip", "cr_dist.hip", "cr_sampler.cpp"]
+           "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_attn_wide.hip", "cr_attn_bf.hip", "cr_gemm_bf.hip", "cr_block.hip", "cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_head.hip", "cr_adam.hip", "cr_tgrad.hip", "cr_dist.hip", "cr_sampler.cpp", "cr_index.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wall", "-Wno-unused-function",
          # no SLP vectorisation: it packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  (a) Beside MFMAs those cost more
@@ -143,6 +143,13 @@ def file_flags(source_name, timeline=False):
     return [f for f in flags if not (f == "-fno-slp-vectorize" and source_name in slp_ok)]
 
 
+# every object depends on these (a change rebuilds the library; the ISA summaries carry their digest)
+HEADERS = [os.path.join(CSRC, h) for h in ("cr_common.hpp", "cr_attn_common.hpp", "cr_bf16.hpp", "cr_rlayout.hpp", "cr_rbwd.hpp")] \
+    + [os.path.join(ROOT, "include", "castrec.h")]
+# ... and single sources on these besides
+EXTRA_DEPS = {"cr_adam.hip": ["cr_tgrad.hpp"], "cr_tgrad.hip": ["cr_tgrad.hpp"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -168,8 +175,7 @@ def build(force=False, verbose=False, timeline=False):
     # place behind a packed write of the same pair -- checked on every build, below -- and 4 000 replays of a D = 128 / 4-head step
     # hold the same bits: tools/diag_repro2.py, profiles/r04_flake/reproducibility_runs.json)
     os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
-    headers = [os.path.join(CSRC, "cr_common.hpp"), os.path.join(CSRC, "cr_attn_common.hpp"), os.path.join(CSRC, "cr_bf16.hpp"), os.path.join(CSRC, "cr_rlayout.hpp"), os.path.join(CSRC, "cr_rbwd.hpp"),
-               os.path.join(ROOT, "include", "castrec.h")]
+    headers = HEADERS
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -177,11 +183,12 @@ def build(force=False, verbose=False, timeline=False):
         objs.append(obj)
         fl = file_flags(s, timeline)
         checked = s in ISA_CHECKED and not timeline
-        if checked and not force and not _stale(obj, [src] + headers) and not isa_is_current(s, fl, headers):
+        deps = [src] + headers + [os.path.join(CSRC, h) for h in EXTRA_DEPS.get(s, [])]
+        if checked and not force and not _stale(obj, deps) and not isa_is_current(s, fl, headers):
             force_this = True                              # an object without a current ISA summary (older build, other flags)
         else:
             force_this = False
-        if force or force_this or _stale(obj, [src] + headers):
+        if force or force_this or _stale(obj, deps):
             cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append((cmd, s if checked else None, fl))
 

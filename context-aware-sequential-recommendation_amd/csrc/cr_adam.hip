@@ -6,8 +6,12 @@
 // normalisation by n_target, reduction of the dense-parameter slabs, zeroing of the table gradient.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "cr_common.hpp"
+#include "cr_tgrad.hpp"
+
+int tg_unit_grid(const cr_tgrad_desc* d);     // cr_tgrad.hip
 
 // Sum of the gradient slabs for ADAM_COLS = 256 consecutive dense parameters [j0, j0 + 256): wave w of the block's
 // ADAM_WAVES waves adds slabs w, w + 16, w + 32, ... -- each read is 1 KiB contiguous (16 bytes per lane; the first version
@@ -55,22 +59,29 @@ __device__ __forceinline__ float slab_sum256(const float* slabs, int n_slabs, in
 // of config C5 (71.7 GB per step): 14.2 -> 13.6 ms.  (Four groups cost 76 bytes of scratch at this kernel's 128 registers -- the four
 // arrays' 64-bit addresses; a contiguous region per workgroup, which needs one 32-bit offset only, ran the sweep 20 % SLOWER: 256
 // separate streams per array instead of one moving window.)
-template <bool STREAM>
-__global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb_dense, int nb_lazy, int nb_ring) {
-    __shared__ float part[ADAM_WAVES][ADAM_COLS];
-    cr_kernarg_touch<sizeof(cr_adam_desc)>();
+// LPR > 0 (with VEC): the table section's gradient comes from the batch's occurrence index `g` (cr_tgrad.hpp): nb_units blocks sum
+// the listed rows and update them in place, the sweep blocks give every row WITHOUT a unit the zero-gradient update -- no table_grad
+// array is read or zeroed (two of the sweep's eight streams: config C5's dense step moves 53.8 instead of 71.7 GB).
+template <bool STREAM, int LPR, int VEC>
+__global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgrad_desc g, int nb_dense, int nb_lazy, int nb_units, int nb_ring) {
+    __shared__ float part_s[ADAM_WAVES * ADAM_COLS + 4];                         // (+ one word: "this slice arrived last", cr_tgrad.hpp)
+    float (*part)[ADAM_COLS] = reinterpret_cast<float (*)[ADAM_COLS]>(part_s);
+    constexpr bool TG = LPR > 0;
+    cr_kernarg_touch<sizeof(cr_adam_desc) + (TG ? sizeof(cr_tgrad_desc) : 0)>();
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
     if ((int)blockIdx.x >= (int)gridDim.x - nb_ring) {
-        // the last nb_ring blocks: the next step's ids out of the resident ring (nothing else in this launch reads ids)
+        // the last nb_ring blocks: the next step's ids out of the resident ring (nothing else in this launch reads the static id
+        // buffers; the occurrence index of the RUNNING step is read from its ring slot, which these blocks do not write)
         constexpr int NT = 64 * ADAM_WAVES;
+        const long long n_copy = d.ids_copy_elems ? d.ids_copy_elems : d.ids_slot_elems;
         const int32_t* src1 = d.ids_ring + (long long)((t + 1u) % (uint32_t)d.ids_ring_slots) * d.ids_slot_elems;
         const long long first = (long long)((int)blockIdx.x - ((int)gridDim.x - nb_ring)) * NT + threadIdx.x, stride = (long long)nb_ring * NT;
-        if ((d.ids_slot_elems & 3) == 0 && (((uintptr_t)d.ids_ring | (uintptr_t)d.ids_dst) & 15) == 0) {
+        if ((d.ids_slot_elems & 3) == 0 && (n_copy & 3) == 0 && (((uintptr_t)d.ids_ring | (uintptr_t)d.ids_dst) & 15) == 0) {
             const int4* src = reinterpret_cast<const int4*>(src1);
             int4* dst = reinterpret_cast<int4*>(d.ids_dst);
-            for (long long i = first; i < (d.ids_slot_elems >> 2); i += stride) dst[i] = src[i];
+            for (long long i = first; i < (n_copy >> 2); i += stride) dst[i] = src[i];
         } else {                                         // (a slot that is no multiple of 16 bytes: B * T odd)
-            for (long long i = first; i < d.ids_slot_elems; i += stride) d.ids_dst[i] = src1[i];
+            for (long long i = first; i < n_copy; i += stride) d.ids_dst[i] = src1[i];
         }
         return;
     }
@@ -131,6 +142,75 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb
                 d.table_grad[i] = 0.0f;
                 update(i, g);
             }
+        }
+    } else if (TG && (int)blockIdx.x < nb_dense + nb_lazy + nb_units) {
+        // the rows the batch looked up: gradient = ordered sum over the row's occurrences, update in place
+        const int32_t* ix = tg_index(g, t);
+        scalars();
+        tg_unit_blocks<TG ? LPR : 16, TG ? VEC : 1, (TG && VEC == 4) ? 8 : 16>(g, ix, (int)blockIdx.x - nb_dense - nb_lazy, nb_units, part_s,
+            reinterpret_cast<int*>(part_s + ADAM_WAVES * ADAM_COLS), [&](int row, int col0, const float (&acc)[TG ? VEC : 1]) {
+                constexpr int W = TG ? VEC : 1;
+                const long long i = (long long)row * g.D + col0;
+                float p[W], m[W], v[W];
+                tg_load<W>(p, d.p + i); tg_load<W>(m, d.m + i); tg_load<W>(v, d.v + i);
+#pragma unroll
+                for (int u = 0; u < W; ++u) {
+                    float gu = acc[u] * inv_n;
+                    if (i + u < d.n_l2) gu = fmaf(d.l2, p[u], gu);
+                    m[u] = d.beta1 * m[u] + (1.0f - d.beta1) * gu;
+                    v[u] = d.beta2 * v[u] + (1.0f - d.beta2) * gu * gu;
+                    p[u] -= lr_t * m[u] / (sqrtf(v[u]) + d.eps);
+                }
+                tg_store<W>(d.m + i, m); tg_store<W>(d.v + i, v); tg_store<W>(d.p + i, p);
+            });
+    } else if (TG) {
+        // the rows WITHOUT a unit: the zero-gradient update of TensorFlow's dense Adam (m, v decay, p moves on its momentum)
+        const int32_t* ix = tg_index(g, t);
+        const uint32_t* bits = reinterpret_cast<const uint32_t*>(ix + ix[6]);
+        const int nb_table = gridDim.x - nb_dense - nb_lazy - nb_units - nb_ring;
+        const int tb = (int)blockIdx.x - nb_dense - nb_lazy - nb_units;
+        constexpr int NT = 64 * ADAM_WAVES;
+        const long long stride = (long long)nb_table * NT;
+        auto touched = [&](uint32_t row) { return ((bits[row >> 5] >> (row & 31)) & 1u) != 0u; };
+        scalars();
+        if ((g.D & 3) == 0) {
+            const float b1 = d.beta1, b2 = d.beta2, c1 = 1.0f - d.beta1, c2 = 1.0f - d.beta2;
+            auto ld4 = [](const float* q) { return STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f4a*>(q)) : *reinterpret_cast<const f4a*>(q); };
+            auto st4 = [](float* q, const f4a x) {
+                if (STREAM) __builtin_nontemporal_store(x, reinterpret_cast<f4a*>(q));
+                else *reinterpret_cast<f4a*>(q) = x;
+            };
+            const long long n4 = d.n_table >> 2;
+            const unsigned D4 = (unsigned)g.D >> 2;
+            constexpr int U = 4;
+            for (long long q = (long long)tb * NT + threadIdx.x; q < n4; q += U * stride) {
+                bool go[U];
+                f4a p[U], m[U], v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long long qq = q + u * stride;
+                    go[u] = qq < n4 && !touched((uint32_t)((unsigned long long)qq / D4));
+                    if (go[u]) { p[u] = ld4(d.p + 4 * qq); m[u] = ld4(d.m + 4 * qq); v[u] = ld4(d.v + 4 * qq); }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!go[u]) continue;
+                    const long long i = 4 * (q + u * stride);
+                    f4a po;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float gu = 0.0f;
+                        if (i + e < d.n_l2) gu = fmaf(d.l2, p[u][e], gu);
+                        m[u][e] = b1 * m[u][e] + c1 * gu;
+                        v[u][e] = b2 * v[u][e] + c2 * gu * gu;
+                        po[e] = p[u][e] - lr_t * m[u][e] / (sqrtf(v[u][e]) + d.eps);
+                    }
+                    st4(d.m + i, m[u]); st4(d.v + i, v[u]); st4(d.p + i, po);
+                }
+            }
+        } else {
+            for (long long i = (long long)tb * NT + threadIdx.x; i < d.n_table; i += stride)
+                if (!touched((uint32_t)((unsigned long long)i / (unsigned)g.D))) update(i, 0.0f);
         }
     } else {
         // table section: 16 bytes per lane per array (4-byte accesses moved 3.2 TB/s on a 188 MB table), two
@@ -228,7 +308,7 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, int nb
 extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     CR_REQUIRE(d && d->p && d->m && d->v && d->state, "cr_adam_step: NULL pointer");
     CR_REQUIRE(d->n_table >= 0 && d->n_dense >= 0 && d->n_table + d->n_dense > 0, "cr_adam_step: bad sizes");
-    CR_REQUIRE(d->n_table == 0 || d->table_grad, "cr_adam_step: table_grad is NULL");
+    CR_REQUIRE(d->n_table == 0 || d->table_grad || d->tg, "cr_adam_step: table_grad is NULL");
     CR_REQUIRE(d->n_dense == 0 || (d->dense_slabs && d->n_slabs > 0), "cr_adam_step: dense_slabs missing");
     CR_REQUIRE(d->step_snapshot == nullptr || d->stats != nullptr, "cr_adam_step: step_snapshot needs stats (a copy of the sums that does not alias state[0..2])");
     const int nb_dense = cr_ceil_div(d->n_dense, ADAM_COLS);
@@ -249,13 +329,46 @@ extern "C" int cr_adam_step(const cr_adam_desc* d, void* stream) {
     if (d->ids_ring) {
         CR_REQUIRE(d->lazy_ids == nullptr, "cr_adam_step: ids_ring and lazy_ids exclude each other (row-sparse Adam reads the step's ids)");
         CR_REQUIRE(d->ids_dst && d->ids_ring_slots > 0 && d->ids_slot_elems > 0, "cr_adam_step: bad id-ring arguments");
-        const long long slot4 = (d->ids_slot_elems + 3) / 4;
+        CR_REQUIRE(d->ids_copy_elems >= 0 && d->ids_copy_elems <= d->ids_slot_elems, "cr_adam_step: ids_copy_elems exceeds the slot");
+        const long long slot4 = ((d->ids_copy_elems ? d->ids_copy_elems : d->ids_slot_elems) + 3) / 4;
         nb_ring = (int)((slot4 + NT - 1) / NT > 256 ? 256 : (slot4 + NT - 1) / NT);
     }
     static const char* nt_env = getenv("CASTREC_ADAM_STREAM");
     const bool stream_sweep = nt_env ? atoi(nt_env) != 0 : n_swept * 4 >= (256ll << 20);
-    if (stream_sweep) hipLaunchKernelGGL(k_adam<true>, dim3(nb_dense + nb_lazy + nb_table + nb_ring), dim3(NT), 0, cr_stream(stream), *d, nb_dense, nb_lazy, nb_ring);
-    else hipLaunchKernelGGL(k_adam<false>, dim3(nb_dense + nb_lazy + nb_table + nb_ring), dim3(NT), 0, cr_stream(stream), *d, nb_dense, nb_lazy, nb_ring);
+    cr_tgrad_desc g;
+    memset(&g, 0, sizeof(g));
+    int nb_units = 0, lpr = 0, vec = 0;
+    if (d->tg) {
+        g = *d->tg;
+        const char* why = tg_unsupported(&g);
+        CR_REQUIRE(why == nullptr, "cr_adam_step: tg: %s", why ? why : "");
+        CR_REQUIRE(d->lazy_ids == nullptr, "cr_adam_step: tg and lazy_ids exclude each other");
+        CR_REQUIRE(d->n_table == ((int64_t)g.lay.V + g.lay.T_pos) * g.D, "cr_adam_step: tg: n_table must be (V + T_pos) * D");
+        CR_REQUIRE((g.ring != nullptr) == (d->ids_ring != nullptr) && (!g.ring || (g.ring == d->ids_ring && g.ring_slots == d->ids_ring_slots && g.slot_words == d->ids_slot_elems)),
+                   "cr_adam_step: tg: the index ring must be the id ring of this launch (or both absent)");
+        int ent = 0;
+        tg_shape(g.D, &lpr, &vec, &ent);
+        nb_units = tg_unit_grid(&g);
+    }
+    const dim3 grid(nb_dense + nb_lazy + nb_units + nb_table + nb_ring);
+#define ADAM_LAUNCH(S, L, V) hipLaunchKernelGGL((k_adam<S, L, V>), grid, dim3(NT), 0, cr_stream(stream), *d, g, nb_dense, nb_lazy, nb_units, nb_ring)
+    if (!d->tg) {
+        if (stream_sweep) ADAM_LAUNCH(true, 0, 1);
+        else ADAM_LAUNCH(false, 0, 1);
+    } else if (vec == 4 && lpr == 64) {
+        if (stream_sweep) ADAM_LAUNCH(true, 64, 4);
+        else ADAM_LAUNCH(false, 64, 4);
+    } else if (vec == 4 && lpr == 32) {
+        if (stream_sweep) ADAM_LAUNCH(true, 32, 4);
+        else ADAM_LAUNCH(false, 32, 4);
+    } else if (vec == 4) ADAM_LAUNCH(false, 16, 4);
+    else if (vec == 2 && lpr == 64) ADAM_LAUNCH(false, 64, 2);
+    else if (vec == 2 && lpr == 32) ADAM_LAUNCH(false, 32, 2);
+    else if (vec == 2) ADAM_LAUNCH(false, 16, 2);
+    else if (lpr == 64) ADAM_LAUNCH(false, 64, 1);
+    else if (lpr == 32) ADAM_LAUNCH(false, 32, 1);
+    else ADAM_LAUNCH(false, 16, 1);
+#undef ADAM_LAUNCH
     return cr_check_launch("cr_adam_step");
 }
 

@@ -79,10 +79,14 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
             if (d.pos_logits) d.pos_logits[m] = pl;
             if (d.neg_logits) d.neg_logits[m] = nl;
         }
-        if (act && (d.d_seq_emb || d.table_grad)) {
+        if (act && (d.d_seq_emb || d.table_grad || d.coef_out)) {
             // d/dpl [-log(sig(pl)+e)] = -sig(1-sig)/(sig+e);  d/dnl [-log(1-sig(nl)+e)] = sig(1-sig)/(1-sig+e)
             const float dpl = -ist * sp * (1.0f - sp) / (sp + 1e-24f);
             const float dnl = ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f);
+            if (d.coef_out && l == 0) {                  // the item table's gradient is gathered from the batch's occurrence index
+                d.coef_out[m] = dpl;
+                d.coef_out[(size_t)d.M + m] = dnl;
+            }
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = l + LPR * i;
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
         }
         const float dpl = act ? -ist * sp * (1.0f - sp) / (sp + 1e-24f) : 0.0f;
         const float dnl = act ? ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f) : 0.0f;
+        if (d.coef_out && l == 0 && act) {               // the item table's gradient is gathered from the batch's occurrence index
+            d.coef_out[m] = dpl;
+            d.coef_out[(size_t)d.M + m] = dnl;
+        }
         // ---- LayerNorm backward of this row (modules.py:74-78), dy in registers
         const float mean = head_row_sum<LPR>(xs) * invD;
         float v = 0.0f;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = l + LPR * i;
-                if (c < d.D) n.dx[(size_t)m * n.lddx + c] = rstd * (dy[i] * gam[i] - c1 - x[i] * c2);
+                if (c < d.D) n.dx[(size_t)m * n.lddx + c] = cr_ln_bwd_tail(dy[i] * gam[i], c1, x[i], c2, rstd);
             }
         }
         if (d.table_grad) {

@@ -70,16 +70,7 @@ __device__ __forceinline__ void r_gemm_t(f32x4 (&acc)[4], const __bf16* Wh, cons
     }
 }
 
-// Two image layouts.  ATTN: cr_bf16.hpp's (16-byte chunks XOR-ed with row & 6: one image serves row reads AND transposed reads) --
-// a tile written from layout R hits it with 4-way bank conflicts (16 rows, one chunk: four chunk positions), which the attention
-// images accept.  Weight-gradient images are only ever read transposed, so they use layout W: 8-byte slots (four elements), slot
-// index XOR-ed with a bijection of the row's low four bits -- rows 2, 4, 6 of an aligned 8-row group move to other 32-byte quads
-// (the transposed read's 32-lane half: 8 rows x 32 bytes, conflict-free), rows that differ in bits 0 / 3 permute inside the quad
-// (the write's 16 lanes: 16 rows, one slot each, all 32 banks once).  Counters before: a third of the LDS-active cycles of the
-// block backward were bank conflicts, all of them these writes (1 144 per sequence pair x 12 extra cycles).
-__device__ __forceinline__ int wimg_swz(int row) { return (((row >> 1) & 3) << 2) | ((row & 1) << 1) | ((row >> 3) & 1); }
-__device__ __forceinline__ int wimg_off(int row, int slot) { return row * 64 + ((slot ^ wimg_swz(row)) << 2); }      // bf16 elements
-
+// (the two image layouts, ATTN and W: cr_rlayout.hpp)
 // the wave's tile (layout R) -> rows [row0, row0 + 16) of an image in natural column order (read transposed)
 template <bool SPLIT, bool ATTN = false>
 __device__ __forceinline__ void img_put(__bf16* Ih, __bf16* Il, int row0, const f32x4 (&x)[4]) {
@@ -103,11 +94,6 @@ __device__ __forceinline__ void img_put(__bf16* Ih, __bf16* Il, int row0, const 
     }
 }
 
-// four rows (k = 4 lg + 0..3 of the tile at row0) of image column 16 jt + li of a layout-W image: the K = 16 MFMA's A or B operand
-__device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane) {
-    const int lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + wimg_off(row0 + 4 * lg + q, 4 * jt + p)));
-}
 // acc[j] += a^T g over the rows of `ntr` tiles: output tile (in-column tile it, out-column tiles jt0, jt0 + 1).
 // Two tiles per k-step: v_mfma_f32_16x16x16_bf16 holds the matrix pipe for the same 16 cycles as the 16x16x32 shape
 // (tools/probes/probe_issue_cost.hip: 6.9 ns per instruction either way, and the pipe is shared by the SIMD's waves), so a product

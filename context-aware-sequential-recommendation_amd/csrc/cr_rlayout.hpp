@@ -173,6 +173,28 @@ __device__ __forceinline__ bf8 tr_frag_l(const __bf16* img, int ra, int rb, int 
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Two image layouts.  ATTN: cr_bf16.hpp's (16-byte chunks XOR-ed with row & 6: one image serves row reads AND transposed reads) --
+// a tile written from layout R hits it with 4-way bank conflicts (16 rows, one chunk: four chunk positions), which the attention
+// images accept.  Weight-gradient images are only ever read transposed, so they use layout W: 8-byte slots (four elements), slot
+// index XOR-ed with a bijection of the row's low four bits -- rows 2, 4, 6 of an aligned 8-row group move to other 32-byte quads
+// (the transposed read's 32-lane half: 8 rows x 32 bytes, conflict-free), rows that differ in bits 0 / 3 permute inside the quad
+// (the write's 16 lanes: 16 rows, one slot each, all 32 banks once).  Counters before: a third of the LDS-active cycles of the
+// block backward were bank conflicts, all of them these writes (1 144 per sequence pair x 12 extra cycles).
+__device__ __forceinline__ int wimg_swz(int row) { return (((row >> 1) & 3) << 2) | ((row & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int wimg_off(int row, int slot) { return row * 64 + ((slot ^ wimg_swz(row)) << 2); }      // bf16 elements
+
+// four rows (k = 4 lg + 0..3 of the tile at row0) of image column 16 jt + li of a layout-W image: the K = 16 MFMA's A or B operand
+__device__ __forceinline__ bf4 tr4(const __bf16* img, int row0, int jt, int lane) {
+    const int lg = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4*)(img + wimg_off(row0 + 4 * lg + q, 4 * jt + p)));
+}
+// B operand with k = row out of a layout-W image (cr_bf16.hpp's tr_frag for that layout): k index 8 lg + j <-> row (j < 4 ? ra : rb) +
+// 4 lg + (j & 3), output column 16 jt + li
+__device__ __forceinline__ bf8 tr_frag_w(const __bf16* img, int ra, int rb, int jt, int lane) {
+    const bf4 t0 = tr4(img, ra, jt, lane), t1 = tr4(img, rb, jt, lane);
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // ---- out^T = W^T x^T on the lane's row -------------------------------------------------------------------
 template <bool SPLIT>
 __device__ __forceinline__ void r_split(const f32x4 (&x)[4], bf8 (&h)[2], bf8 (&l)[2]) {

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                     h[r] = hh[0]; h[r + 1] = hh[1];
                     l[r] = ll[0]; l[r + 1] = ll[1];
                 }
-                const int o = img_off<2>(q0 + li, 2 * ct + (lg >> 1)) + 4 * (lg & 1);
+                // layout W (cr_rlayout.hpp): this image is only ever read transposed, and a tile written from layout R into the dual-use
+                // layout hits four chunk positions with sixteen rows -- 4-way bank conflicts on every write, a fifth of the launch's
+                // LDS-active cycles (round 4's counters; the block backward's weight-gradient images had the same and lost it the same way)
+                const int o = wimg_off(q0 + li, 4 * ct + lg);
                 *reinterpret_cast<bf4*>(Vh + o) = h;
                 if (SPLIT) *reinterpret_cast<bf4*>(Vl + o) = l;
             }
@@ -419,8 +422,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                             bf8 vh[JB], vl[JB];
 #pragma unroll
                             for (int jt = 0; jt < JB; ++jt) {
-                                vh[jt] = tr_frag_l(Vh, ra, rb, j0 + jt, ln);
-                                vl[jt] = SPLIT ? tr_frag_l(Vl, ra, rb, j0 + jt, ln) : vh[jt];
+                                vh[jt] = tr_frag_w(Vh, ra, rb, j0 + jt, ln);
+                                vl[jt] = SPLIT ? tr_frag_w(Vl, ra, rb, j0 + jt, ln) : vh[jt];
                             }
 #pragma unroll
                             for (int jt = 0; jt < JB; ++jt) o[j0 + jt] = mma<SPLIT>(vh[jt], vl[jt], ph, pl, o[j0 + jt]);

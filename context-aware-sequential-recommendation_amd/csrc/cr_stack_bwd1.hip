@@ -1494,7 +1494,8 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
         CR_REQUIRE(e->ids && e->M == d->M && e->D == d->D && e->ld_out == d->D && e->col_off == 0 && e->T > 0 && e->V > 0,
                    "cr_stack_block_bwd: the embedding recipe must describe the block's dense input x");
         CR_REQUIRE(!bd->dx_accumulate, "cr_stack_block_bwd: dx_accumulate with a scatter (this kernel must be the only producer of dx)");
-        CR_REQUIRE(sc->table_grad || sc->d_addend || sc->pos_grad, "cr_stack_block_bwd: nothing to scatter into");
+        // (table_grad, pos_grad and d_addend all NULL is the occurrence-index form: the masked, dropped-out partial rows are LEFT in
+        //  dx / dx2 -- d_addend / d_addend2 with an addend -- for cr_table_grad / cr_adam_desc.tg to gather; no atomics here)
         if (sc->n_slabs > 0) {
             // small-table mode (cr_embed_bwd's contract: every slab in use written, their sum is the gradient): two slabs per pair
             const int nw = B < bd->n_slabs ? B : bd->n_slabs;

@@ -271,8 +271,34 @@ class Engine:
         i32 = dict(dtype=torch.int32, device=self.dev)
         # the six id inputs of one batch live in ONE [6, M] buffer so a staged batch is a single D2D copy
         self.ID_KEYS = ("seq", "pos", "neg", "time", "hours", "days")
-        self.ids_all = torch.zeros(6, self.M, **i32)
+        # The occurrence index of the batch (castrec.h, "occurrence index"; round 5): item -> the rows that hold it as seq / pos /
+        # neg id, built on the host beside the batch and travelling with the ids -- a SLOT is [6 M ids | pad | index] -- so that the
+        # item (and learned positional) table's gradient is an ordered gather inside cr_adam_step instead of float atomics from the
+        # head and the embedding backward.  Off (CASTREC_NO_INDEX=1, row-sparse Adam, hidden sizes the gather does not take): the
+        # atomics of rounds 1-4.
+        ng, ent = C.c_int(0), C.c_int(0)                        # the gather's geometry at this hidden size (0: a size it does not take)
+        self.use_index = bool(training and not self.lazy_adam and os.environ.get("CASTREC_NO_INDEX") != "1"
+                              and L.lib.cr_tgrad_geometry(self.D, C.byref(ng), C.byref(ent)))
+        self.ids_words = 6 * self.M
+        self.index_off = (self.ids_words + 3) // 4 * 4
+        self.index_lay, self._ixb = None, None
+        if self.use_index:
+            self.index_lay = L.IndexLayout()
+            t_pos = self.T if "pos_emb" in self.layout.entries else 0
+            L.check(L.lib.cr_batch_index_layout(self.M, itemnum + 1, t_pos, ng.value, ent.value, C.byref(self.index_lay)), "cr_batch_index_layout")
+            self._ixb = L.lib.cr_index_builder_create(self.M, itemnum + 1, t_pos, ng.value, ent.value)
+            if not self._ixb:
+                raise MemoryError("cr_index_builder_create(%d, %d, %d)" % (self.M, itemnum + 1, t_pos))
+            # workspace of the rows a batch cuts into slices (a hot item with more occurrences than one workgroup sums)
+            self._tg_part = torch.zeros(self.index_lay.cap_blocks, (self.D + 3) // 4 * 4, dtype=torch.float32, device=self.dev)
+            self._tg_tickets = torch.zeros(self.index_lay.cap_blocks, dtype=torch.int32, device=self.dev)
+        self.slot_words = self.index_off + (int(self.index_lay.total_words) if self.use_index else 0) if self.use_index else self.ids_words
+        self.batch_buf = torch.zeros(self.slot_words, **i32)
+        self.ids_all = self.batch_buf[:self.ids_words].view(6, self.M)
         self.ids = {k: self.ids_all[i] for i, k in enumerate(self.ID_KEYS)}
+        self._host_slot = np.zeros(self.slot_words, np.int32)          # host mirror of the static batch buffer (set_batch builds the index in it)
+        self._tg_rows = None                                            # (rows, rows2 or None, ld, scale): the seq lookup's gradient rows
+        self.bitwise_reproducible = self.use_index                      # no float atomics left in a step's gradients (loss sums apart)
         self.static_pe = torch.from_numpy(positional_encoding(self.D, self.T)).to(self.dev)
         self._build()
         self._finalize()
@@ -355,7 +381,13 @@ class Engine:
         if not self.training:
             return
 
-        def make_bwd_desc():
+        # the item table's seq lookup under the occurrence index: no table / positional gradient is scattered -- the masked,
+        # dropped-out gradient rows are left in a row buffer for the gather (cr_adam_desc.tg / cr_table_grad)
+        indexed = self.use_index and table == "item_emb" and ids_key == "seq"
+        if indexed:
+            assert not small and self._tg_rows is None, "one seq lookup of the item table per graph"
+
+        def make_bwd_desc(in_block=False):
             f = L.EmbedDesc.from_buffer_copy(d)
             f.out = self._grad_of(out).data_ptr()
             dadd = None
@@ -363,6 +395,19 @@ class Engine:
                 assert self._acc(id(addend[1])) == 0, "addend gradient must be first-written here"
                 dadd = addend[1].data_ptr()
             g2 = self._second_grad(out) if (ld_out == D and col_off == 0) else None   # a gradient in two partials: the kernels add them
+            if indexed:
+                if not in_block:
+                    # cr_embed_bwd writes the rows as `d_addend` (the addend's gradient where the graph has one -- it IS the row --
+                    # else a buffer of their own)
+                    if addend:
+                        rows = addend[1]
+                        assert rows.shape[1] % (4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)) == 0
+                    else:
+                        rows = self.buf("item_rows", D)
+                        f.ld_add = D
+                        dadd = rows.data_ptr()
+                    self._tg_rows = (rows, None, rows.shape[1], float(scale))
+                return L.EmbedBwdDesc(f, None, None, dadd, 0, 0, g2.data_ptr() if g2 is not None else None)
             return L.EmbedBwdDesc(f, self._gptr(table), self._gptr("pos_emb") if pos == "learned" else None, dadd,
                                   self.Gs.shape[1] if small else 0, self.n_slabs if small else 0, g2.data_ptr() if g2 is not None else None)
 
@@ -373,7 +418,7 @@ class Engine:
         #  per sequence pair to write to)
         if (out.data_ptr() in self._pending_embed and (addend is None or addend[0].shape[1] == D)
                 and (not small or (V <= 256 and D <= 64 and pos is None and self.n_slabs >= 2 * min(self.B, self.n_slabs)))):
-            self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None, small, table)
+            self._scatter_recipe[out.data_ptr()] = (make_bwd_desc, addend[0] if addend else None, small, table, indexed, float(scale))
 
         def factory():
             if out.data_ptr() in self._scatter_claimed:
@@ -406,6 +451,10 @@ class Engine:
                               O.NO_DROP, None, 0)
                 self._call(lst, "cr_eltwise", C.byref(e))
                 del self._grad2[ptr]
+                if self._tg_rows is not None and self._tg_rows[0] is g and self._tg_rows[1] is g2:
+                    # the occurrence index's row pair was this pair: g now holds the SUM (the add above is in place), so the gather
+                    # reads one partial
+                    self._tg_rows = (g, None) + self._tg_rows[2:]
         return lst
 
     def op_layernorm(self, x, y, y_ld, y_col, pname, flags=None, skip_fwd=False):
@@ -771,7 +820,7 @@ class Engine:
                 rec = self._scatter_recipe.get(x.data_ptr())
                 if rec is not None and not bbd.dx_accumulate:
                     self._scatter_claimed.add(x.data_ptr())
-                    sc = rec[0]()
+                    sc = rec[0](True) if rec[4] else rec[0]()
                     if rec[2]:                                             # small table: two slabs per sequence pair
                         self._block_slab_range(rec[3], rec[3], 2 * min(self.B, self.n_slabs))
                     if sc.d_addend:
@@ -779,6 +828,13 @@ class Engine:
                         ext.d_addend2 = dadd2.data_ptr()
                         self._grad2[rec[1].data_ptr()] = dadd2            # the addend's gradient is d_addend + d_addend2
                         self._grad2_bufs[rec[1].data_ptr()] = (rec[1], dadd2)
+                    if rec[4]:
+                        # occurrence index: the kernel leaves the two masked partials of the input gradient where they wait (the
+                        # addend's gradient pair, else dx / dx2) and scatters nothing; cr_adam_step gathers scale * (rows + rows2)
+                        if sc.d_addend:
+                            self._tg_rows = (self._grad_of(rec[1]), dadd2, D, rec[5])
+                        else:
+                            self._tg_rows = (dx, dx2, D, rec[5])
                     self._keep.append(sc)
                 else:
                     self._grad2[x.data_ptr()] = dx2                       # the block input's gradient is dx + dx2
@@ -820,6 +876,8 @@ class Engine:
                 self._call(lst, "cr_block_ln_ffn_bwd", C.byref(bbd))
             self._call(lst, "cr_attn_bwd", C.byref(abd))
             recipe = self._scatter_recipe.get(x.data_ptr())
+            if recipe is not None and recipe[4]:
+                recipe = None                                              # (indexed: these kernels only know the atomic scatter; cr_embed_bwd leaves the rows)
             if recipe is not None and not recipe[2] and not bbd.dx_accumulate:
                 self._scatter_claimed.add(x.data_ptr())
                 if rows_bf:
@@ -920,7 +978,7 @@ class Engine:
             self._ln_claimed.add(seq_emb.data_ptr())
             d = L.HeadDesc(seq_emb.data_ptr(), seq_emb.shape[1], self._pptr("item_emb"), self.ids["pos"].data_ptr(),
                            self.ids["neg"].data_ptr(), M, D, self.itemnum + 1, self.state.data_ptr(), None, 0,
-                           self._gptr("item_emb"), None, None)
+                           None if self.use_index else self._gptr("item_emb"), None, None, self._head_coef())
             n = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), None, 0, dx.data_ptr(), D, 0,
                             self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
             self._call(self.fwd, "cr_head_fwd_bwd_ln", C.byref(d), C.byref(n))
@@ -929,8 +987,14 @@ class Engine:
         self._grad_written.add(id(ds))
         d = L.HeadDesc(seq_emb.data_ptr(), seq_emb.shape[1], self._pptr("item_emb"), self.ids["pos"].data_ptr(),
                        self.ids["neg"].data_ptr(), M, D, self.itemnum + 1, self.state.data_ptr(), ds.data_ptr(), ds.shape[1],
-                       self._gptr("item_emb"), None, None)
+                       None if self.use_index else self._gptr("item_emb"), None, None, self._head_coef())
         self._call(self.fwd, "cr_head_fwd_bwd", C.byref(d))
+
+    def _head_coef(self):
+        """[2, M] d loss_sum / d logit of the pos / neg item per row: what the occurrence index's gather multiplies seq_emb rows with."""
+        if not self.use_index:
+            return None
+        return self.vec("head.coef", 2 * self.M).data_ptr()
 
     # ---- the eleven graphs -----------------------------------------------------------------------
     def _build(self):
@@ -1073,6 +1137,18 @@ class Engine:
             ad = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(), self.Gs.data_ptr(),
                             lay.n_table, lay.n_dense, self.n_slabs, float(self.hp.lr), 0.9, 0.98, 1e-8, self.state.data_ptr(),
                             snap, tsnap, l2, n_l2, *lazy, counts)
+            self._tgd, self._tgrad = None, None
+            if self.use_index:
+                # the table section's gradient by gather (castrec.h cr_tgrad_desc): inside the plain step's Adam launch; as a launch of
+                # its own (cr_table_grad -> Gt) in front of the data-parallel exchange, and for grads()
+                assert self._tg_rows is not None, "occurrence index: no gradient-row buffer for the item table's seq lookup"
+                rows, rows2, ld_rows, scale = self._tg_rows
+                se = self.seq_emb
+                self._tgd = L.TgradDesc(self.batch_buf.data_ptr() + 4 * self.index_off, None, 0, 0, 0, self.state.data_ptr() + 4 * 4,
+                                        self.index_lay, rows.data_ptr(), rows2.data_ptr() if rows2 is not None else None, ld_rows, scale,
+                                        se.data_ptr(), se.shape[1], self._head_coef(), self.D, self._tg_part.data_ptr(), self._tg_tickets.data_ptr())
+                ad.tg = C.pointer(self._tgd)
+                self._tgrad = ("cr_table_grad", L.lib.cr_table_grad, (C.byref(self._tgd), self.Gt.data_ptr()))
             self._adam = ("cr_adam_step", L.lib.cr_adam_step, (C.byref(ad),))
             ad1 = L.AdamDesc(self.P.data_ptr(), self.Mom.data_ptr(), self.Vel.data_ptr(), self.Gt.data_ptr(),
                              self.Gflat.data_ptr() + 4 * lay.n_table, lay.n_table, lay.n_dense, 1, float(self.hp.lr), 0.9, 0.98,
@@ -1104,7 +1180,39 @@ class Engine:
                     raise ValueError("%s ids outside [0, %d] (min %d, max %d): the lookup table has %d rows"
                                      % (k, limits[k], int(a.min()), int(a.max()), limits[k] + 1))
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32))
-            self.ids[k].copy_(t.reshape(-1).to(torch.int32), non_blocking=True)
+            if self.use_index:
+                # the host mirror of the static batch buffer: the index is built from it below, and ids + index go over in ONE copy
+                i = self.ID_KEYS.index(k)
+                self._host_slot[i * self.M:(i + 1) * self.M] = t.reshape(-1).to(torch.int32).cpu().numpy()
+            else:
+                self.ids[k].copy_(t.reshape(-1).to(torch.int32), non_blocking=True)
+        if self.use_index:
+            used = self._build_index(self._host_slot)
+            self.batch_buf[:used].copy_(torch.from_numpy(self._host_slot[:used]))
+
+    def _build_index(self, host_slot):
+        """host_slot: int32 [slot_words] holding the six id rows; the occurrence index of its seq / pos / neg ids is written behind them."""
+        M = self.M
+        base = host_slot.ctypes.data
+        L.check(L.lib.cr_index_build(self._ixb, base, base + 4 * M, base + 8 * M, base + 4 * self.index_off), "cr_index_build")
+        return self.index_off + int(host_slot[self.index_off + 4])     # words of the slot in use: a copy may stop there
+
+    def pack_slot(self, seq, pos, neg, time=None, hours=None, days=None, out=None):
+        """One batch as a SLOT of the id ring / the staging area: int32 [slot_words] = the six id rows (+ the batch's occurrence index
+        behind them where the engine uses one).  `out`: a host array to fill (e.g. a pinned ring slot's numpy view)."""
+        host = np.zeros(self.slot_words, np.int32) if out is None else out
+        for i, a in enumerate((seq, pos, neg, time, hours, days)):
+            if a is None:
+                host[i * self.M:(i + 1) * self.M] = 0
+            else:
+                host[i * self.M:(i + 1) * self.M] = np.asarray(a).reshape(-1)
+        if self.use_index:
+            self._build_index(host)
+        return host
+
+    def load_slot(self, slot):
+        """A packed slot (device tensor [slot_words], pack_slot's layout) into the static batch buffer: ids AND index."""
+        self.batch_buf.copy_(slot.reshape(-1))
 
     def set_step(self, k=1):
         """The next launch runs as step number k (dropout keys, Adam bias correction); loss sums cleared."""
@@ -1117,6 +1225,8 @@ class Engine:
             self._feed_next, self._feed_started, self._feed_first = int(k), False, int(k)
             torch.cuda.synchronize()
             self._feed_done.clear()
+        if getattr(self, "_tg_tickets", None) is not None:
+            self._tg_tickets.zero_()                     # (every launch leaves them zero; a failed one might not)
         if getattr(self, "lazy_flags", None) is not None:
             # row-sparse Adam claims a row with atomicExch(flag, step) != step: a flag left by an earlier run of the same
             # step number (counter moved back, checkpoint loaded) would read as "already claimed" and skip the row
@@ -1157,9 +1267,13 @@ class Engine:
         if ring is None:
             self._id_ring = None
             for ad in ads:
-                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = None, 0, 0, None
+                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst, ad.ids_copy_elems = None, 0, 0, None, 0
+            if self._tgd is not None:
+                self._tgd.ring, self._tgd.ring_slots, self._tgd.slot_words, self._tgd.index_off = None, 0, 0, 0
             return
-        assert ring.dtype == torch.int32 and ring.is_cuda and ring.is_contiguous() and tuple(ring.shape[1:]) == (6, self.M), ring.shape
+        assert ring.dtype == torch.int32 and ring.is_cuda and ring.is_contiguous(), ring.shape
+        assert int(np.prod(ring.shape[1:])) == self.slot_words, \
+            "ring slots of %s words, the engine's slots have %d (pack_slot: 6 x %d ids%s)" % (tuple(ring.shape[1:]), self.slot_words, self.M, " + the occurrence index" if self.use_index else "")
         self._id_ring = ring
         if self.lazy_adam:
             self._ring_next = ("cr_ids_ring_next", L.lib.cr_ids_ring_next,
@@ -1167,8 +1281,12 @@ class Engine:
         else:
             # extra workgroups of the Adam launch move the batch (castrec.h cr_adam_desc.ids_ring): no launch of its own.  (A forked
             # graph branch beside Adam was measured first: the fork and join cost 17 us per step, four times the copy they hid.)
+            # Only the ids move: the occurrence index of a step is read where it lies, in the ring slot of that step.
             for ad in ads:
-                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), 6 * self.M, self.ids_all.data_ptr()
+                ad.ids_ring, ad.ids_ring_slots, ad.ids_slot_elems, ad.ids_dst = ring.data_ptr(), int(ring.shape[0]), self.slot_words, self.ids_all.data_ptr()
+                ad.ids_copy_elems = self.ids_words
+            if self._tgd is not None:
+                self._tgd.ring, self._tgd.ring_slots, self._tgd.slot_words, self._tgd.index_off = ring.data_ptr(), int(ring.shape[0]), self.slot_words, self.index_off
 
     # ---- host batches fed AHEAD of the steps that use them --------------------------------------
     def enable_feed(self, n_slots=8, steps_per_graph=1):
@@ -1181,8 +1299,8 @@ class Engine:
         # an event behind every `_feed_every`-th step tells feed() that a slot's last reader has finished (behind EVERY step it
         # cost 5 us per step, tools/probes/ev_cost.py); a slot is rewritten n_slots steps after its batch ran
         self._feed_every = 4 if n_slots >= 8 else 1
-        self._feed_ring = torch.zeros(n_slots, 6, self.M, dtype=torch.int32, device=self.dev)
-        self._feed_host = torch.zeros(n_slots, 6, self.M, dtype=torch.int32).pin_memory()
+        self._feed_ring = torch.zeros(n_slots, self.slot_words, dtype=torch.int32, device=self.dev)
+        self._feed_host = torch.zeros(n_slots, self.slot_words, dtype=torch.int32).pin_memory()
         self._feed_np = self._feed_host.numpy()
         self._feed_stream = torch.cuda.Stream()
         self._feed_h2d = [None] * n_slots            # per slot: its host -> device copy has finished
@@ -1213,16 +1331,20 @@ class Engine:
         if self._feed_h2d[slot] is not None:
             self._feed_h2d[slot].synchronize()       # the pinned buffer's previous copy (n batches ago) has left it
         host = self._feed_np[slot]
+        hid = host[:self.ids_words].reshape(6, self.M)
         for i, a in enumerate((seq, pos, neg, time, hours, days)):
             if a is None:
-                host[i] = 0
+                hid[i] = 0
             else:
-                host[i] = np.asarray(a).reshape(-1)
+                hid[i] = np.asarray(a).reshape(-1)
         if self._check_ids:
-            lo, hi = host.min(axis=1), host.max(axis=1)
+            lo, hi = hid.min(axis=1), hid.max(axis=1)
             for i, key, lim in self._feed_limits:
                 if lo[i] < 0 or hi[i] > lim:
                     raise ValueError("%s ids outside [0, %d] (min %d, max %d): the lookup table has %d rows" % (key, lim, lo[i], hi[i], lim + 1))
+        used = self.slot_words
+        if self.use_index:
+            used = self._build_index(host)               # (after the range check: the builder indexes its work arrays with these ids)
         # the slot held batch k - n: read by the tail of step k - n - 1 or, where that step ran with nothing fed ahead, by step
         # k - n's own copy into the static buffers -- the new copy waits for the launch of step k - n
         # (a HOST wait, like the two in train_fed: step k - n ended long ago, while a device-side wait between two streams
@@ -1236,7 +1358,7 @@ class Engine:
                 # records; never skip the wait silently): the compute stream itself
                 torch.cuda.current_stream().synchronize()
         with torch.cuda.stream(self._feed_stream):
-            self._feed_ring[slot].copy_(self._feed_host[slot], non_blocking=True)
+            self._feed_ring[slot][:used].copy_(self._feed_host[slot][:used], non_blocking=True)      # (the index's capacity beyond its use stays behind)
             ev = torch.cuda.Event()
             ev.record()
         self._feed_h2d[slot] = ev
@@ -1257,7 +1379,7 @@ class Engine:
         if not self._feed_started:
             # nobody moved this batch into the static buffers (first step, or the step before ran with no batch fed ahead)
             self._feed_h2d[k % n].synchronize()
-            self.ids_all.copy_(self._feed_ring[k % n])
+            self.ids_all.copy_(self._feed_ring[k % n][:self.ids_words].view(6, self.M))
         # the tail of step k + j - 1 moves batch k + j: those that are fed (a step or more ago: long there) must have arrived
         for j in range(1, min(G, self._feed_have - 1) + 1):
             self._feed_h2d[(k + j) % n].synchronize()
@@ -1291,7 +1413,7 @@ class Engine:
         s = torch.cuda.current_stream().cuda_stream
         self._run(self.fwd, s)
         self._run(self.bwd, s)
-        self._run([self._reduce], s)
+        self._run(([self._tgrad] if self._tgrad else []) + [self._reduce], s)
 
     def launch_adam_from_flat(self):
         """Adam on the (all-reduced) flat bucket; the global loss statistics are read from its tail."""
@@ -1305,7 +1427,9 @@ class Engine:
         side = torch.cuda.Stream()
         side.wait_stream(s0)
         k = self.bwd_table_done
-        progs = [self.fwd + self.bwd[:k], self.bwd[k:] + [self._reduce], ([self._l2] if self._l2 else []) + [self._adam_flat]]
+        # (occurrence index: the table gradient is WRITTEN into the bucket by cr_table_grad behind the last launch that leaves rows for it)
+        progs = [self.fwd + self.bwd[:k] + ([self._tgrad] if self._tgrad else []), self.bwd[k:] + [self._reduce],
+                 ([self._l2] if self._l2 else []) + [self._adam_flat]]
         graphs = []
         with torch.cuda.stream(side):
             for prog in progs:
@@ -1381,6 +1505,11 @@ class Engine:
     def grads(self):
         """Normalised gradients by logical name, valid after launch_step(apply=False)."""
         n = float(self.state[2])
+        if self._tgrad is not None:
+            # the plain step never materialises the table gradient (cr_adam_step gathers it row by row): form it now, by the same gather
+            self.Gt.zero_()
+            self._run([self._tgrad], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
         flat = torch.cat([self.Gt, self.Gs.sum(0)[:self.layout.n_dense]]) / max(n, 1.0)
         return {k: self.layout.view(flat, k).clone() for k in self.layout.logical_names()}
 

@@ -117,7 +117,18 @@ class StackDesc(C.Structure):
 class HeadDesc(C.Structure):
     _fields_ = [("seq_emb", c_p), ("ld", c_i), ("table", c_p), ("pos", c_p), ("neg", c_p),
                 ("M", c_i), ("D", c_i), ("V", c_i), ("state", c_p), ("d_seq_emb", c_p), ("ldd", c_i),
-                ("table_grad", c_p), ("pos_logits", c_p), ("neg_logits", c_p)]
+                ("table_grad", c_p), ("pos_logits", c_p), ("neg_logits", c_p), ("coef_out", c_p)]
+
+
+class IndexLayout(C.Structure):
+    _fields_ = [("M", c_i), ("V", c_i), ("T_pos", c_i), ("ng", c_i), ("ent", c_i), ("cap_blocks", c_i), ("cap_occ", c_i), ("bitmap_words", c_i),
+                ("off_recs", C.c_int64), ("total_words", C.c_int64)]
+
+
+class TgradDesc(C.Structure):
+    _fields_ = [("index", c_p), ("ring", c_p), ("ring_slots", c_i), ("slot_words", C.c_int64), ("index_off", C.c_int64), ("step", c_p),
+                ("lay", IndexLayout), ("rows", c_p), ("rows2", c_p), ("ld_rows", c_i), ("scale", c_f), ("seq_emb", c_p), ("ld_emb", c_i),
+                ("coef", c_p), ("D", c_i), ("part_rows", c_p), ("tickets", c_p)]
 
 
 class AdamDesc(C.Structure):
@@ -125,7 +136,8 @@ class AdamDesc(C.Structure):
                 ("n_table", C.c_int64), ("n_dense", c_i), ("n_slabs", c_i), ("lr", c_f), ("beta1", c_f),
                 ("beta2", c_f), ("eps", c_f), ("state", c_p), ("stats", c_p), ("step_snapshot", c_p), ("l2", c_f), ("n_l2", C.c_int64),
                 ("lazy_ids", c_p), ("n_lazy_ids", c_i), ("lazy_rows", c_i), ("lazy_D", c_i), ("lazy_flags", c_p), ("slab_counts", c_p),
-                ("ids_ring", c_p), ("ids_ring_slots", c_i), ("ids_slot_elems", C.c_int64), ("ids_dst", c_p)]
+                ("ids_ring", c_p), ("ids_ring_slots", c_i), ("ids_slot_elems", C.c_int64), ("ids_dst", c_p),
+                ("ids_copy_elems", C.c_int64), ("tg", C.POINTER(TgradDesc))]
 
 
 def _sig(name, restype, argtypes):
@@ -188,13 +200,20 @@ _sig("cr_graph_destroy", c_i, [c_p])
 _sig("cr_sampler_create", c_p, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_double, C.c_double, c_u32, c_i])
 _sig("cr_sampler_next", c_i, [c_p] + [c_p] * 8)
 _sig("cr_sampler_destroy", None, [c_p])
+_sig("cr_tgrad_geometry", c_i, [c_i, C.POINTER(c_i), C.POINTER(c_i)])
+_sig("cr_batch_index_layout", c_i, [c_i, c_i, c_i, c_i, c_i, C.POINTER(IndexLayout)])
+_sig("cr_index_builder_create", c_p, [c_i, c_i, c_i, c_i, c_i])
+_sig("cr_index_build", c_i, [c_p, c_p, c_p, c_p, c_p])
+_sig("cr_index_builder_destroy", None, [c_p])
+_sig("cr_table_grad", c_i, [C.POINTER(TgradDesc), c_p, c_p])
 
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_ids_ring_next", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
            "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_rows_pack", "cr_rows_add", "cr_block_ln_qkv_bwd_scatter",
            "cr_wide_supported", "cr_wide_ln_qkv_fwd", "cr_wide_ln_ffn_fwd", "cr_wide_ln_ffn_fwd_tail", "cr_wide_ln_ffn_bwd", "cr_wide_ln_qkv_bwd",
            "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
-           "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy"]
+           "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy",
+           "cr_tgrad_geometry", "cr_batch_index_layout", "cr_index_builder_create", "cr_index_build", "cr_index_builder_destroy", "cr_table_grad"]
 
 lib = _lib
 

@@ -421,6 +421,75 @@ int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* str
 int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                    int B, int T, int D, int V, int n_cand, float* logits, void* stream);
 
+/* ---- occurrence index of a batch (round 5; csrc/cr_index.cpp, csrc/cr_tgrad.hip) ---------------------------------
+ * The gradient of a looked-up table row is the sum of the gradient rows of every position that looked it up: the three
+ * lookups of the item table (seq ids: modules.py:157 through sasrec.py:27; pos / neg ids: sasrec.py:89-90) and the learned
+ * positional table's (sasrec.py:40-50).  TensorFlow forms those sums in its gather's gradient; rounds 1-4 formed them with float
+ * atomics from the head kernel and the first block's backward (2.56 M + 1.28 M of them per step at the headline shape: ~13 us,
+ * and the only sums of a step whose order -- hence whose last bits -- changed from run to run).  The index turns the scatter into
+ * a gather: per table row the list of (kind, batch row) pairs, built on the host beside the batch (a stable counting sort, O(rows
+ * of the batch)), travelling with the ids, summed on the device in the list's order -- bitwise reproducible, no atomics.
+ *
+ * Flat row numbering: item rows 0 .. V-1 (row 0, the zero pad, is never listed), then -- T_pos > 0 -- the positional rows V .. V +
+ * T_pos - 1 (the positional table follows the item table in the table section, same width).
+ * An occurrence is one word: kind << 30 | m.  kind 0: seq id at batch row m (gradient row = scale * rows[m]); 1 / 2: pos / neg id at
+ * row m (coef[m] / coef[M + m] times seq_emb[m]); 3: positional row (1.0 * rows[m]).  Within a table row: kind 0 (or 3) by ascending
+ * m, then kind 1, then kind 2.
+ * The PLAN of the gather is part of the index, made for the device's geometry: a workgroup has `ng` lane groups, a lane group sums at
+ * most `ent` occurrences (one batch of loads -- the sums of a Zipf corpus are bound by dependent round trips and one CU's load
+ * issue, not by bytes: a hot item holds thousands of a batch's rows).  Workgroup w, lane group g has the record (four words)
+ *   {flat row, first occurrence, count (0 = idle), q | k << 6 | j << 13 | n << 22}
+ * a row with c occurrences takes k = ceil(c / ent) CONSECUTIVE groups of one workgroup, q = 0 .. k-1 (their partials are added in q
+ * order); a row that needs more than ng groups is cut into n slices of whole workgroups w0 .. w0 + n - 1 (j = 0 .. n-1: their partial
+ * rows are added in j order by the slice that finishes last -- cr_tgrad_desc.part_rows / tickets); else n = 1, j = 0.
+ * Words of the index buffer (all offsets in int32 words, 16-byte aligned):
+ *   [0] workgroups in use  [1] listed rows  [2] occurrences  [3] CR_INDEX_MAGIC  [4] words in use (a copy may stop there)
+ *   [5] offset of the occurrences  [6] offset of the bitmap  [7] 0 | records, ng x 4 words per workgroup | occurrences | bitmap
+ * (bit r & 31 of word r >> 5 set <=> flat row r is listed).  total_words is the capacity for ANY batch of the layout's shape. */
+#define CR_INDEX_MAGIC 0x43524959
+typedef struct {
+    int M, V, T_pos;
+    int ng, ent;                      /* lane groups per workgroup, occurrences per lane group (cr_tgrad_geometry) */
+    int cap_blocks, cap_occ, bitmap_words;
+    int64_t off_recs, total_words;
+} cr_index_layout;
+/* (lane groups per 1024-thread workgroup, occurrences per group) the device code uses at hidden size D; 0 where D is not taken
+ * (the gather takes D a multiple of 4 up to 256, even up to 128, any up to 64) */
+int cr_tgrad_geometry(int D, int* ng, int* ent);
+int cr_batch_index_layout(int M, int V, int T_pos, int ng, int ent, cr_index_layout* out);
+/* Host side, no HIP.  A builder keeps two int32 work arrays of V + T_pos entries between calls (so a build costs O(M), not O(V));
+ * not re-entrant on one handle.  seq / pos / neg: [M] ids in [0, V) (the caller range-checks them: Engine.set_batch / feed);
+ * `out`: layout.total_words words; words [0, out[4]) are written. */
+typedef struct cr_index_builder cr_index_builder;
+cr_index_builder* cr_index_builder_create(int M, int V, int T_pos, int ng, int ent);
+int cr_index_build(cr_index_builder* b, const int32_t* seq, const int32_t* pos, const int32_t* neg, int32_t* out);
+void cr_index_builder_destroy(cr_index_builder* b);
+
+/* The table gradient of a step from the index: grad[row] = sum over the row's occurrences, in list order, for every row that has a
+ * unit.  rows / rows2: the gradient rows of the stack input ([M, ld_rows]; rows2 = optional second partial, added: cr_stack_block_bwd
+ * leaves them as two partials), already masked and through the embedding dropout; seq_emb: the head's input rows; coef: [2, M] the head's
+ * d loss / d logit (cr_head_desc.coef_out).  `index`: the buffer of the CURRENT step -- or, ring != NULL, slot (*step mod ring_slots)
+ * of a ring of slots of slot_words words holds it at word index_off (the id ring of cr_adam_desc: a slot = ids + index).
+ * cr_table_grad WRITES the rows that have units into table_grad ([V + T_pos, D], plain stores: the other rows are not touched -- zero
+ * where the caller keeps them zero, as cr_adam_step does) -- the data-parallel path, whose bucket is all-reduced before Adam.  The
+ * one-GPU path hands the same description to cr_adam_step (cr_adam_desc.tg), which sums each listed row and applies its update in
+ * place, and sweeps the rows WITHOUT units with a zero gradient (TensorFlow's dense update, modules.py:154-157 + sasrec.py:120-121):
+ * no table_grad array at all. */
+typedef struct {
+    const int32_t* index;             /* static index buffer (used when ring == NULL) */
+    const int32_t* ring; int ring_slots; int64_t slot_words, index_off;
+    const uint32_t* step;             /* device word: the step number that selects the ring slot */
+    cr_index_layout lay;
+    const float* rows; const float* rows2; int ld_rows;
+    float scale;                      /* modules.py:159-160 */
+    const float* seq_emb; int ld_emb;
+    const float* coef;                /* [2, M] */
+    int D;
+    float* part_rows; uint32_t* tickets;   /* workspace of the sliced rows: [lay.cap_blocks, D] floats and [lay.cap_blocks] words, the
+                                              words ZERO before the first launch (every launch leaves them zero) */
+} cr_tgrad_desc;
+int cr_table_grad(const cr_tgrad_desc* d, float* table_grad, void* stream);
+
 /* ---- Adam, TensorFlow formulation (sasrec.py:120) ------------------------------------
  * g = grad * (1 / n_target); table part: grad = table_grad[i] (zeroed after use);
  * dense part: grad = sum_s dense_slabs[s*n_dense + i].  lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
@@ -486,65 +555,6 @@ int cr_reduce_slabs(const float* dense_slabs, int n_slabs, int n_dense, float* o
 int cr_rows_pack(float* table, const int32_t* ids, int n, int D, int V, uint32_t* flags, const uint32_t* tag, float* packed,
                  int zero_rows, void* stream);
 int cr_rows_add(float* table, const float* packed, int n, int D, int V, void* stream);
-
-/* ---- occurrence index of a batch (round 5; csrc/cr_index.cpp, csrc/cr_tgrad.hip) ---------------------------------
- * The gradient of a looked-up table row is the sum of the gradient rows of every position that looked it up: the three
- * lookups of the item table (seq ids: modules.py:157 through sasrec.py:27; pos / neg ids: sasrec.py:89-90) and the learned
- * positional table's (sasrec.py:40-50).  TensorFlow forms those sums in its gather's gradient; rounds 1-4 formed them with float
- * atomics from the head kernel and the first block's backward (2.56 M + 1.28 M of them per step at the headline shape: ~13 us,
- * and the only sums of a step whose order -- hence whose last bits -- changed from run to run).  The index turns the scatter into
- * a gather: per table row the list of (kind, batch row) pairs, built on the host beside the batch (a stable counting sort, O(rows
- * of the batch)), travelling with the ids, summed on the device in the list's order -- bitwise reproducible, no atomics.
- *
- * Flat row numbering: item rows 0 .. V-1 (row 0, the zero pad, is never listed), then -- T_pos > 0 -- the positional rows V .. V +
- * T_pos - 1 (the positional table follows the item table in the table section, same width).
- * An occurrence is one word: kind << 30 | m.  kind 0: seq id at batch row m (gradient row = scale * rows[m]); 1 / 2: pos / neg id at
- * row m (coef[m] / coef[M + m] times seq_emb[m]); 3: positional row (1.0 * rows[m]).  Within a table row: kind 0 (or 3) by ascending
- * m, then kind 1, then kind 2.
- * A unit is four words {flat row, first occurrence, count, 0}.  LIGHT units (count <= CR_INDEX_HEAVY) are summed by one lane group,
- * HEAVY ones by a whole workgroup (hot items of a Zipf corpus hold thousands of a batch's rows).  Units appear in the order of first
- * appearance (seq, then pos, then neg ids by ascending m; then the positional rows): any order gives the same sums.
- * Words of the index buffer (cr_index_layout, all offsets in int32 words, every section 16-byte aligned):
- *   [0] n_light  [1] n_heavy  [2] n_occ  [3] CR_INDEX_MAGIC  [4..7] 0 | light units | heavy units | occurrences | touched-row bitmap
- * (bit r & 31 of word r >> 5 set <=> flat row r has a unit). */
-#define CR_INDEX_HEAVY 64
-#define CR_INDEX_MAGIC 0x43524958
-typedef struct {
-    int M, V, T_pos;
-    int cap_light, cap_heavy, cap_occ, bitmap_words;
-    int64_t off_light, off_heavy, off_occ, off_bitmap, total_words;
-} cr_index_layout;
-int cr_batch_index_layout(int M, int V, int T_pos, cr_index_layout* out);
-/* Host side, no HIP.  A builder keeps two int32 work arrays of V + T_pos entries between calls (so a build costs O(M), not O(V));
- * not re-entrant on one handle.  seq / pos / neg: [M] ids in [0, V) (the caller range-checks them: Engine.set_batch / feed);
- * `out`: layout.total_words words, written completely. */
-typedef struct cr_index_builder cr_index_builder;
-cr_index_builder* cr_index_builder_create(int M, int V, int T_pos);
-int cr_index_build(cr_index_builder* b, const int32_t* seq, const int32_t* pos, const int32_t* neg, int32_t* out);
-void cr_index_builder_destroy(cr_index_builder* b);
-
-/* The table gradient of a step from the index: grad[row] = sum over the row's occurrences, in list order, for every row that has a
- * unit.  rows / rows2: the gradient rows of the stack input ([M, ld_rows]; rows2 = optional second partial, added: cr_stack_block_bwd
- * leaves them as two partials), already masked and through the embedding dropout; seq_emb: the head's input rows; coef: [2, M] the head's
- * d loss / d logit (cr_head_desc.coef_out).  `index`: the buffer of the CURRENT step -- or, ring != NULL, slot (*step mod ring_slots)
- * of a ring of slots of slot_words words holds it at word index_off (the id ring of cr_adam_desc: a slot = ids + index).
- * cr_table_grad WRITES the rows that have units into table_grad ([V + T_pos, D], plain stores: the other rows are not touched -- zero
- * where the caller keeps them zero, as cr_adam_step does) -- the data-parallel path, whose bucket is all-reduced before Adam.  The
- * one-GPU path hands the same description to cr_adam_step (cr_adam_desc.tg), which sums each listed row and applies its update in
- * place, and sweeps the rows WITHOUT units with a zero gradient (TensorFlow's dense update, modules.py:154-157 + sasrec.py:120-121):
- * no table_grad array at all. */
-typedef struct {
-    const int32_t* index;             /* static index buffer (used when ring == NULL) */
-    const int32_t* ring; int ring_slots; int64_t slot_words, index_off;
-    const uint32_t* step;             /* device word: the step number that selects the ring slot */
-    cr_index_layout lay;
-    const float* rows; const float* rows2; int ld_rows;
-    float scale;                      /* modules.py:159-160 */
-    const float* seq_emb; int ld_emb;
-    const float* coef;                /* [2, M] */
-    int D;
-} cr_tgrad_desc;
-int cr_table_grad(const cr_tgrad_desc* d, float* table_grad, void* stream);
 
 /* ---- HIP graph capture of a whole step (launch-bound inner loop) ---------------------- */
 int cr_graph_begin(void* stream);

@@ -56,6 +56,36 @@ def test_round3_entries_validate_their_arguments_without_gpu():
     assert L.lib.cr_adam_step(ctypes.byref(ad), None) == -1 and b"exclude each other" in L.lib.cr_last_error()
 
 
+def test_round5_entries_validate_their_arguments_without_gpu():
+    """cr_batch_index_layout / cr_index_build / cr_table_grad / cr_adam_desc.tg reject bad descriptions before any HIP call."""
+    lay = L.IndexLayout()
+    assert L.lib.cr_batch_index_layout(0, 10, 0, 32, 16, ctypes.byref(lay)) == -1 and b"cr_batch_index_layout" in L.lib.cr_last_error()
+    assert L.lib.cr_batch_index_layout(12, 10, 5, 32, 16, ctypes.byref(lay)) == -1            # T_pos must divide M
+    assert L.lib.cr_batch_index_layout(12, 10, 4, 65, 16, ctypes.byref(lay)) == -1            # at most 64 lane groups
+    assert L.lib.cr_batch_index_layout(12, 10, 4, 64, 8, ctypes.byref(lay)) == 0              # the plan of D = 48: 64 groups of 8 occurrences
+    assert lay.cap_occ == 48 and lay.bitmap_words == 1 and lay.off_recs == 8 and lay.total_words % 4 == 0 and lay.cap_blocks >= 2
+    assert L.lib.cr_index_build(None, None, None, None, None) == -1 and b"cr_index_build" in L.lib.cr_last_error()
+    g = L.TgradDesc()
+    assert L.lib.cr_table_grad(ctypes.byref(g), None, None) == -1 and b"cr_table_grad" in L.lib.cr_last_error()
+    buf = (ctypes.c_int32 * 64)()
+    p = ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 16
+    g.lay, g.D, g.rows, g.seq_emb, g.coef, g.ld_rows, g.ld_emb, g.index, g.part_rows, g.tickets = lay, 67, p, p, p, 67, 67, p, p, p
+    assert L.lib.cr_table_grad(ctypes.byref(g), p, None) == -1 and b"hidden size" in L.lib.cr_last_error()     # odd and above 64
+    g.D, g.ld_rows, g.ld_emb = 48, 50, 48
+    assert L.lib.cr_table_grad(ctypes.byref(g), p, None) == -1 and b"leading dimensions" in L.lib.cr_last_error()
+    g.ld_rows = 48
+    g.index = None
+    assert L.lib.cr_table_grad(ctypes.byref(g), p, None) == -1 and b"index" in L.lib.cr_last_error()
+    g.index = p
+    ad = L.AdamDesc()
+    ad.p = ad.m = ad.v = ad.state = p
+    ad.n_table, ad.tg = 8, ctypes.pointer(g)                 # (V + T_pos) * D = 14 * 48 is what the index describes
+    assert L.lib.cr_adam_step(ctypes.byref(ad), None) == -1 and b"n_table must be" in L.lib.cr_last_error()
+    ad.n_table = 14 * 48
+    ad.lazy_ids, ad.lazy_flags, ad.n_lazy_ids, ad.lazy_rows, ad.lazy_D = p, p, 4, 2, 4
+    assert L.lib.cr_adam_step(ctypes.byref(ad), None) == -1 and b"exclude each other" in L.lib.cr_last_error()
+
+
 def test_struct_sizes_match_c_layout(tmp_path):
     """sizeof of every descriptor as gcc lays it out from include/castrec.h == the ctypes mirror."""
     import shutil
@@ -67,7 +97,8 @@ def test_struct_sizes_match_c_layout(tmp_path):
              ("cr_ln_bwd_desc", L.LnBwdDesc), ("cr_gemm_desc", L.GemmDesc), ("cr_wgrad_desc", L.WgradDesc),
              ("cr_elt_desc", L.EltDesc), ("cr_attn_desc", L.AttnDesc), ("cr_attn_bwd_desc", L.AttnBwdDesc),
              ("cr_block_desc", L.BlockDesc), ("cr_block_bwd_desc", L.BlockBwdDesc), ("cr_block_bwd1_ext", L.BlockBwd1Ext), ("cr_block_tail_desc", L.BlockTailDesc),
-             ("cr_stack_desc", L.StackDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc)]
+             ("cr_stack_desc", L.StackDesc), ("cr_head_desc", L.HeadDesc), ("cr_adam_desc", L.AdamDesc),
+             ("cr_index_layout", L.IndexLayout), ("cr_tgrad_desc", L.TgradDesc)]
     # every structure the header declares has a mirror in this list
     hdr = open(os.path.join(ROOT, "include", "castrec.h")).read()
     declared = set(re.findall(r"\}\s*(cr_[a-z_0-9]+)\s*;", hdr))

@@ -46,8 +46,7 @@ def test_scanner_sees_the_failing_chain_and_nothing_else():
 
 
 def _headers():
-    return [os.path.join(B.CSRC, h) for h in ("cr_common.hpp", "cr_attn_common.hpp", "cr_bf16.hpp", "cr_rlayout.hpp", "cr_rbwd.hpp")] \
-        + [os.path.join(B.ROOT, "include", "castrec.h")]
+    return B.HEADERS
 
 
 @pytest.mark.parametrize("src", B.ISA_CHECKED)

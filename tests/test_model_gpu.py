@@ -423,6 +423,69 @@ def test_block_backward_is_bitwise_reproducible(E, B, n_slabs):
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
 
 
+@pytest.mark.parametrize("model,D,T", [("cast_1", 50, 100), ("sasrec", 50, 100), ("sasrec", 64, 50), ("cast_3", 20, 24), ("sasrec", 128, 40)])
+def test_a_step_is_bitwise_reproducible_with_the_occurrence_index(E, model, D, T):
+    """Round 5: no float atomics are left in a step's gradients -- the item (and learned positional) table's rows are gathered from
+    the batch's occurrence index in list order (castrec.h "occurrence index") where rounds 1-4 scattered float atomics from the head
+    and the embedding backward.  Same batch, same state: the table gradient (Engine.grads: cr_table_grad) holds the same bits on
+    every run, and two engines hold the same PARAMETER bits after three optimiser steps (cr_adam_step's in-place gather)."""
+    rs = np.random.RandomState(31)
+    B, itemnum = 7, 60                                    # few items: hot rows (hundreds of occurrences -- the heavy units) and rows no batch touches
+    H = 2 if D in (64, 128) else 1
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=9, num_context_blocks=1, lr=1e-3, seed=11)
+    a = E.Engine(model, 9, itemnum, hp, B, training=True)
+    b = E.Engine(model, 9, itemnum, hp, B, training=True)
+    assert a.use_index and a.bitwise_reproducible and a._adam[2][0]._obj.tg
+    names = [n for n, _, _ in a.fwd + a.bwd]
+    assert not any(n.endswith("_scatter") for n in names)
+    b.P.copy_(a.P)
+    batches = [make_batch(rs, B, T, itemnum, 9) for _ in range(3)]
+    tabs = []
+    for _ in range(3):
+        a.set_batch(*batches[0])
+        a.set_step(1)
+        a.launch_step(apply=False)
+        torch.cuda.synchronize()
+        g = a.grads()
+        tabs.append(torch.cat([g[k].reshape(-1) for k in sorted(g) if k in ("item_emb", "pos_emb")] + [a.Gs.reshape(-1)]))
+    assert float(tabs[0].abs().max()) > 0 and torch.equal(tabs[0], tabs[1]) and torch.equal(tabs[0], tabs[2])
+    a.set_step(1)
+    for bt in batches:
+        a.train_step(*bt)
+        b.train_step(*bt)
+    torch.cuda.synchronize()
+    assert torch.equal(a.P, b.P) and torch.equal(a.Mom, b.Mom) and torch.equal(a.Vel, b.Vel)
+    assert bool((a.P != E.Engine(model, 9, itemnum, hp, B, training=False).P).any())
+
+
+def test_index_and_atomics_paths_agree(E, monkeypatch):
+    """CASTREC_NO_INDEX=1 brings the float-atomic scatters of rounds 1-4 back: same gradients (to rounding: another order of the
+    sums), same training run."""
+    rs = np.random.RandomState(33)
+    B, T, D, itemnum = 6, 40, 50, 70
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=9, lr=1e-3, seed=11)
+    a = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    monkeypatch.setenv("CASTREC_NO_INDEX", "1")
+    b = E.Engine("cast_1", 9, itemnum, hp, B, training=True)
+    monkeypatch.delenv("CASTREC_NO_INDEX")
+    assert a.use_index and not b.use_index and b._adam[2][0]._obj.tg is None or not b._adam[2][0]._obj.tg
+    b.P.copy_(a.P)
+    bt = make_batch(rs, B, T, itemnum, 9)
+    for e in (a, b):
+        e.set_batch(*bt); e.set_step(1); e.Gflat.zero_(); e.launch_step(apply=False)
+    torch.cuda.synchronize()
+    ga, gb = a.grads(), b.grads()
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-6 * max(1.0, float(gb[k].abs().max())), k
+    for e in (a, b):
+        e.Gflat.zero_(); e.set_step(1)
+    for _ in range(4):
+        bt = make_batch(rs, B, T, itemnum, 9)
+        a.train_step(*bt); b.train_step(*bt)
+    torch.cuda.synchronize()
+    assert same_run(a, b)
+
+
 def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False, n_slabs=5, dropout=0.1):
     """kink_free: the feed-forward pre-activations are pushed away from the ReLU kink (small W1, biases of +-1 alternating by
     unit), the oracle runs with ITS OWN gates (no hand-over), and the test first proves that the engine's gates are the
@@ -680,7 +743,7 @@ def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
     b = E.Engine("cast_1", 9, itemnum, hp, B, training=True, lazy_adam=lazy)
     b.P.copy_(a.P)
     batches = [make_batch(rs, B, T, itemnum, 20) for _ in range(NS)]
-    ring = torch.from_numpy(np.stack([np.stack([x.reshape(-1) for x in bt]) for bt in batches]).astype(np.int32)).cuda()
+    ring = torch.from_numpy(np.stack([b.pack_slot(*bt) for bt in batches])).cuda()          # a slot: the six id rows (+ the batch's occurrence index)
     b.use_id_ring(ring)
     if graph:
         b.capture()
@@ -694,7 +757,7 @@ def test_id_ring_feeds_the_batches_a_copy_per_step_would(E, lazy, graph):
             b.launch_step()
     torch.cuda.synchronize()
     assert b.step_number() == first + 2 * NS + 1
-    assert torch.equal(b.ids_all.cpu(), ring[b.step_number() % NS].cpu())       # the coming step's batch is in place
+    assert torch.equal(b.ids_all.cpu().reshape(-1), ring[b.step_number() % NS][:6 * B * T].cpu())       # the coming step's batch is in place
     nt = a.layout.n_table
     assert same_run(a, b) and same_loss_auc(a, b, batches[(first + 2 * NS) % NS][1])
     b.P.copy_(a.P); b.Mom.copy_(a.Mom); b.Vel.copy_(a.Vel)
