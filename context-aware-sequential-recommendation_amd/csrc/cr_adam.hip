@@ -69,13 +69,16 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
     constexpr bool TG = LPR > 0;
     cr_kernarg_touch<sizeof(cr_adam_desc) + (TG ? sizeof(cr_tgrad_desc) : 0)>();
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
-    if ((int)blockIdx.x >= (int)gridDim.x - nb_ring) {
+    // (the unit workgroups dispatched FIRST -- physical blocks 0 .. nb_units-1 -- ran the launch 4 us longer than this order: 29.7
+    //  against 25.8 us; the dense blocks' slab sums are the other long chain and want the early start)
+    const int bid = (int)blockIdx.x;
+    if (bid >= (int)gridDim.x - nb_ring) {
         // the last nb_ring blocks: the next step's ids out of the resident ring (nothing else in this launch reads the static id
         // buffers; the occurrence index of the RUNNING step is read from its ring slot, which these blocks do not write)
         constexpr int NT = 64 * ADAM_WAVES;
         const long long n_copy = d.ids_copy_elems ? d.ids_copy_elems : d.ids_slot_elems;
         const int32_t* src1 = d.ids_ring + (long long)((t + 1u) % (uint32_t)d.ids_ring_slots) * d.ids_slot_elems;
-        const long long first = (long long)((int)blockIdx.x - ((int)gridDim.x - nb_ring)) * NT + threadIdx.x, stride = (long long)nb_ring * NT;
+        const long long first = (long long)(bid - ((int)gridDim.x - nb_ring)) * NT + threadIdx.x, stride = (long long)nb_ring * NT;
         if ((d.ids_slot_elems & 3) == 0 && (n_copy & 3) == 0 && (((uintptr_t)d.ids_ring | (uintptr_t)d.ids_dst) & 15) == 0) {
             const int4* src = reinterpret_cast<const int4*>(src1);
             int4* dst = reinterpret_cast<int4*>(d.ids_dst);
@@ -104,9 +107,9 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
         d.v[i] = v;
         d.p[i] -= lr_t * m / (sqrtf(v) + d.eps);
     };
-    if ((int)blockIdx.x < nb_dense) {
-        const int j0 = blockIdx.x * ADAM_COLS;
-        const int ns = d.slab_counts ? min(d.slab_counts[blockIdx.x], d.n_slabs) : d.n_slabs;
+    if (bid < nb_dense) {
+        const int j0 = bid * ADAM_COLS;
+        const int ns = d.slab_counts ? min(d.slab_counts[bid], d.n_slabs) : d.n_slabs;
         // the parameter and its moments are requested BEFORE the slab sum (they do not depend on it): one memory round trip less on
         // the critical path of this short kernel
         const bool mine = threadIdx.x < ADAM_COLS && j0 + (int)threadIdx.x < d.n_dense;
@@ -123,13 +126,13 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
             d.v[i] = v;
             d.p[i] = p0 - lr_t * m / (sqrtf(v) + d.eps);
         }
-    } else if ((int)blockIdx.x < nb_dense + nb_lazy) {
+    } else if (bid < nb_dense + nb_lazy) {
         // lazy rows: wave w of the lazy blocks walks ids w, w + W, ...; the first wave to swap the step number into a row's
         // flag owns the row (every other occurrence of the id finds it there and moves on)
         const int lane = threadIdx.x & 63;
         const int W = nb_lazy * ADAM_WAVES;
         scalars();
-        for (int k = ((int)blockIdx.x - nb_dense) * ADAM_WAVES + (threadIdx.x >> 6); k < d.n_lazy_ids; k += W) {
+        for (int k = (bid - nb_dense) * ADAM_WAVES + (threadIdx.x >> 6); k < d.n_lazy_ids; k += W) {
             const int id = d.lazy_ids[k];
             if (id <= 0 || id >= d.lazy_rows) continue;                       // row 0: the zero-pad row never has a gradient
             int mine = 0;
@@ -143,32 +146,37 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
                 update(i, g);
             }
         }
-    } else if (TG && (int)blockIdx.x < nb_dense + nb_lazy + nb_units) {
-        // the rows the batch looked up: gradient = ordered sum over the row's occurrences, update in place
+    } else if (TG && bid < nb_dense + nb_lazy + nb_units) {
+        // the rows the batch looked up: gradient = ordered sum over the row's occurrences, update in place.  A lane group's p / m / v
+        // (of the row its record names) are requested in front of the batch's loads: one round trip less behind the sums.
         const int32_t* ix = tg_index(g, t);
+        constexpr int W = TG ? VEC : 1;
+        float p0[W], m0[W], v0[W];
         scalars();
-        tg_unit_blocks<TG ? LPR : 16, TG ? VEC : 1, (TG && VEC == 4) ? 8 : 16>(g, ix, (int)blockIdx.x - nb_dense - nb_lazy, nb_units, part_s,
-            reinterpret_cast<int*>(part_s + ADAM_WAVES * ADAM_COLS), [&](int row, int col0, const float (&acc)[TG ? VEC : 1]) {
-                constexpr int W = TG ? VEC : 1;
+        tg_unit_blocks<TG ? LPR : 16, W, (TG && VEC == 4) ? 8 : 16>(g, ix, bid - nb_dense - nb_lazy, nb_units, part_s,
+            reinterpret_cast<int*>(part_s + ADAM_WAVES * ADAM_COLS),
+            [&](int row, int col0, const float (&acc)[W]) {
                 const long long i = (long long)row * g.D + col0;
-                float p[W], m[W], v[W];
-                tg_load<W>(p, d.p + i); tg_load<W>(m, d.m + i); tg_load<W>(v, d.v + i);
 #pragma unroll
                 for (int u = 0; u < W; ++u) {
                     float gu = acc[u] * inv_n;
-                    if (i + u < d.n_l2) gu = fmaf(d.l2, p[u], gu);
-                    m[u] = d.beta1 * m[u] + (1.0f - d.beta1) * gu;
-                    v[u] = d.beta2 * v[u] + (1.0f - d.beta2) * gu * gu;
-                    p[u] -= lr_t * m[u] / (sqrtf(v[u]) + d.eps);
+                    if (i + u < d.n_l2) gu = fmaf(d.l2, p0[u], gu);
+                    m0[u] = d.beta1 * m0[u] + (1.0f - d.beta1) * gu;
+                    v0[u] = d.beta2 * v0[u] + (1.0f - d.beta2) * gu * gu;
+                    p0[u] -= lr_t * m0[u] / (sqrtf(v0[u]) + d.eps);
                 }
-                tg_store<W>(d.m + i, m); tg_store<W>(d.v + i, v); tg_store<W>(d.p + i, p);
+                tg_store<W>(d.m + i, m0); tg_store<W>(d.v + i, v0); tg_store<W>(d.p + i, p0);
+            },
+            [&](int row, int col) {
+                const long long i = (long long)row * g.D + col;       // (an idle group names row 0: a valid address, never consumed)
+                tg_load<W>(p0, d.p + i); tg_load<W>(m0, d.m + i); tg_load<W>(v0, d.v + i);
             });
     } else if (TG) {
         // the rows WITHOUT a unit: the zero-gradient update of TensorFlow's dense Adam (m, v decay, p moves on its momentum)
         const int32_t* ix = tg_index(g, t);
         const uint32_t* bits = reinterpret_cast<const uint32_t*>(ix + ix[6]);
         const int nb_table = gridDim.x - nb_dense - nb_lazy - nb_units - nb_ring;
-        const int tb = (int)blockIdx.x - nb_dense - nb_lazy - nb_units;
+        const int tb = bid - nb_dense - nb_lazy - nb_units;
         constexpr int NT = 64 * ADAM_WAVES;
         const long long stride = (long long)nb_table * NT;
         auto touched = [&](uint32_t row) { return ((bits[row >> 5] >> (row & 31)) & 1u) != 0u; };
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
         // groups of four in flight per thread; the scalar head / tail (a start or an end that is not a multiple of 4) goes to
         // the first table block
         const int nb_table = gridDim.x - nb_dense - nb_lazy - nb_ring;
-        const int tb = (int)blockIdx.x - nb_dense - nb_lazy;
+        const int tb = bid - nb_dense - nb_lazy;
         const long long first = nb_lazy > 0 ? (long long)d.lazy_rows * d.lazy_D : 0;   // the lazy part of the table section is not swept
         constexpr int NT = 64 * ADAM_WAVES;
         const long long a0 = min((first + 3) & ~3ll, d.n_table);
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bid == 0 && threadIdx.x == 0) {
         d.state[5] = (n > 0.0f ? st[0] / n : 0.0f) + (d.n_l2 > 0 ? d.state[7] : 0.0f);   // loss (sasrec.py:105-110)
         d.state[6] = n > 0.0f ? st[1] / n : 0.0f;        // auc   (sasrec.py:113-115)
         if (d.step_snapshot) {                           // end of the step: no block of this kernel reads state[0..4]

@@ -10,7 +10,8 @@ __global__ __launch_bounds__(TG_NT) void k_table_grad(cr_tgrad_desc g, float* ta
     __shared__ float part[TG_NT * VEC + 4];
     const int32_t* ix = tg_index(g, g.step ? *g.step : 0u);
     tg_unit_blocks<LPR, VEC, ENT>(g, ix, blockIdx.x, gridDim.x, part, reinterpret_cast<int*>(part + TG_NT * VEC),
-                                  [&](int row, int col0, const float (&acc)[VEC]) { tg_store<VEC>(table_grad + (size_t)row * g.D + col0, acc); });
+                                  [&](int row, int col0, const float (&acc)[VEC]) { tg_store<VEC>(table_grad + (size_t)row * g.D + col0, acc); },
+                                  [](int, int) {});
 }
 
 extern "C" int cr_tgrad_geometry(int D, int* ng, int* ent) {
@@ -22,7 +23,7 @@ extern "C" int cr_tgrad_geometry(int D, int* ng, int* ent) {
 }
 
 // unit workgroups of a launch: one wave of them where the chip holds it (a batch's plan: a few hundred at the headline shape)
-int tg_unit_grid(const cr_tgrad_desc* d) { return d->lay.cap_blocks < 512 ? d->lay.cap_blocks : 512; }
+int tg_unit_grid(const cr_tgrad_desc* d) { return d->lay.cap_blocks < 320 ? d->lay.cap_blocks : 320; }
 
 extern "C" int cr_table_grad(const cr_tgrad_desc* d, float* table_grad, void* stream) {
     const char* why = tg_unsupported(d);

@@ -47,56 +47,70 @@ __device__ __forceinline__ const int32_t* tg_index(const cr_tgrad_desc& g, uint3
     return g.ring ? g.ring + (size_t)(step % (uint32_t)g.ring_slots) * (size_t)g.slot_words + (size_t)g.index_off : g.index;
 }
 
-// acc = sum over occurrences [s, s + n) of the list (n <= ENT), in order; `col`: the lane's first column (clamped into the row)
-template <int VEC, int ENT>
+// acc = sum over occurrences [s, s + n) of the list (n <= ENT <= LPR), in order; `col`: the lane's first column (clamped into the row).
+// Lane j of the group fetches occurrence j and its coefficient ONCE (two load instructions per wave for all of its groups' entries);
+// the group then takes them from that lane, entry after entry (cross-lane reads, no memory).  The launch is bound by the CU's load
+// ISSUE (one wave instruction per ~16 clocks: a row load of this shape carries 400-1 024 bytes): first version -- every lane loading
+// every occurrence word and coefficient itself, and a second row load per entry whether it had a second partial or not -- issued 64
+// loads per wave and batch where this issues ~25: 12.2 -> ... us for the headline batch (rocprofv3, cr_table_grad alone).
+template <int LPR, int VEC, int ENT>
 __device__ __forceinline__ void tg_batch(const cr_tgrad_desc& g, const int32_t* occ, int s, int n, int col, float (&acc)[VEC]) {
+    static_assert(ENT <= LPR, "an occurrence per lane of the group");
     const size_t M = (size_t)g.lay.M;
     const float* rows2 = g.rows2;
-    uint32_t w[ENT];
-#pragma unroll
-    for (int j = 0; j < ENT; ++j) w[j] = (uint32_t)occ[s + (j < n ? j : 0)];
-    float c1[ENT], c2[ENT], v1[ENT][VEC], v2[ENT][VEC];
+    const int lane = threadIdx.x & 63, lg = lane % LPR, gbase = lane - lg;
+    // my occurrence (lanes >= n repeat the last one with a zero coefficient; an idle group -- n == 0 -- reads word s = 0 of the list)
+    const uint32_t wm = (uint32_t)occ[s + (lg < n ? lg : (n > 0 ? n - 1 : 0))];
+    const int kind_m = (int)(wm >> 30);
+    const bool isrow_m = kind_m == 0 || kind_m == 3;
+    const float cf = g.coef[isrow_m ? 0 : (size_t)(kind_m - 1) * M + (size_t)(wm & 0x3fffffffu)];     // (row kinds: a dummy read)
+    const float cm = lg < n ? (kind_m == 0 ? g.scale : (kind_m == 3 ? 1.0f : cf)) : 0.0f;
+    float c1[ENT], v1[ENT][VEC], v2[ENT][VEC];
+    bool two[ENT];
 #pragma unroll
     for (int j = 0; j < ENT; ++j) {
-        const bool ok = j < n;
-        const int kind = (int)(w[j] >> 30);
-        const size_t m = (size_t)(w[j] & 0x3fffffffu);
+        const uint32_t w = (uint32_t)__shfl((int)wm, gbase + j, 64);
+        c1[j] = __shfl(cm, gbase + j, 64);
+        const int kind = (int)(w >> 30);
+        const size_t m = (size_t)(w & 0x3fffffffu);
         const bool isrow = kind == 0 || kind == 3;
-        const float cf = g.coef[isrow ? 0 : (size_t)(kind - 1) * M + m];                 // (row kinds: a dummy read, not used)
-        const float c = !ok ? 0.0f : (kind == 0 ? g.scale : (kind == 3 ? 1.0f : cf));
         const float* p1 = isrow ? g.rows + m * (size_t)g.ld_rows : g.seq_emb + m * (size_t)g.ld_emb;
-        const float* p2 = (isrow && rows2) ? rows2 + m * (size_t)g.ld_rows : p1;
-        c1[j] = c;
-        c2[j] = (isrow && rows2) ? c : 0.0f;
         tg_load<VEC>(v1[j], p1 + col);
-        tg_load<VEC>(v2[j], p2 + col);
+        two[j] = isrow && rows2 != nullptr && j < n;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) v2[j][u] = 0.0f;
+        if (two[j]) tg_load<VEC>(v2[j], rows2 + m * (size_t)g.ld_rows + col);        // (uniform per lane group)
     }
 #pragma unroll
     for (int u = 0; u < VEC; ++u) acc[u] = 0.0f;
 #pragma unroll
     for (int j = 0; j < ENT; ++j)
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) acc[u] = fmaf(c2[j], v2[j][u], fmaf(c1[j], v1[j][u], acc[u]));
+        for (int u = 0; u < VEC; ++u) acc[u] = fmaf(c1[j], v2[j][u], fmaf(c1[j], v1[j][u], acc[u]));
 }
 
 // Workgroup `ub` of `nub` unit workgroups.  consume(flat row, first column of the lane, acc) is called by the lanes whose columns
 // exist, once per listed row.  part: LDS, TG_NT * VEC floats; flag: one LDS word.
-template <int LPR, int VEC, int ENT, typename F>
-__device__ __forceinline__ void tg_unit_blocks(const cr_tgrad_desc& g, const int32_t* ix, int ub, int nub, float* part, int* flag, F&& consume) {
+template <int LPR, int VEC, int ENT, typename F, typename P>
+__device__ __forceinline__ void tg_unit_blocks(const cr_tgrad_desc& g, const int32_t* ix, int ub, int nub, float* part, int* flag, F&& consume, P&& prefetch) {
     constexpr int NG = TG_NT / LPR;
-    const int n_blocks = ix[0];
     const int32_t* recs = ix + g.lay.off_recs;
-    const int32_t* occ = ix + ix[5];
     const int grp = threadIdx.x / LPR, l = threadIdx.x % LPR;
     const int col0 = VEC * l;
     const bool colok = col0 < g.D;                        // (D is a multiple of VEC by the launcher's choice of VEC)
     const int col = colok ? col0 : 0;
+    // the header and this workgroup's first record are requested together (a record slot inside the capacity always exists): the
+    // chain header -> record -> occurrences -> rows is this launch's critical path, four dependent round trips as first written
+    int4 rec = *reinterpret_cast<const int4*>(recs + 4 * ((size_t)min(ub, g.lay.cap_blocks - 1) * NG + grp));
+    const int n_blocks = ix[0];
+    const int32_t* occ = ix + ((g.lay.off_recs + 4 * NG * n_blocks + 3) & ~3);          // (= ix[5], without waiting for it)
     for (int u = ub; u < n_blocks; u += nub) {
-        const int4 rec = *reinterpret_cast<const int4*>(recs + 4 * ((size_t)u * NG + grp));
+        if (u != ub) rec = *reinterpret_cast<const int4*>(recs + 4 * ((size_t)u * NG + grp));
         const uint32_t info = (uint32_t)rec.w;
         const int q = info & 63, k = (info >> 6) & 127, sidx = (info >> 13) & 511, nsl = info >> 22;
+        prefetch(rec.x, col);                             // what consume() will need of the row (requested in front of the batch's loads)
         float acc[VEC];
-        tg_batch<VEC, ENT>(g, occ, rec.y, rec.z, col, acc);          // (an idle group: count 0, every coefficient 0)
+        tg_batch<LPR, VEC, ENT>(g, occ, rec.y, rec.z, col, acc);     // (an idle group: count 0, every coefficient 0)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) part[(grp * LPR + l) * VEC + e] = acc[e];
         __syncthreads();
