@@ -281,7 +281,9 @@ class DataParallel:
         report["finite"] = launched and bool(torch.isfinite(p).all())
         if ref is not None and launched:
             if bitwise is None:
-                bitwise = bool(getattr(self.replica, "bitwise_reproducible", False))
+                # (bit for bit only with one rank: with more, the eager and the captured collectives may sum the ranks' buckets in
+                #  another order -- channels, algorithm -- which is rounding, not a fault)
+                bitwise = bool(getattr(self.replica, "bitwise_reproducible", False)) and self.world == 1
             if bitwise:
                 report["matches_eager"] = bool(torch.equal(p, ref))
             else:

@@ -27,7 +27,10 @@ def test_config_c4_full_size(E, prec):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)              # (f32 above 64 columns: the unfused kernels, by design)
-        eng = _other_shapes(E, "sasrec", 128, 4, 200, 4, B=128, prec=prec, itemnum=368000, zipf=1.0, n_slabs=None, dropout=0.2)
+        # (f32: 4e-4 of a parameter's largest gradient at the small shapes; here a positional row's gradient is the sum of 128
+        #  sequences' rows with cancellation -- 5e-4 observed on pos_emb -- so the bound is the north star's 1e-3)
+        eng = _other_shapes(E, "sasrec", 128, 4, 200, 4, B=128, prec=prec, itemnum=368000, zipf=1.0, n_slabs=None, dropout=0.2,
+                            grad_tol=1e-3 if prec == "f32" else None)
     assert eng.M == 25600 and eng.layout.entries["item_emb"][1] == (368001, 128)
 
 
@@ -141,6 +144,7 @@ def test_config_c5_full_table(E, lazy):
             assert float(diff.max()) < 2.5 * lr, (k, float(diff.max()))
         if step == 1:
             after_step1 = {k: v.clone() for k, v in now.items()}["item_emb"]
+            g_step1 = G["item_emb"].clone()
         if not lazy and step == 2:
             # dense Adam: a row only step 1 touched has moved on its momentum, by the oracle's amount
             t2 = np.isin(uniq, touched_now)
@@ -148,7 +152,11 @@ def test_config_c5_full_table(E, lazy):
             assert bool(only1.any())
             drift_e = (now["item_emb"][only1] - after_step1[only1])
             drift_o = (P["item_emb"][only1] - prev["item_emb"][only1])
-            assert float(drift_o.abs().max()) > 0.05 * lr and float((drift_e - drift_o).abs().max()) < 2e-5
+            # (where step 1's gradient was significant: Adam turns the rounding residue of a ~0 gradient into a move of up to lr on
+            #  either side -- 27 of 1 194 such rows in the first run of this test -- as everywhere in these tests)
+            sig = g_step1[only1].abs() > 1e-5
+            dd = (drift_e - drift_o).abs()
+            assert float(drift_o.abs().max()) > 0.05 * lr and float(sig.double().mean()) > 0.5 and float(dd[sig].max()) < 2e-5, float(dd[sig].max())
         # continue from the engine's values (the allowed Adam differences would otherwise show as activation differences)
         for k in P:
             P[k] = now[k]

@@ -199,3 +199,44 @@ def test_table_grad_gather_equals_the_scatter(D, V, T_pos, two):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), outs[0])
     assert int(tickets.abs().sum()) == 0                  # every launch leaves the slices' tickets zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,stream", [(50, 1, "0"), (64, 2, "0"), (128, 4, "0"), (128, 4, "1"), (33, 1, "0")])
+def test_dense_adam_moves_rows_without_a_unit_on_their_momentum(D, H, stream, monkeypatch):
+    """TensorFlow's Adam is dense on a looked-up table (modules.py:154-157 + sasrec.py:120-121): a row step 1 touched and step 2 does not
+    still moves in step 2 -- m, v decay, p goes on by lr_t m / (sqrt(v) + eps).  Under the occurrence index that update comes from
+    cr_adam_step's sweep of the rows WITHOUT a unit (bitmap), the listed rows' from the gather: every row against the closed form."""
+    import torch
+    from castrec_amd import engine as E
+    monkeypatch.setenv("CASTREC_ADAM_STREAM", stream)     # (the streaming sweep is chosen by size: forced here on a small table)
+    rs = np.random.RandomState(D)
+    B, T, V = 4, 20, 300
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=1, num_heads=H, dropout_rate=0.0, lr=1e-3, seed=3)
+    eng = E.Engine("sasrec", 9, V, hp, B, training=True)
+    assert eng.use_index
+    lay = eng.layout
+    item = lay.view(eng.P, "item_emb")
+    p0 = item.clone()
+    halves = [np.arange(1, 120), np.arange(100, 220)]      # step 2 drops rows 1..99, keeps 100..119, adds 120..219; 220.. never touched
+    snaps = []
+    for step, ids in enumerate(halves, 1):
+        seq, pos, neg = (ids[rs.randint(0, len(ids), (B, T))] for _ in range(3))
+        z = np.zeros_like(seq)
+        eng.set_batch(seq, pos, neg, z, z, z)
+        eng.set_step(step)
+        eng.launch_step(apply=True)
+        torch.cuda.synchronize()
+        snaps.append((item.clone(), lay.view(eng.Mom, "item_emb").clone(), lay.view(eng.Vel, "item_emb").clone(), np.unique(np.r_[seq, pos, neg])))
+    (p1, m1, v1, t1), (p2, m2, v2, t2) = snaps
+    only1 = torch.from_numpy(np.setdiff1d(t1, t2)).to(eng.dev)
+    never = torch.from_numpy(np.setdiff1d(np.arange(1, V + 1), np.union1d(t1, t2))).to(eng.dev)
+    assert len(only1) > 20 and len(never) > 20
+    assert torch.equal(p2[never], p0[never]) and not bool(m2[never].any())          # zero moments: no step moves them
+    lr_t = 1e-3 * np.sqrt(1 - 0.98 ** 2) / (1 - 0.9 ** 2)
+    m_want, v_want = 0.9 * m1[only1].double(), 0.98 * v1[only1].double()
+    p_want = p1[only1].double() - lr_t * m_want / (v_want.sqrt() + 1e-8)
+    assert float(m1[only1].abs().max()) > 0 and float((p_want - p1[only1].double()).abs().max()) > 3e-4
+    assert float((m2[only1].double() - m_want).abs().max()) <= 1e-6 * float(m_want.abs().max())
+    assert float((v2[only1].double() - v_want).abs().max()) <= 1e-6 * float(v_want.abs().max())
+    assert float((p2[only1].double() - p_want).abs().max()) <= 2e-7

@@ -486,7 +486,7 @@ def test_index_and_atomics_paths_agree(E, monkeypatch):
     assert same_run(a, b)
 
 
-def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False, n_slabs=5, dropout=0.1):
+def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9, zipf=None, kink_free=False, n_slabs=5, dropout=0.1, grad_tol=None):
     """kink_free: the feed-forward pre-activations are pushed away from the ReLU kink (small W1, biases of +-1 alternating by
     unit), the oracle runs with ITS OWN gates (no hand-over), and the test first proves that the engine's gates are the
     same everywhere: gradient parity of the split-precision kernels with nothing taken from the engine but the dropout masks."""
@@ -536,7 +536,7 @@ def _other_shapes(E, model, D, H, T, L, B=3, prec="f32", itemnum=41, max_bins=9,
     assert st[0] / st[2] == pytest.approx(float(out["loss"]), rel=tol["loss"])
     got = eng.grads()
     worst = worst_grad_error(got, G, prec)
-    assert worst[0] < 2 * worst[2], worst
+    assert worst[0] < (2 * worst[2] if grad_tol is None else grad_tol), worst
     assert rel(eng.seq_emb, out["seq_emb"].reshape(B * T, -1)) < tol["act"]     # forward parity (north-star bound 1e-3)
     return eng
 
