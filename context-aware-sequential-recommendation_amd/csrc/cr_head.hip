@@ -336,6 +336,170 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
     head_snapshot(d.state);
 }
 
+// The same kernel with VECTOR row accesses (round 5): a lane owns VEC consecutive columns (16- or 8-byte loads: D a multiple of 4,
+// or even), LPR lanes a row (LPR * VEC >= D), and the loop is software-pipelined: the four rows an iteration reads (sequence
+// embedding, LayerNorm input, pos row, neg row) are requested one iteration ahead, the ids two.  k_head_ln above reads a row as
+// LPR-strided dwords (four load instructions per array and row group) and starts each iteration's loads behind the previous one's
+// stores: 14.3 us at the headline shape (two dependent iterations per wave), 81 us for one C5 step's 131 072 table rows (0.52 of the
+// HBM roof over all its bytes).  This kernel is bound by load ISSUE and dependent round trips, so both changes go straight to time.
+typedef float hd_f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float hd_f2 __attribute__((ext_vector_type(2), aligned(4)));
+template <int VEC> struct HdVec { float v[VEC]; };
+template <int VEC>
+__device__ __forceinline__ HdVec<VEC> hd_load(const float* p, bool ok) {
+    HdVec<VEC> r;
+    if constexpr (VEC == 4) {
+        hd_f4 t = (hd_f4){0.f, 0.f, 0.f, 0.f};
+        if (ok) t = *reinterpret_cast<const hd_f4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        hd_f2 t = (hd_f2){0.f, 0.f};
+        if (ok) t = *reinterpret_cast<const hd_f2*>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void hd_store(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) *reinterpret_cast<hd_f4*>(p) = (hd_f4){v[0], v[1], v[2], v[3]};
+    else *reinterpret_cast<hd_f2*>(p) = (hd_f2){v[0], v[1]};
+}
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(1024) void k_head_ln_v(cr_head_desc d, cr_ln_bwd_desc n) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red[3][16 * RPW];
+    __shared__ float wg[16][LPR * VEC], wb[16][LPR * VEC];
+    cr_kernarg_touch<sizeof(cr_head_desc) + sizeof(cr_ln_bwd_desc)>();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    const int c0 = VEC * l;
+    const bool cok = c0 < d.D;
+    const int rps = (d.M + gridDim.x - 1) / gridDim.x;
+    const int m0 = blockIdx.x * rps, m1 = min(d.M, m0 + rps);
+    constexpr int STEP = 16 * RPW;                        // rows per iteration of the workgroup
+    float gam[VEC], ag[VEC], ab[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) { gam[u] = (c0 + u < d.D) ? n.gamma[c0 + u] : 0.0f; ag[u] = 0.0f; ab[u] = 0.0f; }
+    const float invD = 1.0f / (float)d.D;
+    float loss_acc = 0.0f, auc_acc = 0.0f, n_acc = 0.0f;
+    // pipeline: ids of iterations 0 and 1, rows of iteration 0
+    const int mfirst = m0 + wave * RPW + sub;
+    int p_a = 0, ng_a = 0, p_b = 0, ng_b = 0;             // ids of this iteration / the next one
+    if (mfirst < m1) { p_a = d.pos[mfirst]; ng_a = d.neg[mfirst]; }
+    if (mfirst + STEP < m1) { p_b = d.pos[mfirst + STEP]; ng_b = d.neg[mfirst + STEP]; }
+    HdVec<VEC> s_n, x_n, ep_n, en_n;
+    {
+        const bool act = mfirst < m1;
+        const int mm = act ? mfirst : m0;
+        s_n = hd_load<VEC>(d.seq_emb + (size_t)mm * d.ld + c0, cok);
+        x_n = hd_load<VEC>(n.x + (size_t)mm * n.ldx + c0, cok);
+        ep_n = hd_load<VEC>(d.table + (size_t)p_a * d.D + c0, cok && p_a != 0);      // row 0 == zeros (modules.py:154-156)
+        en_n = hd_load<VEC>(d.table + (size_t)ng_a * d.D + c0, cok && ng_a != 0);
+    }
+    for (int mb = m0 + wave * RPW; mb < m1; mb += STEP) {
+        const int m = mb + sub;
+        const bool act = m < m1;
+        const int p = act ? p_a : 0;
+        const HdVec<VEC> s = s_n, xv = x_n, ep = ep_n, en = en_n;
+        // the next iteration's rows (its ids arrived an iteration ago), the ids of the one after
+        {
+            const int mn = m + STEP;
+            const bool actn = mn < m1;
+            const int mmn = actn ? mn : m0;
+            const int pn = actn ? p_b : 0, nn = actn ? ng_b : 0;
+            s_n = hd_load<VEC>(d.seq_emb + (size_t)mmn * d.ld + c0, cok);
+            x_n = hd_load<VEC>(n.x + (size_t)mmn * n.ldx + c0, cok);
+            ep_n = hd_load<VEC>(d.table + (size_t)pn * d.D + c0, cok && pn != 0);
+            en_n = hd_load<VEC>(d.table + (size_t)nn * d.D + c0, cok && nn != 0);
+            p_a = p_b; ng_a = ng_b;
+            p_b = 0; ng_b = 0;
+            if (mn + STEP < m1) { p_b = d.pos[mn + STEP]; ng_b = d.neg[mn + STEP]; }
+        }
+        float pl = 0.0f, nl = 0.0f, xs = 0.0f;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { pl += ep.v[u] * s.v[u]; nl += en.v[u] * s.v[u]; xs += xv.v[u]; }
+        pl = head_row_sum<LPR>(pl);                                            // sasrec.py:100
+        nl = head_row_sum<LPR>(nl);                                            // sasrec.py:101
+        const float ist = (p != 0) ? 1.0f : 0.0f;                              // sasrec.py:104
+        const float sp = 1.0f / (1.0f + expf(-pl)), sn = 1.0f / (1.0f + expf(-nl));
+        if (l == 0 && act) {
+            loss_acc += ist * (-logf(sp + 1e-24f) - logf(1.0f - sn + 1e-24f)); // sasrec.py:105-108
+            const float dlt = pl - nl;
+            const float sgn = (dlt > 0.0f) ? 1.0f : ((dlt < 0.0f) ? -1.0f : 0.0f);
+            auc_acc += ist * (sgn + 1.0f) * 0.5f;                              // sasrec.py:113-115
+            n_acc += ist;
+            if (d.pos_logits) d.pos_logits[m] = pl;
+            if (d.neg_logits) d.neg_logits[m] = nl;
+        }
+        const float dpl = act ? -ist * sp * (1.0f - sp) / (sp + 1e-24f) : 0.0f;
+        const float dnl = act ? ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f) : 0.0f;
+        if (d.coef_out && l == 0 && act) {
+            d.coef_out[m] = dpl;
+            d.coef_out[(size_t)d.M + m] = dnl;
+        }
+        // ---- LayerNorm backward of this row (modules.py:74-78), dy in registers
+        const float mean = head_row_sum<LPR>(xs) * invD;
+        float v = 0.0f, xh[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            const float dxm = (c0 + u < d.D) ? (xv.v[u] - mean) : 0.0f;
+            xh[u] = dxm;
+            v += dxm * dxm;
+        }
+        const float rstd = 1.0f / sqrtf(head_row_sum<LPR>(v) * invD + n.eps);
+        float dy[VEC], c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            dy[u] = dpl * ep.v[u] + dnl * en.v[u];
+            xh[u] *= rstd;
+            const float dg = dy[u] * gam[u];
+            c1 += dg;
+            c2 += dg * xh[u];
+            ag[u] += dy[u] * xh[u];
+            ab[u] += dy[u];
+        }
+        if (act && cok && d.d_seq_emb) hd_store<VEC>(d.d_seq_emb + (size_t)m * d.ldd + c0, dy);
+        c1 = head_row_sum<LPR>(c1) * invD;
+        c2 = head_row_sum<LPR>(c2) * invD;
+        if (act && cok) {
+            float o[VEC];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) o[u] = cr_ln_bwd_tail(dy[u] * gam[u], c1, xh[u], c2, rstd);
+            hd_store<VEC>(n.dx + (size_t)m * n.lddx + c0, o);
+        }
+    }
+    if (l == 0) { red[0][wave * RPW + sub] = loss_acc; red[1][wave * RPW + sub] = auc_acc; red[2][wave * RPW + sub] = n_acc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float v = 0.0f;
+        for (int i = 0; i < 16 * RPW; ++i) v += red[threadIdx.x][i];
+        if (v != 0.0f) atomicAdd(d.state + threadIdx.x, v);
+    }
+    // dgamma / dbeta: the wave's row groups by shuffles, then the 16 waves in a fixed order
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            ag[u] += __shfl_xor(ag[u], o, 64);
+            ab[u] += __shfl_xor(ab[u], o, 64);
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { wg[wave][c0 + u] = ag[u]; wb[wave][c0 + u] = ab[u]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.D; c += 1024) {
+        float g = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { g += wg[w][c]; b += wb[w][c]; }
+        n.dgamma[(size_t)blockIdx.x * n.slab_stride + c] = g;
+        n.dbeta[(size_t)blockIdx.x * n.slab_stride + c] = b;
+    }
+    head_snapshot(d.state);
+}
+
 extern "C" int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream) {
     CR_REQUIRE(d && d->seq_emb && d->table && d->pos && d->neg && d->state, "cr_head_fwd_bwd_ln: NULL pointer");
     CR_REQUIRE(d->M > 0 && d->D > 0 && d->V > 0 && d->ld >= d->D, "cr_head_fwd_bwd_ln: bad shape");
@@ -346,6 +510,26 @@ extern "C" int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n
     if (d->D > 512) return cr_set_error(CR_ERR_UNSUPPORTED, "cr_head_fwd_bwd_ln: D=%d > 512", d->D);
     // lanes per row: 16 (D <= 64), 32 (D <= 128: two rows per wave and DPP row sums -- with a whole wave per row the eight rows
     // of a wave at config C4 were eight serial gather -> reduce -> atomics passes: 36 us), else 64
+    // vector row accesses where the shape allows them, and nothing scatters from this kernel (the occurrence-index form)
+    static const bool no_vec = getenv("CASTREC_HEAD_NO_VEC") != nullptr;
+    const bool al = ((d->ld | n->ldx | n->lddx | (d->d_seq_emb ? d->ldd : 0)) % 2) == 0;
+    // (D = 50: 32 lanes x 8 bytes halve the rows a wave holds per iteration -- four dependent iterations instead of two at the headline
+    //  shape: 17.6 against 16.5 us; 16-byte lanes keep four rows per wave up to 64 columns, and above 64 the scalar form's strided dwords
+    //  lose outright: 82.2 -> 65.1 us for one C5 step's rows, 0.51 -> 0.65 of the HBM roof, bench.py gather.head_ln)
+    if (!no_vec && !d->table_grad && al && d->D % 2 == 0 && d->D <= 256 && (d->D % 4 == 0 || d->D > 64)) {
+        const bool v4 = d->D % 4 == 0 && ((d->ld | n->ldx | n->lddx | (d->d_seq_emb ? d->ldd : 0)) % 4) == 0;
+#define HD_LAUNCH(L, V) hipLaunchKernelGGL((k_head_ln_v<L, V>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n)
+        if (v4 && d->D <= 64) HD_LAUNCH(16, 4);
+        else if (v4 && d->D <= 128) HD_LAUNCH(32, 4);
+        else if (v4) HD_LAUNCH(64, 4);
+        else if (d->D <= 32) HD_LAUNCH(16, 2);
+        else if (d->D <= 64) HD_LAUNCH(32, 2);
+        else if (d->D <= 128) HD_LAUNCH(64, 2);
+        else goto scalar_form;
+#undef HD_LAUNCH
+        return cr_check_launch("cr_head_fwd_bwd_ln");
+    }
+scalar_form:
     if (d->D <= 64)
         hipLaunchKernelGGL((k_head_ln<16, 4>), dim3(n->n_slabs), dim3(1024), 0, cr_stream(stream), *d, *n);
     else if (d->D <= 128)

@@ -475,8 +475,8 @@ def test_index_and_atomics_paths_agree(E, monkeypatch):
         e.set_batch(*bt); e.set_step(1); e.Gflat.zero_(); e.launch_step(apply=False)
     torch.cuda.synchronize()
     ga, gb = a.grads(), b.grads()
-    for k in ga:
-        assert float((ga[k] - gb[k]).abs().max()) <= 1e-6 * max(1.0, float(gb[k].abs().max())), k
+    for k in ga:                                          # (fp32 sums in another order: rounding, relative to the parameter's gradient scale)
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * max(1e-6, float(gb[k].abs().max())), k
     for e in (a, b):
         e.Gflat.zero_(); e.set_step(1)
     for _ in range(4):
