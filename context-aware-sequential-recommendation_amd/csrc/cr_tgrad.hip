@@ -10,8 +10,7 @@ __global__ __launch_bounds__(TG_NT) void k_table_grad(cr_tgrad_desc g, float* ta
     __shared__ float part[TG_NT * VEC + 4];
     const int32_t* ix = tg_index(g, g.step ? *g.step : 0u);
     tg_unit_blocks<LPR, VEC, ENT>(g, ix, blockIdx.x, gridDim.x, part, reinterpret_cast<int*>(part + TG_NT * VEC),
-                                  [&](int row, int col0, const float (&acc)[VEC]) { tg_store<VEC>(table_grad + (size_t)row * g.D + col0, acc); },
-                                  [](int, int) {});
+                                  [&](int row, int col0, const float (&acc)[VEC]) { tg_store<VEC>(table_grad + (size_t)row * g.D + col0, acc); });
 }
 
 extern "C" int cr_tgrad_geometry(int D, int* ng, int* ent) {

@@ -91,8 +91,8 @@ __device__ __forceinline__ void tg_batch(const cr_tgrad_desc& g, const int32_t* 
 
 // Workgroup `ub` of `nub` unit workgroups.  consume(flat row, first column of the lane, acc) is called by the lanes whose columns
 // exist, once per listed row.  part: LDS, TG_NT * VEC floats; flag: one LDS word.
-template <int LPR, int VEC, int ENT, typename F, typename P>
-__device__ __forceinline__ void tg_unit_blocks(const cr_tgrad_desc& g, const int32_t* ix, int ub, int nub, float* part, int* flag, F&& consume, P&& prefetch) {
+template <int LPR, int VEC, int ENT, typename F>
+__device__ __forceinline__ void tg_unit_blocks(const cr_tgrad_desc& g, const int32_t* ix, int ub, int nub, float* part, int* flag, F&& consume) {
     constexpr int NG = TG_NT / LPR;
     const int32_t* recs = ix + g.lay.off_recs;
     const int grp = threadIdx.x / LPR, l = threadIdx.x % LPR;
@@ -108,7 +108,6 @@ __device__ __forceinline__ void tg_unit_blocks(const cr_tgrad_desc& g, const int
         if (u != ub) rec = *reinterpret_cast<const int4*>(recs + 4 * ((size_t)u * NG + grp));
         const uint32_t info = (uint32_t)rec.w;
         const int q = info & 63, k = (info >> 6) & 127, sidx = (info >> 13) & 511, nsl = info >> 22;
-        prefetch(rec.x, col);                             // what consume() will need of the row (requested in front of the batch's loads)
         float acc[VEC];
         tg_batch<LPR, VEC, ENT>(g, occ, rec.y, rec.z, col, acc);     // (an idle group: count 0, every coefficient 0)
 #pragma unroll
