@@ -20,7 +20,14 @@
 // (The first version clamped and masked every piece of every tile per lane: 5 VALU instructions per element, and the
 //  kernel is VALU-issue bound -- about 700 of the 1100 instructions of a phase-A tile were this bookkeeping.)
 struct DCtx { int D, nfull, rem, np; };                   // np = D % 4: elements of the crossing piece
-__device__ __forceinline__ DCtx d_ctx(int D) { DCtx c; c.D = D; c.nfull = D >> 4; c.rem = D & 15; c.np = D & 3; return c; }
+// NF >= 0: the number of whole column tiles as a COMPILE-TIME constant (the caller guarantees NF == D / 16): the tile classification
+// of every helper below then folds at any hidden size of that family -- what is left at run time are two scalars (rem, np) and the
+// lane predicates of the ONE boundary tile.  With nfull a run-time value every tile of every helper keeps all three forms alive, and
+// the one-launch block backward spilled 108-228 bytes per lane (round 4's generic instantiation).
+template <int NF = -1>
+__device__ __forceinline__ DCtx d_ctx(int D) { DCtx c; c.D = D; c.nfull = NF >= 0 ? NF : (D >> 4); c.rem = D & 15; c.np = D & 3; return c; }
+// the template argument for a kernel's hidden-size parameter DS (> 0: exact size; 0: anything; < 0: the family nfull = -DS - 1)
+#define D_NF(DS) ((DS) > 0 ? (DS) / 16 : ((DS) < 0 ? -(DS) - 1 : -1))
 // Thread / lane number the optimiser cannot hoist or share between uses: everything derived from it (column offsets,
 // pad masks) is then recomputed where it is used -- a few VALU ops -- instead of being kept live across the whole kernel
 // (the loop-invariant per-lane values of all helpers together spilled 160 registers).

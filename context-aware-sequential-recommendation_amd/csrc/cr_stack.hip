@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     auto tile_b = [&](int i) { return i == 0 ? tile0 : tile1; };
     const bool wr_kv = !PAIR || blockIdx.y == 0;                             // this workgroup writes K / V / key flags to HBM
     const float c2 = a.isd_log2e;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<D_NF(DS)>(D);
     auto row_of = [&](int tile) { return (u32)(base_row + min(16 * tile + (lane_now() & 15), T - 1)) * (u32)(4 * D); };   // byte offset of the lane's row
 
     WRegs<2, NT> wa;
@@ -547,7 +547,18 @@ static int launch_stack(const StackArgs& a, int B, bool pair, hipStream_t s) {
         if (a.blk[0].ad.H == 2) return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
     }
     if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false, 1>(a, B, s);
-    return pair ? launch_stack_d<NKT, SPLIT, 0, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 1>(a, B, s);
+    if constexpr (NKT == 13 && SPLIT) {
+        // 13 tiles, split arithmetic, another hidden size (the headline's length at --hidden_units 20 / 36 / 44 / 60 ...): the instantiation of
+        // the size's FAMILY (whole 16-column tiles as a constant, cr_rlayout.hpp d_ctx<NF>) -- the fully generic one spilled 24-128 bytes per lane
+        switch (a.blk[0].bd.D / 16) {
+        case 0: return pair ? launch_stack_d<NKT, SPLIT, -1, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -1, false, 1>(a, B, s);
+        case 1: return pair ? launch_stack_d<NKT, SPLIT, -2, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -2, false, 1>(a, B, s);
+        case 2: return pair ? launch_stack_d<NKT, SPLIT, -3, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -3, false, 1>(a, B, s);
+        default: return pair ? launch_stack_d<NKT, SPLIT, -4, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -4, false, 1>(a, B, s);
+        }
+    } else {
+        return pair ? launch_stack_d<NKT, SPLIT, 0, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 1>(a, B, s);
+    }
 }
 static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, hipStream_t st) {
     if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, st) : launch_stack<4, false>(a, B, pair, st);

@@ -205,7 +205,7 @@ struct B1Acc { f32x4 aw1[2], aw2[2], aw1b[2], aw2b[2], ag[4], ab[4], agF[4], abF
 template <bool SPLIT, int DS, bool QSIDE, int HD, class F>
 __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, B1Steps& steps, F&& before_last_products) {
     constexpr bool BIAS = DS == 64;
-    constexpr bool LATE_Q = !QSIDE && (HD == 2 || DS > 50 || DS == 0);       // key side: the tile's Q rows are requested late (registers)
+    constexpr bool LATE_Q = !QSIDE && (HD == 2 || DS > 50 || DS <= 0);       // key side: the tile's Q rows are requested late (registers)
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     float* gam = fl + L::GAM; float* gamF = fl + L::GAMF; float* part = fl + L::PART; float* partF = fl + L::PARTF; float* sdel = fl + L::SDEL;
     constexpr int WST = L::WST, IST = L::IST;
     const int D = DS > 0 ? DS : d.D, T = a.T;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the step counters: requested first of all, used behind the barrier that opens the phase
     uint32_t sv_ffn2 = cr_step_request(d.drop_ffn2), sv_attn = cr_step_request(a.ad.drop), sv_emb = a.scatter ? cr_step_request(a.sc.f.drop) : 0u;
@@ -499,21 +499,22 @@ __device__ __forceinline__ void b1_scatter_rows(const B1Args& a, const float* bu
 // (The rows and ids are requested by b1_small_issue in front of phase 3's products: they are the side's own partial, complete and
 //  visible behind the barrier that ends the attention loops.)
 struct B1Small { RRaw r0, r1; int my_id; };
+template <int NF>
 __device__ __forceinline__ void b1_small_issue(B1Small& q, const B1Args& a, const float* buf, int n, int D) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = a.T, li = lane_now() & 15;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<NF>(D);
     const int tt0 = wave, tt1 = wave + SB_WAVES;          // the wave's rows: tiles w and w + 8
     if (tt0 < a.nkt) r_issue(q.r0, buf, (u32)(n * T + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt0 + li < T);
     if (tt1 < a.nkt) r_issue(q.r1, buf, (u32)(n * T + min(16 * tt1 + li, T - 1)) * (u32)(4 * D), dcx, 16 * tt1 + li < T);
     q.my_id = ((int)threadIdx.x < T) ? a.sc.f.ids[n * T + threadIdx.x] : -1;
 }
-template <bool SPLIT>
+template <bool SPLIT, int NF>
 __device__ __forceinline__ void b1_small_table(const B1Args& a, unsigned char* smem, int* ids_lds, B1Small& q, int n, int D, bool add) {
     const cr_embed_desc& e = a.sc.f;
     __bf16* Gh = reinterpret_cast<__bf16*>(smem);
     __bf16* Gl = Gh + B1_FSTR;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nkt = a.nkt;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<NF>(D);
     RRaw& r0 = q.r0; RRaw& r1 = q.r1;
     const int tt0 = wave, tt1 = wave + SB_WAVES;
     const int t = threadIdx.x;
@@ -705,7 +706,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     float* gam = fl + L::GAM; float* part = fl + L::PART; float* sdel = fl + L::SDEL; float* kb = fl + L::KB;
     constexpr int IST = L::IST;
     const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
     const size_t MD = (size_t)M * D;
@@ -991,7 +992,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt1, dQ);
     }
     B1Small small;
-    if (a.scatter && a.small) b1_small_issue(small, a, a.sbuf, n, D);
+    if (a.scatter && a.small) b1_small_issue<D_NF(DS)>(small, a, a.sbuf, n, D);
     __syncthreads();
     B1_TS(16);
     wgrad_accum<SPLIT, BIAS, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);       // dWq (+ dbq) += q_in^T dQ (nob: the bias sums at D = 64)
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
     b1_ln_flush<2>(part, bd.g_ln1_g + so, bd.g_ln1_b + so, D, add);         // (the folds of phase 2 lie behind two barriers)
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(part), small, n, D, add);   // (part: the sequence's ids)
+    if (a.scatter && a.small) b1_small_table<SPLIT, D_NF(DS)>(a, smem, reinterpret_cast<int*>(part), small, n, D, add);   // (part: the sequence's ids)
     else if (a.scatter) b1_scatter_rows(a, a.sbuf, n, D);
     B1_TS(5);
     (void)MD;
@@ -1023,7 +1024,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     float* tile_flag = fl + L::TFLAG;
     constexpr int WST = L::WST, IST = L::IST;
     const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
-    const DCtx dcx = d_ctx(D);
+    const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
     const size_t MD = (size_t)M * D;
@@ -1347,7 +1348,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             img_put<SPLIT>(Im + 2 * IST, Im + 2 * IST + SB_IMG, 16 * wave, g);
         }
         issue3(rd + 1);
-        if (rd == R - 1 && a.scatter && a.small) b1_small_issue(small, a, a.sbuf2, n, D);     // (the small table's rows: under the last products)
+        if (rd == R - 1 && a.scatter && a.small) b1_small_issue<D_NF(DS)>(small, a, a.sbuf2, n, D);     // (the small table's rows: under the last products)
         __syncthreads();
         if (rd == 0) B1_TS(16);
         wgrad_accum<SPLIT, BIAS>(awk, awkb, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);                // dWk (+ dbk) += x^T dK
@@ -1360,7 +1361,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     b1_wstore<BIAS>(bd.g_wqkv + so + D, 3 * D, bd.g_bqkv + so + D, awk, awkb, D, it, jt0, add);
     b1_wstore<BIAS>(bd.g_wqkv + so + 2 * D, 3 * D, bd.g_bqkv + so + 2 * D, awv, awvb, D, it, jt0, add);
     B1_TS(18);
-    if (a.scatter && a.small) b1_small_table<SPLIT>(a, smem, reinterpret_cast<int*>(fl + L::PART), small, n, D, add);
+    if (a.scatter && a.small) b1_small_table<SPLIT, D_NF(DS)>(a, smem, reinterpret_cast<int*>(fl + L::PART), small, n, D, add);
     else if (a.scatter) b1_scatter_rows(a, a.sbuf2, n, D);
     B1_TS(5);
 }
@@ -1539,10 +1540,17 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     case 32: return split ? launch_b1<true, 32>(a, nwg, s) : launch_b1<false, 32>(a, nwg, s);
     case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);
     case 48: return split ? launch_b1<true, 48>(a, nwg, s) : launch_b1<false, 48>(a, nwg, s);
-    case 16: return split ? launch_b1<true, 16>(a, nwg, s) : launch_b1<false, 16>(a, nwg, s);
-    case 8: return split ? launch_b1<true, 8>(a, nwg, s) : launch_b1<false, 8>(a, nwg, s);
-    case 24: return split ? launch_b1<true, 24>(a, nwg, s) : launch_b1<false, 24>(a, nwg, s);
     case 56: return split ? launch_b1<true, 56>(a, nwg, s) : launch_b1<false, 56>(a, nwg, s);
-    default: return split ? launch_b1<true, 0>(a, nwg, s) : launch_b1<false, 0>(a, nwg, s);
+    default: break;
+    }
+    // any other size: the instantiation of its FAMILY -- the number of whole 16-column tiles as a constant, the hidden size itself at run
+    // time (cr_rlayout.hpp d_ctx<NF>).  Hidden sizes below 48: no scratch (238 / 252 registers); 49 .. 63 other than 50 / 56: 48 / 132 bytes
+    // per lane, where round 4's fully generic instantiation (every size outside the constants) spilled 108 / 228
+    // (-Rpass-analysis=kernel-resource-usage, tools/res_usage.sh cr_stack_bwd1.hip).
+    switch (d->D / 16) {
+    case 0: return split ? launch_b1<true, -1>(a, nwg, s) : launch_b1<false, -1>(a, nwg, s);
+    case 1: return split ? launch_b1<true, -2>(a, nwg, s) : launch_b1<false, -2>(a, nwg, s);
+    case 2: return split ? launch_b1<true, -3>(a, nwg, s) : launch_b1<false, -3>(a, nwg, s);
+    default: return split ? launch_b1<true, -4>(a, nwg, s) : launch_b1<false, -4>(a, nwg, s);
     }
 }
