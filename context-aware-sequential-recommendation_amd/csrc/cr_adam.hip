@@ -187,19 +187,29 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
             };
             const long long n4 = d.n_table >> 2;
             const unsigned D4 = (unsigned)g.D >> 2;
+            const int sh = (D4 & (D4 - 1u)) == 0u ? __builtin_ctz(D4) : -1;      // (128 / 256 columns: a shift instead of a 64-bit division per group)
             constexpr int U = 4;
+            // p / m / v of a group are requested WITHOUT waiting for the bitmap word that says whether the row is listed (a dependent
+            // round trip in front of every batch of loads: the first version swept config C5's table no faster than the sweep that also
+            // read and zeroed a gradient array); a listed row's values are read and dropped (2 % of the rows at C5), only its STORES
+            // are skipped -- the unit workgroups write those elements
             for (long long q = (long long)tb * NT + threadIdx.x; q < n4; q += U * stride) {
-                bool go[U];
+                bool in[U];
+                uint32_t bw[U];
+                uint32_t row[U];
                 f4a p[U], m[U], v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const long long qq = q + u * stride;
-                    go[u] = qq < n4 && !touched((uint32_t)((unsigned long long)qq / D4));
-                    if (go[u]) { p[u] = ld4(d.p + 4 * qq); m[u] = ld4(d.m + 4 * qq); v[u] = ld4(d.v + 4 * qq); }
+                    in[u] = qq < n4;
+                    const long long qc = in[u] ? qq : q;
+                    row[u] = sh >= 0 ? (uint32_t)(qc >> sh) : (uint32_t)((unsigned long long)qc / D4);
+                    bw[u] = bits[row[u] >> 5];
+                    p[u] = ld4(d.p + 4 * qc); m[u] = ld4(d.m + 4 * qc); v[u] = ld4(d.v + 4 * qc);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (!go[u]) continue;
+                    if (!in[u] || ((bw[u] >> (row[u] & 31)) & 1u)) continue;
                     const long long i = 4 * (q + u * stride);
                     f4a po;
 #pragma unroll
