@@ -158,7 +158,8 @@ def algo_work(name, fnargs, eng):
     if name == "cr_wide_ln_qkv_bwd":
         own = bool(fnargs[0]._obj.g_wqkv)
         return 2.0 * M * D * (6 if own else 3) * D, (11.0 if own else 6.0) * M * D * 4, "hbm"  # dQ dK dV d_o x (+ q_in, x, dQ dK dV again) in; dx out
-    if name == "cr_stack_fwd":
+    if name in ("cr_stack_fwd", "cr_stack_fwd_head"):
+        # (cr_stack_fwd_head: + the prediction head on the last launch's rows -- row gathers and dot products, no matrix work counted)
         # per block: Q K V projections + causal attention (QK^T + PV, causal half) + the two feed-forward layers
         nb = fnargs[0]._obj.n_blocks
         return nb * (2.0 * M * D * 3 * D + 2.0 * D * T * (T + 1) * B + 2.0 * M * D * 2 * D), None, "mfma"
@@ -202,7 +203,8 @@ def kernel_profile(eng, staged, n_steps=8):
         per_launch.append(dict(idx=idx, name=n, us=float(np.mean(v)), flops=fl, bytes=by, bound=bound))
     by_name = {}
     for r in per_launch:
-        d = by_name.setdefault(r["name"], dict(us=0.0, launches=0, flops=0.0, bytes=0.0, bound=r["bound"]))
+        # (cr_stack_fwd_head = cr_stack_fwd with the prediction head riding on its last launch: one entry, the stack forward's)
+        d = by_name.setdefault("cr_stack_fwd" if r["name"] == "cr_stack_fwd_head" else r["name"], dict(us=0.0, launches=0, flops=0.0, bytes=0.0, bound=r["bound"]))
         d["us"] += r["us"]; d["launches"] += 1
         d["flops"] += r["flops"] or 0.0; d["bytes"] += r["bytes"] or 0.0
     return per_launch, by_name
@@ -214,7 +216,7 @@ KERNELS_OF = {"cr_attn_fwd": ["k_attn_fwd", "k_bf_fwd"], "cr_attn_bwd": ["k_attn
               "cr_block_ln_qkv_fwd": ["k_block_ln_qkv_fwd"], "cr_block_ln_qkv_fwd_gather": ["k_block_ln_qkv_fwd"],
               "cr_block_ln_ffn_fwd": ["k_block_ln_ffn_fwd"], "cr_block_ln_ffn_fwd_tail": ["k_block_ln_ffn_fwd"],
               "cr_block_ln_ffn_bwd": ["k_block_ln_ffn_bwd"], "cr_block_ln_qkv_bwd": ["k_block_ln_qkv_bwd"],
-              "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"],
+              "cr_block_ln_qkv_bwd_scatter": ["k_block_ln_qkv_bwd"], "cr_stack_fwd": ["k_stack_fwd"], "cr_stack_fwd_head": ["k_stack_fwd"],
               "cr_stack_ffn_bwd": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_ln": ["k_stack_ffn_bwd"], "cr_stack_ffn_bwd_heads": ["k_stack_ffn_bwd"], "cr_stack_qkv_bwd": ["k_stack_qkv_bwd"], "cr_stack_qkv_bwd_scatter": ["k_stack_qkv_bwd"], "cr_stack_block_bwd": ["k_stack_block_bwd"],
               "cr_wide_ln_qkv_fwd": ["k_wide_qkv_fwd"], "cr_wide_ln_ffn_fwd": ["k_wide_ffn_fwd"], "cr_wide_ln_ffn_bwd": ["k_wide_ffn_bwd"],
               "cr_wide_ln_qkv_bwd": ["k_wide_qkv_bwd"], "cr_gemm_rows": ["k_gemm_rows"], "cr_gemm_wgrad": ["k_gemm_wgrad"]}

@@ -145,6 +145,34 @@ __device__ __forceinline__ float cr_ln_bwd_tail(float dg, float c1, float xhat, 
     return t;
 }
 
+// After a workgroup's partial sums are in state[0..2]: take a ticket; the LAST workgroup of the grid copies the now
+// complete sums and the step counter to state[8..11] (castrec.h, state block) and re-arms the ticket.
+// Ordering without __threadfence(): an agent-scope release fence writes the XCD's whole dirty L2 back (this kernel has
+// just produced megabytes of gradients: measured +44 us per step).  Only the three float atomics have to be ordered
+// before the ticket, they are device-scope atomics (performed at the memory side, not in the L2), and they are issued by
+// the same wave as the ticket: waiting for their acknowledgement (vmcnt) is enough.  The last workgroup reads the
+// totals back with atomics as well.
+// `flag`: an LDS word of the caller's
+__device__ __forceinline__ void head_snapshot_at(float* state, unsigned total_workgroups, int* flag) {
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            unsigned* ticket = reinterpret_cast<unsigned*>(state + 12);
+            *flag = (atomicAdd(ticket, 1u) == total_workgroups - 1u) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (threadIdx.x < 3) state[8 + threadIdx.x] = atomicAdd(state + threadIdx.x, 0.0f);
+    if (threadIdx.x == 3) *reinterpret_cast<unsigned*>(state + 11) = *reinterpret_cast<const unsigned*>(state + 4);
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(state + 12) = 0u;
+}
+// (a kernel that declares all 160 KB of LDS dynamically has no room for this static word: head_snapshot_at)
+__device__ __forceinline__ void head_snapshot(float* state, unsigned total_workgroups) {
+    __shared__ int last;
+    head_snapshot_at(state, total_workgroups, &last);
+}
+
 static inline int cr_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised, and that

@@ -19,29 +19,7 @@ __device__ __forceinline__ float head_row_sum(float v) {
     return wave_sum(v);
 }
 
-// After a workgroup's partial sums are in state[0..2]: take a ticket; the LAST workgroup of the grid copies the now
-// complete sums and the step counter to state[8..11] (castrec.h, state block) and re-arms the ticket.
-// Ordering without __threadfence(): an agent-scope release fence writes the XCD's whole dirty L2 back (this kernel has
-// just produced megabytes of gradients: measured +44 us per step).  Only the three float atomics have to be ordered
-// before the ticket, they are device-scope atomics (performed at the memory side, not in the L2), and they are issued by
-// the same wave as the ticket: waiting for their acknowledgement (vmcnt) is enough.  The last workgroup reads the
-// totals back with atomics as well.
-__device__ __forceinline__ void head_snapshot(float* state) {
-    __shared__ int last;
-    if (threadIdx.x < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) {
-            unsigned* ticket = reinterpret_cast<unsigned*>(state + 12);
-            last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    if (!last) return;
-    if (threadIdx.x < 3) state[8 + threadIdx.x] = atomicAdd(state + threadIdx.x, 0.0f);
-    if (threadIdx.x == 3) *reinterpret_cast<unsigned*>(state + 11) = *reinterpret_cast<const unsigned*>(state + 4);
-    if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(state + 12) = 0u;
-}
-
+// (head_snapshot: cr_common.hpp)
 template <int LPR, int MAXC>
 __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
     constexpr int RPW = 64 / LPR;
@@ -125,7 +103,7 @@ __global__ __launch_bounds__(256) void k_head(cr_head_desc d) {
         for (int i = 0; i < 4 * RPW; ++i) v += red[threadIdx.x][i];
         if (v != 0.0f) atomicAdd(d.state + threadIdx.x, v);
     }
-    head_snapshot(d.state);
+    head_snapshot(d.state, gridDim.x);
 }
 
 extern "C" int cr_head_fwd_bwd(const cr_head_desc* d, void* stream) {
@@ -333,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_head_ln(cr_head_desc d, cr_ln_bwd_desc
             __syncthreads();
         }
     }
-    head_snapshot(d.state);
+    head_snapshot(d.state, gridDim.x);
 }
 
 // The same kernel with VECTOR row accesses (round 5): a lane owns VEC consecutive columns (16- or 8-byte loads: D a multiple of 4,
@@ -497,7 +475,7 @@ __global__ __launch_bounds__(1024) void k_head_ln_v(cr_head_desc d, cr_ln_bwd_de
         n.dgamma[(size_t)blockIdx.x * n.slab_stride + c] = g;
         n.dbeta[(size_t)blockIdx.x * n.slab_stride + c] = b;
     }
-    head_snapshot(d.state);
+    head_snapshot(d.state, gridDim.x);
 }
 
 extern "C" int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream) {

@@ -37,6 +37,10 @@ struct StackArgs {
     int gather;                   // blk[0].bd.x is composed here from the embedding recipe `e` (and written: the backward reads it)
     cr_embed_desc e;
     StackBlk blk[CR_STACK_MAX_BLOCKS];
+    // HEAD instantiations (round 5): the prediction head (sasrec.py:87-115) and the backward of the final LayerNorm on the rows this
+    // launch has just normalised -- cr_head_fwd_bwd_ln's work without its launch; hd.seq_emb / hl.x are not read (registers hold them)
+    cr_head_desc hd;
+    cr_ln_bwd_desc hl;
 };
 
 #ifdef CR_TIMELINE
@@ -50,7 +54,16 @@ struct StackArgs {
 #define SK_TS(slot) do { } while (0)
 #endif
 
-#include "cr_rlayout.hpp"
+#include "cr_rbwd.hpp"
+
+// The argument block re-read through a pointer the optimiser cannot trace back to the kernel's parameter: what the head tail needs of
+// it (a dozen pointers, some first used under lane predicates) is then fetched from the scalar cache where it is used instead of being
+// copied to vector registers at the kernel's top and carried -- spilled -- across the attention phase (cr_stack_bwd1.hip b1_args_again).
+__device__ __forceinline__ const StackArgs& stack_args_again() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const StackArgs*>((const void*)p);
+}
 
 // the block's zero-padded vectors (and the final LayerNorm's): ST_NVEC x 64 slots over the workgroup
 template <int NT>
@@ -85,12 +98,17 @@ __device__ __forceinline__ void vec_put(float* vec, const float (&vv)[(ST_NVEC *
 // tile of the heaviest-first order through phase B / C.  Block i + 1 needs y of both, hence one launch per block.
 // HD: heads (1, or 2 with head dim 32: head h is then exactly k-step h of the score product and column tiles 2h, 2h + 1 of
 // the output -- config C3: D = 64, two heads)
-template <int NKT, bool SPLIT, int NW, int DS, bool PAIR, int HD>
+// HEAD: the last block's launch goes on with the prediction head on its own output rows (cr_stack_fwd_head; PAIR launches only: one
+// tile per wave, so the LayerNorm-gradient partials need no registers across an attention phase).  The separate head launch cost
+// 14.5 us of a 324 us step (rocprofv3) for 25 600 rows of ~1 KB: its ids -> table rows -> reductions chain is short work behind a
+// kernel boundary and a cold start; here the ids and the two table rows of a tile are requested while the tile's feed-forward runs.
+template <int NKT, bool SPLIT, int NW, int DS, bool PAIR, int HD, bool HEAD = false>
 __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
+    static_assert(!HEAD || PAIR, "the head tail: PAIR launches");
     constexpr int NT = 64 * NW;
     constexpr int NVV = (ST_NVEC * 64 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cr_kernarg_touch<(sizeof(StackArgs) < 1280 ? sizeof(StackArgs) : 1280)>();      // (the first blocks: one launch per block uses blk[0] only)
+    cr_kernarg_touch<HEAD ? 1280 : ((sizeof(StackArgs) - sizeof(cr_head_desc) - sizeof(cr_ln_bwd_desc)) < 1280 ? (sizeof(StackArgs) - sizeof(cr_head_desc) - sizeof(cr_ln_bwd_desc)) : 1280)>();      // (the first blocks: one launch per block uses blk[0] only)
     // (DS instantiations run with nkt == NKT: the image size is then a constant and the hi / lo / K / V / weight images are
     //  immediates apart: an operand read is one per-lane base + immediate instead of an address sum per read)
     const int IMG = DS > 0 ? 16 * NKT * 64 : a.T16 * 64;
@@ -149,11 +167,17 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         vec_issue<NT>(vv, d, a, D);
         issue_x(d.x, max(tile_a(0), 0), gid0, a.gather != 0);
     }
+    // HEAD: the final LayerNorm's dgamma / dbeta partials of the waves, [2][NW][64] floats of their own behind the key bias (nothing else
+    // of the LDS is free before every wave has left its feed-forward: 159 296 + 4 192 of 163 840 bytes at 13 tiles)
+    float* hpart = kb + 16 * NKT;
+    // (HEAD launches hold ONE block -- PAIR launches do -- as a constant: with a run-time block loop around it, everything loop-invariant of
+    //  the head tail was formed in front of the loop and carried, spilled, across the attention phase)
+    const int nblk = PAIR ? 1 : a.nb;                     // (a PAIR launch is one block: cr_stack_fwd, `per`)
 #pragma unroll 1
-    for (int b = 0; b < a.nb; ++b) {
+    for (int b = 0; b < nblk; ++b) {
         const cr_block_desc& d = a.blk[b].bd;
         const cr_attn_desc& ad = a.blk[b].ad;
-        const bool last = b == a.nb - 1;
+        const bool last = b == nblk - 1;
         // (the block's step counters: requested here, used behind barrier B2)
         const uint32_t sv_a = cr_step_request(ad.drop), sv_1 = cr_step_request(d.drop_ffn1), sv_2 = cr_step_request(d.drop_ffn2);
         {
@@ -273,6 +297,8 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             const u32 mo = (u32)m * (u32)(4 * D);
             const int id_n = ad.dead_ids ? ad.dead_ids[m] : 1;
             const int mk = d.mask_ids[m];
+            int hpid = 0, hnid = 0;                       // HEAD: the row's pos / neg ids (row 0 of the table reads as zeros)
+            if (HEAD && last) { hpid = a.hd.pos[m]; hnid = a.hd.neg[m]; }
             f32x4 o[4];
             bf8 qh[2], ql[2];
             float qvq;
@@ -435,6 +461,14 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
             }
             }   // heads
             if (i + 1 < nB) r_issue(xb, d.x, row_of(tile1), dcx);        // the next tile's x flies under the feed-forward
+            // HEAD: the two table rows are requested here, behind the attention phase (their ids at the tile's top): they fly under LN2 and
+            // the feed-forward, 38 registers that the attention phase does not have
+            RRaw hrp, hrn;
+            if (HEAD && last) {
+                const StackArgs& ah = stack_args_again();
+                r_issue(hrp, ah.hd.table, (u32)hpid * (u32)(4 * D), dcx, rok && hpid != 0);
+                r_issue(hrn, ah.hd.table, (u32)hnid * (u32)(4 * D), dcx, rok && hnid != 0);
+            }
             r_store(d.o, mo, o, rok, dcx);
             if (i == 0) SK_TS(7 + 10 * b);
             // ---- LN2 + point-wise feed-forward (modules.py:300-313), row mask (sasrec.py:83)
@@ -473,6 +507,63 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
                 r_layernorm<false>(fin, acc, vec + 9 * 64, vec + 10 * 64, dcx);
                 r_store(a.out + a.col_out, (u32)m * (u32)(4 * a.ld_out), fin, rok, dcx);
             }
+            if (HEAD && last) {
+                const StackArgs& ah = stack_args_again();
+                // ---- prediction head on the rows in registers (sasrec.py:87-115; cr_head.hip k_head_ln, same arithmetic) ----
+                f32x4 ep[4], en[4], pr[4];
+                r_finish(ep, hrp, dcx);
+                r_finish(en, hrn, dcx);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) pr[ct] = ep[ct] * fin[ct];
+                const float pl = r_rowsum(pr);                                             // sasrec.py:100
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) pr[ct] = en[ct] * fin[ct];
+                const float nl = r_rowsum(pr);                                             // sasrec.py:101
+                const float ist = (rok && hpid != 0) ? 1.0f : 0.0f;                        // sasrec.py:104
+                const float sp = 1.0f / (1.0f + expf(-pl)), sn = 1.0f / (1.0f + expf(-nl));
+                const float dpl = -ist * sp * (1.0f - sp) / (sp + 1e-24f);
+                const float dnl = ist * sn * (1.0f - sn) / (1.0f - sn + 1e-24f);
+                float h_loss = 0.0f, h_auc = 0.0f, h_n = 0.0f;
+                if (lg == 0 && rok) {
+                    h_loss = ist * (-logf(sp + 1e-24f) - logf(1.0f - sn + 1e-24f));        // sasrec.py:105-108
+                    const float dlt = pl - nl;
+                    const float sgn = (dlt > 0.0f) ? 1.0f : ((dlt < 0.0f) ? -1.0f : 0.0f);
+                    h_auc = ist * (sgn + 1.0f) * 0.5f;                                     // sasrec.py:113-115
+                    h_n = ist;
+                    if (ah.hd.pos_logits) ah.hd.pos_logits[m] = pl;
+                    if (ah.hd.neg_logits) ah.hd.neg_logits[m] = nl;
+                    if (ah.hd.coef_out) { ah.hd.coef_out[m] = dpl; ah.hd.coef_out[(size_t)ah.hd.M + m] = dnl; }
+                }
+                {                                         // the wave's three sums (one tile per wave: written, not added to)
+                    const float wl = wave_sum(h_loss), wa = wave_sum(h_auc), wn = wave_sum(h_n);
+                    float* red = hpart + 2 * NW * 64;
+                    if (ln == 0) { red[wave] = wl; red[NW + wave] = wa; red[2 * NW + wave] = wn; }
+                }
+                // the gradient row dy = dpl E[pos] + dnl E[neg] goes straight through the final LayerNorm's backward (modules.py:74-78):
+                // its input is this tile's y (acc), its gain the vector at slot 9
+                f32x4 dyh[4], dxh[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dyh[ct][r] = fmaf(dpl, ep[ct][r], dnl * en[ct][r]);     // (element by element: the vector form is a packed multiply + in-place packed fma, the chain build.py's ISA scan refuses)
+                if (ah.hd.d_seq_emb) r_store(ah.hd.d_seq_emb, (u32)m * (u32)(4 * ah.hd.ldd), dyh, rok, dcx);
+                f32x4 hag[4], hab[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) { hag[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; hab[ct] = hag[ct]; }
+                r_ln_bwd(dxh, acc, dyh, vec + 9 * 64, hag, hab, dcx);
+                r_store(ah.hl.dx, (u32)m * (u32)(4 * ah.hl.lddx), dxh, rok, dcx);
+                // the tile's 16 rows folded per column (DPP row sums), into this wave's slot (one tile per wave: written, not added to)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sg = cr_row16_sum(hag[ct][r]), sb = cr_row16_sum(hab[ct][r]);
+                        if (li == 0) {
+                            hpart[wave * 64 + 16 * ct + 4 * lg + r] = sg;
+                            hpart[(NW + wave) * 64 + 16 * ct + 4 * lg + r] = sb;
+                        }
+                    }
+            }
         }
         SK_TS(10 + 10 * b);
         if (!last) {                                      // the next block's Wk Wv, vectors and first tile (= this block's y)
@@ -483,14 +574,43 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
         }
         if (!last) __syncthreads();                       // B3: images, weights and vectors are rewritten by the next block
     }
+    if (HEAD) {
+        const StackArgs& ah = stack_args_again();
+        // dgamma / dbeta of the final LayerNorm: the waves' partials in a fixed order -> this workgroup's slab; the workgroup's loss sums;
+        // and the ticket that lets the LAST workgroup of the grid snapshot the step's sums (cr_common.hpp head_snapshot)
+        float* red = hpart + 2 * NW * 64;                 // [3][NW]
+        if (nB == 0) {                                    // a wave without a tile: its slots read as zeros
+            hpart[wave * 64 + (threadIdx.x & 63)] = 0.0f;
+            hpart[(NW + wave) * 64 + (threadIdx.x & 63)] = 0.0f;
+            if ((threadIdx.x & 63) == 0) { red[wave] = 0.0f; red[NW + wave] = 0.0f; red[2 * NW + wave] = 0.0f; }
+        }
+        __syncthreads();
+        const unsigned slab = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((int)threadIdx.x < D) {
+            float g = 0.0f, bsum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { g += hpart[w * 64 + threadIdx.x]; bsum += hpart[(NW + w) * 64 + threadIdx.x]; }
+            ah.hl.dgamma[(size_t)slab * ah.hl.slab_stride + threadIdx.x] = g;
+            ah.hl.dbeta[(size_t)slab * ah.hl.slab_stride + threadIdx.x] = bsum;
+        }
+        if (threadIdx.x < 3) {
+            float v = 0.0f;
+            for (int w = 0; w < NW; ++w) v += red[NW * threadIdx.x + w];
+            if (v != 0.0f) atomicAdd(ah.hd.state + threadIdx.x, v);
+        }
+        head_snapshot_at(ah.hd.state, gridDim.x * gridDim.y, reinterpret_cast<int*>(red + 3 * NW));
+    }
     SK_TS(63);
 }
 
 // =====================================================================================================
 // host side
 // =====================================================================================================
-static size_t stack_lds_bytes(int T16, bool split) {
-    return (size_t)T16 * 64 * 2 * (split ? 4 : 2) + (size_t)3 * ST_WIMG * 2 * (split ? 2 : 1) + (size_t)ST_NVEC * 64 * 4 + (size_t)T16 * 4;
+static size_t stack_lds_bytes(int T16, bool split, bool head = false, int nkt_template = 0) {
+    // (HEAD: the key bias is addressed as [16 NKT] -- the instantiation's tile count -- so that the partials behind it have a constant offset)
+    const size_t kb = head ? (size_t)16 * nkt_template * 4 : (size_t)T16 * 4;
+    return (size_t)T16 * 64 * 2 * (split ? 4 : 2) + (size_t)3 * ST_WIMG * 2 * (split ? 2 : 1) + (size_t)ST_NVEC * 64 * 4 + kb
+           + (head ? (size_t)(2 * ST_WAVES * 64 + 3 * ST_WAVES + 4) * 4 : 0);
 }
 
 static const char* stack_unsupported(const cr_stack_desc* s) {
@@ -532,48 +652,97 @@ static const char* stack_unsupported(const cr_stack_desc* s) {
 
 extern "C" int cr_stack_fwd_supported(const cr_stack_desc* s) { return stack_unsupported(s) == nullptr; }
 
-template <int NKT, bool SPLIT, int DS, bool PAIR, int HD>
+template <int NKT, bool SPLIT, int DS, bool PAIR, int HD, bool HEAD = false>
 static int launch_stack_d(const StackArgs& a, int B, hipStream_t s) {
     static cr_devmask attr_set = 0;
-    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD>), &attr_set);
+    int rc = cr_raise_lds_limit(reinterpret_cast<const void*>(&k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD, HEAD>), &attr_set);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD>), dim3(B, PAIR ? 2 : 1), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT), s, a);
-    return cr_check_launch("cr_stack_fwd");
+    hipLaunchKernelGGL((k_stack_fwd<NKT, SPLIT, ST_WAVES, DS, PAIR, HD, HEAD>), dim3(B, PAIR ? 2 : 1), dim3(ST_THREADS), stack_lds_bytes(a.T16, SPLIT, HEAD, NKT), s, a);
+    return cr_check_launch(HEAD ? "cr_stack_fwd_head" : "cr_stack_fwd");
 }
+// head: the launch also runs the prediction head (PAIR launches only; see k_stack_fwd's HEAD)
 template <int NKT, bool SPLIT>
-static int launch_stack(const StackArgs& a, int B, bool pair, hipStream_t s) {
+static int launch_stack(const StackArgs& a, int B, bool pair, bool head, hipStream_t s) {
     constexpr int DS = (NKT == 4 || NKT == 13) ? 50 : 0;                 // the headline hidden size as a constant
     if constexpr (NKT <= 13) {
-        if (a.blk[0].ad.H == 2) return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
+        if (a.blk[0].ad.H == 2) {
+            if (head) return launch_stack_d<NKT, SPLIT, 0, true, 2, true>(a, B, s);
+            return pair ? launch_stack_d<NKT, SPLIT, 0, true, 2>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 2>(a, B, s);
+        }
     }
-    if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) return pair ? launch_stack_d<NKT, SPLIT, DS, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false, 1>(a, B, s);
+    if (DS && a.blk[0].bd.D == DS && a.nkt == NKT) {
+        if (head) return launch_stack_d<NKT, SPLIT, DS, true, 1, true>(a, B, s);
+        return pair ? launch_stack_d<NKT, SPLIT, DS, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DS, false, 1>(a, B, s);
+    }
     if constexpr (NKT == 13 && SPLIT) {
         // 13 tiles, split arithmetic, another hidden size (the headline's length at --hidden_units 20 / 36 / 44 / 60 ...): the instantiation of
         // the size's FAMILY (whole 16-column tiles as a constant, cr_rlayout.hpp d_ctx<NF>) -- the fully generic one spilled 24-128 bytes per lane
+#define ST_FAMILY(DSF)                                                                                                  \
+    do {                                                                                                                \
+        if (head) return launch_stack_d<NKT, SPLIT, DSF, true, 1, true>(a, B, s);                                       \
+        return pair ? launch_stack_d<NKT, SPLIT, DSF, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, DSF, false, 1>(a, B, s); \
+    } while (0)
         switch (a.blk[0].bd.D / 16) {
-        case 0: return pair ? launch_stack_d<NKT, SPLIT, -1, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -1, false, 1>(a, B, s);
-        case 1: return pair ? launch_stack_d<NKT, SPLIT, -2, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -2, false, 1>(a, B, s);
-        case 2: return pair ? launch_stack_d<NKT, SPLIT, -3, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -3, false, 1>(a, B, s);
-        default: return pair ? launch_stack_d<NKT, SPLIT, -4, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, -4, false, 1>(a, B, s);
+        case 0: ST_FAMILY(-1);
+        case 1: ST_FAMILY(-2);
+        case 2: ST_FAMILY(-3);
+        default: ST_FAMILY(-4);
         }
+#undef ST_FAMILY
     } else {
+        if constexpr (NKT <= 13) {
+            if (head) return launch_stack_d<NKT, SPLIT, 0, true, 1, true>(a, B, s);
+        }
         return pair ? launch_stack_d<NKT, SPLIT, 0, true, 1>(a, B, s) : launch_stack_d<NKT, SPLIT, 0, false, 1>(a, B, s);
     }
 }
-static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, hipStream_t st) {
-    if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, st) : launch_stack<4, false>(a, B, pair, st);
-    if (a.nkt <= 8) return split ? launch_stack<8, true>(a, B, pair, st) : launch_stack<8, false>(a, B, pair, st);
-    if (a.nkt <= 13) return split ? launch_stack<13, true>(a, B, pair, st) : launch_stack<13, false>(a, B, pair, st);
-    return launch_stack<16, false>(a, B, pair, st);       // (stack_unsupported: plain bf16, one head)
+static int launch_stack_any(const StackArgs& a, int B, bool split, bool pair, bool head, hipStream_t st) {
+    if (a.nkt <= 4) return split ? launch_stack<4, true>(a, B, pair, head, st) : launch_stack<4, false>(a, B, pair, head, st);
+    if (a.nkt <= 8) return split ? launch_stack<8, true>(a, B, pair, head, st) : launch_stack<8, false>(a, B, pair, head, st);
+    if (a.nkt <= 13) return split ? launch_stack<13, true>(a, B, pair, head, st) : launch_stack<13, false>(a, B, pair, head, st);
+    return launch_stack<16, false>(a, B, pair, false, st);       // (stack_unsupported: plain bf16, one head; no head tail at 16 tiles)
 }
 
 // batches up to this size run two workgroups per sequence, one launch per block (256 CUs, one workgroup each)
 static const int g_stack_pair_max_b = getenv("CASTREC_STACK_PAIR_MAX_B") ? atoi(getenv("CASTREC_STACK_PAIR_MAX_B")) : 160;
 
-extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
+static bool stack_pair_mode(const cr_stack_desc* s) {
+    const cr_attn_desc& a0 = s->attn[0];
+    return a0.B <= g_stack_pair_max_b && (a0.T + 15) / 16 >= 2;
+}
+
+// why the prediction head cannot ride on the stack's last launch (nullptr: it can)
+static const char* stack_head_unsupported(const cr_stack_desc* s, const cr_head_desc* h, const cr_ln_bwd_desc* n) {
     const char* why = stack_unsupported(s);
-    CR_REQUIRE(why == nullptr, "cr_stack_fwd: unsupported (%s)", why ? why : "");
+    if (why) return why;
+    if (!h || !n) return "NULL head / LayerNorm description";
+    const cr_block_desc& bl = s->blocks[s->n_blocks - 1];
+    const cr_attn_desc& a0 = s->attn[0];
+    if (!stack_pair_mode(s)) return "two workgroups per sequence only (B <= 160, more than one tile)";
+    if ((a0.T + 15) / 16 > 13) return "at most 13 tiles";
+    if (!s->out || s->col_out != 0) return "the stack must end in its final LayerNorm, written dense";
+    if (h->seq_emb != s->out || h->ld != s->ld_out || h->M != bl.M || h->D != bl.D || !h->table || !h->pos || !h->neg || !h->state) return "head description";
+    if (h->table_grad) return "no table scatter here (cr_head_desc.coef_out: the occurrence index)";
+    if ((size_t)h->V * h->D * 4 >= ((size_t)1 << 32)) return "item table of 4 GiB or more (32-bit row offsets)";
+    if (n->x != bl.y || n->ldx != bl.D || n->gamma != s->lnf_gamma || !n->dx || n->lddx != bl.D || !n->dgamma || !n->dbeta || n->accumulate || n->M != bl.M || n->D != bl.D)
+        return "LayerNorm description (x = the last block's y, gamma = the final LayerNorm's)";
+    if (n->n_slabs < 2 * a0.B) return "two slabs per sequence (n_slabs >= 2 B)";
+    if (h->d_seq_emb && h->ldd < bl.D) return "d_seq_emb";
+    const int T16 = (a0.T + 15) / 16 * 16;
+    const int nktt = T16 / 16 <= 4 ? 4 : (T16 / 16 <= 8 ? 8 : 13);
+    if (stack_lds_bytes(T16, a0.precision == CR_PREC_BF16X3, true, nktt) > 160 * 1024) return "no LDS left for the head's partials";
+    return nullptr;
+}
+extern "C" int cr_stack_fwd_head_supported(const cr_stack_desc* s, const cr_head_desc* h, const cr_ln_bwd_desc* n) {
+    return stack_head_unsupported(s, h, n) == nullptr;
+}
+
+static int stack_fwd_impl(const cr_stack_desc* s, const cr_head_desc* h, const cr_ln_bwd_desc* n, void* stream) {
+    const char* why = h ? stack_head_unsupported(s, h, n) : stack_unsupported(s);
+    CR_REQUIRE(why == nullptr, "%s: unsupported (%s)", h ? "cr_stack_fwd_head" : "cr_stack_fwd", why ? why : "");
     StackArgs a;
+    memset(&a.hd, 0, sizeof(a.hd));
+    memset(&a.hl, 0, sizeof(a.hl));
     const cr_attn_desc& a0 = s->attn[0];
     a.T16 = (a0.T + 15) / 16 * 16;
     a.nkt = a.T16 / 16;
@@ -582,7 +751,7 @@ extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
     a.ts = g_attn_ts_which == 7 ? g_attn_ts : nullptr;
     a.ld_out = s->ld_out; a.col_out = s->col_out;
     const bool split = a0.precision == CR_PREC_BF16X3;
-    const bool pair = a0.B <= g_stack_pair_max_b && a.nkt >= 2;
+    const bool pair = stack_pair_mode(s);
     hipStream_t st = cr_stream(stream);
     const int per = pair ? 1 : s->n_blocks;               // blocks per launch
     memset(&a.e, 0, sizeof(a.e));
@@ -598,8 +767,17 @@ extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) {
             a.blk[i].bd = s->blocks[j];
             a.blk[i].ad = s->attn[j];
         }
-        int rc = launch_stack_any(a, a0.B, split, pair, st);
+        const bool head = h != nullptr && i0 + per >= s->n_blocks;      // the head rides on the LAST launch
+        if (head) { a.hd = *h; a.hl = *n; }
+        int rc = launch_stack_any(a, a0.B, split, pair, head, st);
         if (rc) return rc;
     }
     return CR_OK;
+}
+
+extern "C" int cr_stack_fwd(const cr_stack_desc* s, void* stream) { return stack_fwd_impl(s, nullptr, nullptr, stream); }
+
+extern "C" int cr_stack_fwd_head(const cr_stack_desc* s, const cr_head_desc* h, const cr_ln_bwd_desc* n, void* stream) {
+    CR_REQUIRE(h && n, "cr_stack_fwd_head: NULL head / LayerNorm description");
+    return stack_fwd_impl(s, h, n, stream);
 }

@@ -238,6 +238,11 @@ class Engine:
                 items = batch_size * (2 if self.T > 112 else 1)
                 if n_slabs < items <= 512:
                     n_slabs = items
+                # the prediction head as the tail of the trunk's last forward launch (cr_stack_fwd_head): its two workgroups per sequence
+                # write a slab each of the final LayerNorm's gradient
+                if (training and self.T > 16 and batch_size <= 160 and n_slabs < 2 * batch_size <= 512
+                        and os.environ.get("CASTREC_NO_HEAD_FUSION") != "1"):
+                    n_slabs = 2 * batch_size
         self.n_slabs = n_slabs
         # cr_gemm_wgrad reduces over rows in n_wslabs workgroups per output tile: at the large hidden sizes of the unfused / wide
         # path (D x D weights, 4 blocks) a slab per 128 rows is 264 MB written and read again per step (config C4); 32 suffice
@@ -981,6 +986,16 @@ class Engine:
                            None if self.use_index else self._gptr("item_emb"), None, None, self._head_coef())
             n = L.LnBwdDesc(x.data_ptr(), D, self._pptr(pname + ".gamma"), None, 0, dx.data_ptr(), D, 0,
                             self._gptr(pname + ".gamma"), self._gptr(pname + ".beta"), self.Gs.shape[1], self.n_slabs, M, D, 1e-8)
+            # the head as the tail of the stack's last forward launch (cr_stack_fwd_head): no launch of its own.  Needs the occurrence
+            # index (nothing is scattered from there) and the launch form with two workgroups per sequence.
+            last = self.fwd[-1] if self.fwd else None
+            if (self.use_index and last is not None and last[0] == "cr_stack_fwd" and os.environ.get("CASTREC_NO_HEAD_FUSION") != "1"
+                    and last[2][0]._obj.out == seq_emb.data_ptr()
+                    and L.lib.cr_stack_fwd_head_supported(last[2][0], C.byref(d), C.byref(n))):
+                self._keep += [d, n]
+                self.fwd[-1] = ("cr_stack_fwd_head", L.lib.cr_stack_fwd_head, (last[2][0], C.byref(d), C.byref(n)))
+                self._block_slab_range(pname + ".gamma", pname + ".beta", 2 * self.B)      # workgroup (sequence, half) writes slab half * B + sequence
+                return
             self._call(self.fwd, "cr_head_fwd_bwd_ln", C.byref(d), C.byref(n))
             return
         ds = self._grad_of(seq_emb)
@@ -1524,7 +1539,7 @@ class Engine:
         n = 0
         pair_max = int(os.environ.get("CASTREC_STACK_PAIR_MAX_B", 160))
         for name, _, args in self.fwd + self.bwd:
-            if name == "cr_stack_fwd":
+            if name in ("cr_stack_fwd", "cr_stack_fwd_head"):
                 sd = args[0]._obj
                 n += sd.n_blocks if (self.B <= pair_max and self.T > 16) else 1
             elif name == "cr_stack_block_bwd":

@@ -187,6 +187,8 @@ _sig("cr_wide_ln_ffn_bwd", c_i, [C.POINTER(BlockBwdDesc), c_p, c_p, c_i, c_i, c_
 _sig("cr_wide_ln_qkv_bwd", c_i, [C.POINTER(BlockBwdDesc), c_i, c_p])
 _sig("cr_head_fwd_bwd", c_i, [C.POINTER(HeadDesc), c_p])
 _sig("cr_head_fwd_bwd_ln", c_i, [C.POINTER(HeadDesc), C.POINTER(LnBwdDesc), c_p])
+_sig("cr_stack_fwd_head_supported", c_i, [C.POINTER(StackDesc), C.POINTER(HeadDesc), C.POINTER(LnBwdDesc)])
+_sig("cr_stack_fwd_head", c_i, [C.POINTER(StackDesc), C.POINTER(HeadDesc), C.POINTER(LnBwdDesc), c_p])
 _sig("cr_test_logits", c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 _sig("cr_adam_step", c_i, [C.POINTER(AdamDesc), c_p])
 _sig("cr_reduce_slabs", c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p])
@@ -211,7 +213,7 @@ EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_ids_ring_next", "
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
            "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_rows_pack", "cr_rows_add", "cr_block_ln_qkv_bwd_scatter",
            "cr_wide_supported", "cr_wide_ln_qkv_fwd", "cr_wide_ln_ffn_fwd", "cr_wide_ln_ffn_fwd_tail", "cr_wide_ln_ffn_bwd", "cr_wide_ln_qkv_bwd",
-           "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
+           "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_stack_fwd_head_supported", "cr_stack_fwd_head", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy",
            "cr_tgrad_geometry", "cr_batch_index_layout", "cr_index_builder_create", "cr_index_build", "cr_index_builder_destroy", "cr_table_grad"]
 

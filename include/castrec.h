@@ -417,6 +417,16 @@ int cr_head_fwd_bwd(const cr_head_desc* d, void* stream);
  * cr_head_fwd_bwd followed by cr_layernorm_bwd. */
 int cr_head_fwd_bwd_ln(const cr_head_desc* d, const cr_ln_bwd_desc* n, void* stream);
 
+/* cr_stack_fwd followed by cr_head_fwd_bwd_ln(h, n) WITHOUT the second launch (round 5): the stack's last launch goes on with the
+ * prediction head (sasrec.py:87-115) and the final LayerNorm's backward on the rows it has just normalised -- 14.5 us of the headline's
+ * 324 us step were that launch.  `h`, `n`: the cr_head_fwd_bwd_ln call as it would have followed (h->seq_emb == d->out, n->x == the last
+ * block's y, n->gamma == d->lnf_gamma); h->table_grad must be NULL (no scatter from here: h->coef_out and the occurrence index).
+ * Requirements (cr_stack_fwd_head_supported) beyond cr_stack_fwd's: batches that run two workgroups per sequence (B <= 160, T > 16), at
+ * most 13 tiles, n->n_slabs >= 2 B: workgroup (sequence x, half y) WRITES slab y B + x of n->dgamma / n->dbeta; slabs >= 2 B are not
+ * written (cr_adam_desc.slab_counts).  Same results as the two calls. */
+int cr_stack_fwd_head_supported(const cr_stack_desc* d, const cr_head_desc* h, const cr_ln_bwd_desc* n);   /* 1 / 0 */
+int cr_stack_fwd_head(const cr_stack_desc* d, const cr_head_desc* h, const cr_ln_bwd_desc* n, void* stream);
+
 /* test_logits (sasrec.py:93-97): logits[b, j] = seq_emb[b*T + T-1, :] . table'[cand[b, j], :] */
 int cr_test_logits(const float* seq_emb, int ld, const float* table, const int32_t* cand,
                    int B, int T, int D, int V, int n_cand, float* logits, void* stream);
