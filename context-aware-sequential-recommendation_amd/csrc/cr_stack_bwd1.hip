@@ -47,6 +47,15 @@
 #define B1_ROWS 224                       // rows of an attention image (14 tiles of 16)
 #define B1_FSTR (B1_ROWS * 64)            // bf16 elements of one image half
 
+// The kernel's hidden-size parameter DS also carries, for the headline shape, the number of 16-row tiles as a CONSTANT: DS = D | nkt << 8
+// (0 < D < 256).  Round counts, tile bounds and the guards of the unrolled weight-gradient products then fold, as the column-tile
+// classification does with D.  DS < 0: the families of cr_rlayout.hpp d_ctx<NF>; 0: everything at run time.
+#define DS_EXACT(DS) ((DS) > 0 ? ((DS) & 255) : (DS))
+#define DS_D(DS, run) ((DS) > 0 ? ((DS) & 255) : (run))
+#define B1_NKT(DS, a) ((DS) > 255 ? ((DS) >> 8) : (a).nkt)
+#undef D_NF
+#define D_NF(DS) ((DS) > 0 ? ((DS) & 255) / 16 : ((DS) < 0 ? -(DS) - 1 : -1))
+
 struct B1Args {
     cr_block_bwd_desc bd;
     cr_attn_desc ad;
@@ -204,8 +213,8 @@ struct B1Acc { f32x4 aw1[2], aw2[2], aw1b[2], aw2b[2], ag[4], ab[4], agF[4], abF
 // gradients (the phase-2 staging's loads go out there: their latency passes under the products)
 template <bool SPLIT, int DS, bool QSIDE, int HD, class F>
 __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, int n, B1Acc& A, B1Steps& steps, F&& before_last_products) {
-    constexpr bool BIAS = DS == 64;
-    constexpr bool LATE_Q = !QSIDE && (HD == 2 || DS > 50 || DS <= 0);       // key side: the tile's Q rows are requested late (registers)
+    constexpr bool BIAS = DS_EXACT(DS) == 64;
+    constexpr bool LATE_Q = !QSIDE && (HD == 2 || DS_EXACT(DS) > 50 || DS <= 0);       // key side: the tile's Q rows are requested late (registers)
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& d = bd.f;
@@ -214,7 +223,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
     float* gam = fl + L::GAM; float* gamF = fl + L::GAMF; float* part = fl + L::PART; float* partF = fl + L::PARTF; float* sdel = fl + L::SDEL;
     constexpr int WST = L::WST, IST = L::IST;
-    const int D = DS > 0 ? DS : d.D, T = a.T;
+    const int D = DS_D(DS, d.D), T = a.T;
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the step counters: requested first of all, used behind the barrier that opens the phase
@@ -237,7 +246,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     };
     // the rows of a tile in two halves: what the chain opens with (dy, dy2, y, hid), and what its end needs (f_in / Q, o, q_in)
     auto issue_a = [&](int rd) {
-        if (rd * SB_TPR < a.nkt && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+        if (rd * SB_TPR < B1_NKT(DS, a) && wave < min(SB_TPR, B1_NKT(DS, a) - rd * SB_TPR)) {
             int m; bool rok;
             tile_rows(rd, m, rok);
             const u32 mo = (u32)m * (u32)(4 * D);
@@ -253,7 +262,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         }
     };
     auto issue_b = [&](int rd) {
-        if (rd * SB_TPR < a.nkt && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+        if (rd * SB_TPR < B1_NKT(DS, a) && wave < min(SB_TPR, B1_NKT(DS, a) - rd * SB_TPR)) {
             int m; bool rok;
             tile_rows(rd, m, rok);
             const u32 mo = (u32)m * (u32)(4 * D);
@@ -263,7 +272,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         }
     };
     auto issue = [&](int rd) { issue_a(rd); issue_b(rd); };
-    const int R = a.nkt > SB_TPR ? 2 : 1;
+    const int R = B1_NKT(DS, a) > SB_TPR ? 2 : 1;
     {
         // (memory returns in order: the weights are requested first, or their staging would wait for the tile as well)
         WRegs<2, SB_NT> w;
@@ -279,11 +288,11 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
         w_put_perm<2, SB_NT, SPLIT>(Wi, w, D, d.w1, D, 0, d.w2, D, 0, d.w2, D, 0);
         B1_TS(12);
         if (t < 64) { gam[t] = gv; gamF[t] = gf; }
-        if (!QSIDE && (a.nkt & 1)) {
+        if (!QSIDE && (B1_NKT(DS, a) & 1)) {
             // an odd tile count: the key-owner pass reads the absent second tile of the last pair (with zero coefficients):
             // its rows must hold finite values (16 rows x 128 bytes per image half, 16 bytes per thread)
             const int im = t >> 7, o16 = t & 127;
-            if (im < L::NIMG) *reinterpret_cast<float4*>(smem + (size_t)im * L::LOB + (size_t)(16 * a.nkt) * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (im < L::NIMG) *reinterpret_cast<float4*>(smem + (size_t)im * L::LOB + (size_t)(16 * B1_NKT(DS, a)) * 128 + 16 * o16) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
@@ -293,7 +302,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     const DropCtx d2 = drop_ctx(d.drop_ffn2, steps.ffn2);
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
-        const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);          // tiles of this round (wave-uniform)
+        const int ntr = min(SB_TPR, B1_NKT(DS, a) - rd * SB_TPR);          // tiles of this round (wave-uniform)
         if (wave < ntr) {
             const int lg = lane_now() >> 4;
             int m; bool rok;
@@ -424,7 +433,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     B1_TS(28);
     before_last_products();
     if (QSIDE) {
-        const int ntr = min(SB_TPR, a.nkt - (R - 1) * SB_TPR);
+        const int ntr = min(SB_TPR, B1_NKT(DS, a) - (R - 1) * SB_TPR);
         __syncthreads();
         B1_TS(10);
         wgrad_accum<SPLIT, BIAS>(aw2, aw2b, Im, Im + SB_IMG, Im + IST, Im + IST + SB_IMG, ntr, it, jt0);
@@ -688,14 +697,14 @@ __device__ __forceinline__ void b1_stage_kv_put(B1Stage& r, unsigned char* smem,
 template <int DS>
 __device__ __forceinline__ void b1_q_stage_issue(const B1Args& a, int n, B1Stage& st, WRegs<1, SB_NT>& w) {
     const cr_block_desc& bk = a.bd.f;
-    const int D = DS > 0 ? DS : bk.D, T = a.T;
+    const int D = DS_D(DS, bk.D), T = a.T;
     w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
-    b1_stage_kv_issue(st, a, n * T, 16 * a.nkt, D, bk.M);
+    b1_stage_kv_issue(st, a, n * T, 16 * B1_NKT(DS, a), D, bk.M);
 }
 
 template <bool SPLIT, int DS, int HD>
 __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, const B1Steps& steps, B1Stage& stg, WRegs<1, SB_NT>& w) {
-    constexpr bool BIAS = DS == 64;
+    constexpr bool BIAS = DS_EXACT(DS) == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -705,7 +714,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
     float* gam = fl + L::GAM; float* part = fl + L::PART; float* sdel = fl + L::SDEL; float* kb = fl + L::KB;
     constexpr int IST = L::IST;
-    const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
+    const int D = DS_D(DS, bk.D), T = a.T, T16 = 16 * B1_NKT(DS, a);
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
@@ -769,11 +778,11 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         for (int h = 0; h < HD; ++h) st[h] = *reinterpret_cast<const f4s*>(d.row_stats + ((size_t)h * d.B * T + m_) * 4);   // [head][sequence][row]
         qv_n = d.q_valid[m_];
     };
-    if ((int)(tpk & 31u) < a.nkt) issue_tile((int)(tpk & 31u));
+    if ((int)(tpk & 31u) < B1_NKT(DS, a)) issue_tile((int)(tpk & 31u));
 #pragma unroll 1
     for (int ti = 0; ti < 2; ++ti) {
         const int qt = (int)((tpk >> (5 * ti)) & 31u);
-        if (qt >= a.nkt) break;                           // 31 = none (wave-uniform)
+        if (qt >= B1_NKT(DS, a)) break;                           // 31 = none (wave-uniform)
         if (ti == 1) B1_TS(8);
         const int q0 = 16 * qt, q = q0 + li;
         const bool rok = q < T;
@@ -938,7 +947,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         // the NEXT tile's inputs, under the LayerNorm backward and the stores.  Behind the chain's own loads, and only where a next
         // tile exists: an unconditional request in front of them (static load counts, no full drain at the first use) made single
         // columns of dx differ between runs of the same step (tools/diag_repro.py) -- not understood, not kept
-        if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));
+        if (ti == 0 && (int)((tpk >> 5) & 31u) < B1_NKT(DS, a)) issue_tile((int)((tpk >> 5) & 31u));
         r_ln_bwd(dxl, x, dqin, gam, ag, ab, dcx);
         b1_ln_fold(part + ti * (2 * SB_WAVES * 64), ag, ab);       // (the wave's first tile: PART, its second: PARTF)
         if (ar.bd.dx_accumulate) {
@@ -961,13 +970,13 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     RRaw rq0, rq1, rg0, rg1;
     const int tt0 = wave, tt1 = wave + SB_WAVES;
     const u32 mo0 = (u32)(base_row + min(16 * tt0 + li, T - 1)) * (u32)(4 * D), mo1 = (u32)(base_row + min(16 * tt1 + li, T - 1)) * (u32)(4 * D);
-    if (tt0 < a.nkt) r_issue(rq0, bk.q_in, mo0, dcx);
-    if (tt1 < a.nkt) r_issue(rq1, bk.q_in, mo1, dcx);
+    if (tt0 < B1_NKT(DS, a)) r_issue(rq0, bk.q_in, mo0, dcx);
+    if (tt1 < B1_NKT(DS, a)) r_issue(rq1, bk.q_in, mo1, dcx);
     B1_DRAIN();
     __syncthreads();                                      // every pass is done: the K / V images are dead, dQ rows are visible
     B1_TS(7);
-    if (tt0 < a.nkt) r_issue(rg0, dQg, mo0, dcx, 16 * tt0 + li < T);
-    if (tt1 < a.nkt) r_issue(rg1, dQg, mo1, dcx, 16 * tt1 + li < T);
+    if (tt0 < B1_NKT(DS, a)) r_issue(rg0, dQg, mo0, dcx, 16 * tt0 + li < T);
+    if (tt1 < B1_NKT(DS, a)) r_issue(rg1, dQg, mo1, dcx, 16 * tt1 + li < T);
     // ---- phase 3: dWq dbq from images of q_in and dQ, dgamma1 dbeta1; then the scatter of this side's partial ----
     f32x4 awq[2], nob[2];
 #pragma unroll
@@ -975,7 +984,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
     // ONE round: the images of q_in and dQ over all tiles (2 x 14 tiles x hi, lo) are exactly the image area
     __bf16* Gm = reinterpret_cast<__bf16*>(smem + L::MATB);
-    if (tt0 < a.nkt) {
+    if (tt0 < B1_NKT(DS, a)) {
         f32x4 qin[4], dQ[4];
         r_finish(qin, rq0, dcx);
         plant_one(qin, D);
@@ -983,7 +992,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
         r_finish(dQ, rg0, dcx);
         img_put<SPLIT>(Gm, Gm + B1_FSTR, 16 * tt0, dQ);
     }
-    if (tt1 < a.nkt) {
+    if (tt1 < B1_NKT(DS, a)) {
         f32x4 qin[4], dQ[4];
         r_finish(qin, rq1, dcx);
         plant_one(qin, D);
@@ -995,7 +1004,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     if (a.scatter && a.small) b1_small_issue<D_NF(DS)>(small, a, a.sbuf, n, D);
     __syncthreads();
     B1_TS(16);
-    wgrad_accum<SPLIT, BIAS, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, a.nkt, it, jt0);       // dWq (+ dbq) += q_in^T dQ (nob: the bias sums at D = 64)
+    wgrad_accum<SPLIT, BIAS, 2 * SB_TPR>(awq, nob, Im, Im + B1_FSTR, Gm, Gm + B1_FSTR, B1_NKT(DS, a), it, jt0);       // dWq (+ dbq) += q_in^T dQ (nob: the bias sums at D = 64)
     B1_TS(17);
     const size_t so = (size_t)blockIdx.x * bd.slab_stride;
     b1_wstore<BIAS>(bd.g_wqkv + so, 3 * D, bd.g_bqkv + so, awq, nob, D, it, jt0, add);
@@ -1012,7 +1021,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
 // =====================================================================================================
 template <bool SPLIT, int DS, int HD>
 __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, int n, bool add, B1Acc& A, const B1Steps& steps) {
-    constexpr bool BIAS = DS == 64;
+    constexpr bool BIAS = DS_EXACT(DS) == 64;
     typedef B1Lds<SPLIT> L;
     const cr_block_bwd_desc& bd = a.bd;
     const cr_block_desc& bk = bd.f;
@@ -1023,7 +1032,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     float* sdel = fl + L::SDEL; float* smx = fl + L::SMX; float* suni = fl + L::SUNI; float* sqv = fl + L::SQV;
     float* tile_flag = fl + L::TFLAG;
     constexpr int WST = L::WST, IST = L::IST;
-    const int D = DS > 0 ? DS : bk.D, T = a.T, T16 = 16 * a.nkt;
+    const int D = DS_D(DS, bk.D), T = a.T, T16 = 16 * B1_NKT(DS, a);
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
@@ -1057,7 +1066,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         // normal row: suni = 0; uniform row: suni = 1/T; dead row: neither (smx = 1e30 wherever the row is not normal)
         const float flag = t < T ? st[0].z : 2.0f;          // (normal / uniform / dead is the same in every head: the masks are)
         const bool normal = flag == 0.0f;
-        if (t < T16 + ((a.nkt & 1) ? 16 : 0)) {             // (an odd tile count: the absent tile of the last pair reads as dead rows)
+        if (t < T16 + ((B1_NKT(DS, a) & 1) ? 16 : 0)) {             // (an odd tile count: the absent tile of the last pair reads as dead rows)
 #pragma unroll
             for (int h = 0; h < HD; ++h) {
                 smx[h * B1_ROWS + t] = normal ? st[h].x - __log2f(st[h].y) : 1e30f;      // 1 / sum inside the exponent: P = exp2(s c - m')
@@ -1078,7 +1087,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
                 tile_flag[t >> 4] = anyu ? 2.0f : (anyn ? 1.0f : 0.0f);
             }
         }
-        if (t == 0 && (a.nkt & 1)) tile_flag[a.nkt] = 0.0f;
+        if (t == 0 && (B1_NKT(DS, a) & 1)) tile_flag[B1_NKT(DS, a)] = 0.0f;
     }
     __syncthreads();
     B1_TS(3);
@@ -1087,7 +1096,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     unsigned live_m, uni_m;
     {
         const float tf = tile_flag[lane & 15];
-        const unsigned nm = (1u << a.nkt) - 1u;
+        const unsigned nm = (1u << B1_NKT(DS, a)) - 1u;
         live_m = (unsigned)__ballot(lane < 16 && tf != 0.0f) & nm;
         uni_m = (unsigned)__ballot(lane < 16 && tf == 2.0f) & nm;
     }
@@ -1114,11 +1123,11 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
         gfrag_issue<2>(vn, d.V, d.ld, base_row + 16 * kt_, 0, T - 16 * kt_, D, M);
         kvn = d.k_valid[base_row + min(16 * kt_ + (lane_now() & 15), T - 1)];
     };
-    if ((int)(tpk & 31u) < a.nkt) issue_tile((int)(tpk & 31u));
+    if ((int)(tpk & 31u) < B1_NKT(DS, a)) issue_tile((int)(tpk & 31u));
 #pragma unroll 1
     for (int ti = 0; ti < 2; ++ti) {
         const int kt = (int)((tpk >> (5 * ti)) & 31u);
-        if (kt >= a.nkt) break;
+        if (kt >= B1_NKT(DS, a)) break;
         if (ti == 1) B1_TS(8);
         const int key0 = 16 * kt, key = key0 + li;
         const bool rok = key < T;
@@ -1138,7 +1147,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
             dk[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dv[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const int ntile = a.nkt;
+        const int ntile = B1_NKT(DS, a);
         // x = idx * PHI + key of attention_weights[n, 4 lg, key]: a query tile adds 16 T PHI, a row T PHI (scalars)
         const uint32_t xbase = (drop_base + (uint32_t)(4 * lg) * (uint32_t)T) * CR_PHI + dc.key;
         const uint32_t xT = (uint32_t)T * CR_PHI;
@@ -1290,7 +1299,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) dk[jt] *= a.isd;                                   // dS / sqrt(d), once per output element
         if (ti == 0) B1_TS(6);
-        if (ti == 0 && (int)((tpk >> 5) & 31u) < a.nkt) issue_tile((int)((tpk >> 5) & 31u));   // the next tile's K / V rows, under this tile's row chain
+        if (ti == 0 && (int)((tpk >> 5) & 31u) < B1_NKT(DS, a)) issue_tile((int)((tpk >> 5) & 31u));   // the next tile's K / V rows, under this tile's row chain
         // ---- the tile goes on through registers: this side's partial of dx = dK Wk^T + dV Wv^T ----
         const B1Args& ar = b1_args_again();                               // (this chain's pointers: not carried across the loop)
         r_store<B1_NT_WS>(const_cast<float*>(ar.bd.dqkv) + MD, mo, dk, rok, dcx);   // dK, dV: for the weight-gradient images of phase 3
@@ -1320,11 +1329,11 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) { awk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; awv[j] = awk[j]; awkb[j] = awk[j]; awvb[j] = awk[j]; }
     const int it = wave >> 1, jt0 = 2 * (wave & 1);
-    const int R = a.nkt > SB_TPR ? 2 : 1;
+    const int R = B1_NKT(DS, a) > SB_TPR ? 2 : 1;
     // a round's rows (x, dK, dV of the wave's tile) are requested one round ahead: the second round's fly under the first round's products
     RRaw r1, r2, r3;
     auto issue3 = [&](int rd) {
-        if (rd < R && wave < min(SB_TPR, a.nkt - rd * SB_TPR)) {
+        if (rd < R && wave < min(SB_TPR, B1_NKT(DS, a) - rd * SB_TPR)) {
             const int qq = 16 * (rd * SB_TPR + wave) + (lane_now() & 15);
             const u32 mo = (u32)(base_row + min(qq, T - 1)) * (u32)(4 * D);
             r_issue(r1, bk.x, mo, dcx);
@@ -1336,7 +1345,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     B1Small small;
 #pragma unroll 1
     for (int rd = 0; rd < R; ++rd) {
-        const int ntr = min(SB_TPR, a.nkt - rd * SB_TPR);
+        const int ntr = min(SB_TPR, B1_NKT(DS, a) - rd * SB_TPR);
         if (wave < ntr) {
             f32x4 x[4], g[4];
             r_finish(x, r1, dcx);
@@ -1536,7 +1545,11 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     // scratch); any other size runs the generic instantiation (live predicates: it spills -- see DESIGN.md section 4)
     switch (d->D) {
     case 64: return split ? launch_b1<true, 64, 2>(a, nwg, s) : launch_b1<false, 64, 2>(a, nwg, s);      // two heads of 32 columns
-    case 50: return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
+    case 50:
+        // (the headline's length, 13 tiles, as a constant too: DS = D | nkt << 8)
+        static const bool no_nk = getenv("CASTREC_B1_NO_NKT") != nullptr;       // (measurement switch)
+        if (a.nkt == 13 && !no_nk) return split ? launch_b1<true, 50 | (13 << 8)>(a, nwg, s) : launch_b1<false, 50 | (13 << 8)>(a, nwg, s);
+        return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
     case 32: return split ? launch_b1<true, 32>(a, nwg, s) : launch_b1<false, 32>(a, nwg, s);
     case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);
     case 48: return split ? launch_b1<true, 48>(a, nwg, s) : launch_b1<false, 48>(a, nwg, s);
