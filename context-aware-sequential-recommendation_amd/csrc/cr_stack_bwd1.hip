@@ -52,7 +52,8 @@
 // classification does with D.  DS < 0: the families of cr_rlayout.hpp d_ctx<NF>; 0: everything at run time.
 #define DS_EXACT(DS) ((DS) > 0 ? ((DS) & 255) : (DS))
 #define DS_D(DS, run) ((DS) > 0 ? ((DS) & 255) : (run))
-#define B1_NKT(DS, a) ((DS) > 255 ? ((DS) >> 8) : (a).nkt)
+#define B1_NKT(DS, a) ((DS) > 255 ? (((DS) >> 8) & 255) : (a).nkt)
+#define B1_T(DS, a) ((DS) > 65535 ? ((DS) >> 16) : (a).T)          // ... and the sequence length: DS = D | nkt << 8 | T << 16
 #undef D_NF
 #define D_NF(DS) ((DS) > 0 ? ((DS) & 255) / 16 : ((DS) < 0 ? -(DS) - 1 : -1))
 
@@ -223,7 +224,7 @@ __device__ __forceinline__ void b1_phase1(const B1Args& a, unsigned char* smem, 
     float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
     float* gam = fl + L::GAM; float* gamF = fl + L::GAMF; float* part = fl + L::PART; float* partF = fl + L::PARTF; float* sdel = fl + L::SDEL;
     constexpr int WST = L::WST, IST = L::IST;
-    const int D = DS_D(DS, d.D), T = a.T;
+    const int D = DS_D(DS, d.D), T = B1_T(DS, a);
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the step counters: requested first of all, used behind the barrier that opens the phase
@@ -697,7 +698,7 @@ __device__ __forceinline__ void b1_stage_kv_put(B1Stage& r, unsigned char* smem,
 template <int DS>
 __device__ __forceinline__ void b1_q_stage_issue(const B1Args& a, int n, B1Stage& st, WRegs<1, SB_NT>& w) {
     const cr_block_desc& bk = a.bd.f;
-    const int D = DS_D(DS, bk.D), T = a.T;
+    const int D = DS_D(DS, bk.D), T = B1_T(DS, a);
     w_issue<1, SB_NT>(w, D, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0, bk.wqkv, 3 * D, 0);
     b1_stage_kv_issue(st, a, n * T, 16 * B1_NKT(DS, a), D, bk.M);
 }
@@ -714,7 +715,7 @@ __device__ __forceinline__ void b1_q_side(const B1Args& a, unsigned char* smem, 
     float* fl = reinterpret_cast<float*>(smem + L::F_OFF_BYTES);
     float* gam = fl + L::GAM; float* part = fl + L::PART; float* sdel = fl + L::SDEL; float* kb = fl + L::KB;
     constexpr int IST = L::IST;
-    const int D = DS_D(DS, bk.D), T = a.T, T16 = 16 * B1_NKT(DS, a);
+    const int D = DS_D(DS, bk.D), T = B1_T(DS, a), T16 = 16 * B1_NKT(DS, a);
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
@@ -1032,7 +1033,7 @@ __device__ __forceinline__ void b1_k_side(const B1Args& a, unsigned char* smem, 
     float* sdel = fl + L::SDEL; float* smx = fl + L::SMX; float* suni = fl + L::SUNI; float* sqv = fl + L::SQV;
     float* tile_flag = fl + L::TFLAG;
     constexpr int WST = L::WST, IST = L::IST;
-    const int D = DS_D(DS, bk.D), T = a.T, T16 = 16 * B1_NKT(DS, a);
+    const int D = DS_D(DS, bk.D), T = B1_T(DS, a), T16 = 16 * B1_NKT(DS, a);
     const DCtx dcx = d_ctx<D_NF(DS)>(D);
     const int base_row = n * T, M = bk.M;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lg = lane >> 4;
@@ -1546,9 +1547,9 @@ extern "C" int cr_stack_block_bwd(const cr_block_bwd_desc* bd, const cr_attn_des
     switch (d->D) {
     case 64: return split ? launch_b1<true, 64, 2>(a, nwg, s) : launch_b1<false, 64, 2>(a, nwg, s);      // two heads of 32 columns
     case 50:
-        // (the headline's length, 13 tiles, as a constant too: DS = D | nkt << 8)
+        // (the headline's length -- 200 positions, 13 tiles -- as constants too: DS = D | nkt << 8 | T << 16)
         static const bool no_nk = getenv("CASTREC_B1_NO_NKT") != nullptr;       // (measurement switch)
-        if (a.nkt == 13 && !no_nk) return split ? launch_b1<true, 50 | (13 << 8)>(a, nwg, s) : launch_b1<false, 50 | (13 << 8)>(a, nwg, s);
+        if (a.T == 200 && !no_nk) return split ? launch_b1<true, 50 | (13 << 8) | (200 << 16)>(a, nwg, s) : launch_b1<false, 50 | (13 << 8) | (200 << 16)>(a, nwg, s);
         return split ? launch_b1<true, 50>(a, nwg, s) : launch_b1<false, 50>(a, nwg, s);
     case 32: return split ? launch_b1<true, 32>(a, nwg, s) : launch_b1<false, 32>(a, nwg, s);
     case 40: return split ? launch_b1<true, 40>(a, nwg, s) : launch_b1<false, 40>(a, nwg, s);
