@@ -69,8 +69,10 @@ __global__ __launch_bounds__(64 * ADAM_WAVES) void k_adam(cr_adam_desc d, cr_tgr
     constexpr bool TG = LPR > 0;
     cr_kernarg_touch<sizeof(cr_adam_desc) + (TG ? sizeof(cr_tgrad_desc) : 0)>();
     const uint32_t t = d.step_snapshot ? *d.step_snapshot : *reinterpret_cast<const uint32_t*>(d.state + 4);
-    // (the unit workgroups dispatched FIRST -- physical blocks 0 .. nb_units-1 -- ran the launch 4 us longer than this order: 29.7
-    //  against 25.8 us; the dense blocks' slab sums are the other long chain and want the early start)
+    // (Two other dispatch orders were measured and lost: the unit workgroups FIRST -- 29.7 against 25.8 us at the time: the dense blocks'
+    //  slab sums are the other long chain and want the early start -- and the short sections, id ring and sweep, first -- 21.8 against
+    //  20.6 us.  The unit grid holds a batch's plan in ONE pass -- 384 workgroups: 260-280 are in use at the headline shape; at 256 a few
+    //  workgroups ran two passes: 20.6 against 19.8 us.)
     const int bid = (int)blockIdx.x;
     if (bid >= (int)gridDim.x - nb_ring) {
         // the last nb_ring blocks: the next step's ids out of the resident ring (nothing else in this launch reads the static id

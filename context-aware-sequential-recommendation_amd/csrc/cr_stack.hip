@@ -171,8 +171,10 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     // of the LDS is free before every wave has left its feed-forward: 159 296 + 4 192 of 163 840 bytes at 13 tiles)
     float* hpart = kb + 16 * NKT;
     // (HEAD launches hold ONE block -- PAIR launches do -- as a constant: with a run-time block loop around it, everything loop-invariant of
-    //  the head tail was formed in front of the loop and carried, spilled, across the attention phase)
-    const int nblk = PAIR ? 1 : a.nb;                     // (a PAIR launch is one block: cr_stack_fwd, `per`)
+    //  the head tail was formed in front of the loop and carried, spilled, across the attention phase.  NOT for the other PAIR launches:
+    //  the constant there removed 32 bytes of scratch from the generic instantiations and made the headline's launches 1 us LONGER each --
+    //  28.98 / 26.16 / 28.36 against 27.88 / 25.22 / 27.72 us by position, rocprofv3)
+    const int nblk = HEAD ? 1 : a.nb;
 #pragma unroll 1
     for (int b = 0; b < nblk; ++b) {
         const cr_block_desc& d = a.blk[b].bd;

@@ -22,7 +22,7 @@ extern "C" int cr_tgrad_geometry(int D, int* ng, int* ent) {
 }
 
 // unit workgroups of a launch: one wave of them where the chip holds it (a batch's plan: a few hundred at the headline shape)
-int tg_unit_grid(const cr_tgrad_desc* d) { return d->lay.cap_blocks < 320 ? d->lay.cap_blocks : 320; }
+int tg_unit_grid(const cr_tgrad_desc* d) { return d->lay.cap_blocks < 384 ? d->lay.cap_blocks : 384; }
 
 extern "C" int cr_table_grad(const cr_tgrad_desc* d, float* table_grad, void* stream) {
     const char* why = tg_unsupported(d);
