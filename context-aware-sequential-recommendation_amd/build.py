@@ -51,24 +51,62 @@ def _operands(rest):
     return [o.strip().lstrip("-").strip("|") for o in rest.split(",") if o.strip()]
 
 
+_VREG = re.compile(r"^v(?:\[(\d+):(\d+)\]|(\d+))$")
+_WRITES_VGPR = ("v_", "ds_read", "global_load", "buffer_load", "flat_load", "scratch_load")
+
+
+def _vregs(op):
+    """The VGPR numbers an operand names: 'v[4:7]' -> {4, 5, 6, 7}, 'v9' -> {9}, anything else -> empty."""
+    m = _VREG.match(op)
+    if not m:
+        return frozenset()
+    if m.group(3) is not None:
+        return frozenset([int(m.group(3))])
+    return frozenset(range(int(m.group(1)), int(m.group(2)) + 1))
+
+
 def scan_isa(text):
-    """Scans an AMDGPU assembly listing.  Returns dict(kernels, pk_fma, pk_add, pk_mul, in_place_any, violations) where a
-    violation is (function, line number, the chain's lines): see ISA_CHECKED."""
-    out = dict(kernels=0, pk_fma=0, pk_add=0, pk_mul=0, in_place_any=0, violations=[])
+    """Scans an AMDGPU assembly listing.  Returns dict(kernels, pk_fma, pk_add, pk_mul, in_place_any, mfma, mixed_mfma_chains,
+    violations) where a violation is (function, line number, the chain's lines): see ISA_CHECKED.  Two kinds:
+    * an in-place packed fp32 chain (profiles/r04_flake/README.md);
+    * an MFMA whose SrcC is the destination of the latest MFMA that wrote those registers and that one has ANOTHER shape (round 5:
+      v_mfma_f32_16x16x16_bf16 accumulating onto v_mfma_f32_16x16x32_bf16's result gave wrong, run-dependent values in the first
+      two accumulator registers -- the plain-bf16 block backward's weight gradients at the headline length; one shape along an
+      accumulation chain is the form that is exact: cr_rbwd.hpp wgrad_accum).  Listing order, not control flow: a heuristic, which
+      is what a build-time tripwire can be."""
+    out = dict(kernels=0, pk_fma=0, pk_add=0, pk_mul=0, in_place_any=0, mfma={}, mixed_mfma_chains=0, violations=[])
     func, last = "?", []                                  # last: the two preceding vector instructions (mnemonic, dst, line)
+    mfma_dst = {}                                         # register set -> (mnemonic, line) of the MFMA that wrote it last
     for no, line in enumerate(text.splitlines(), 1):
         if line and not line[0].isspace():
             m = _LABEL.match(line)
             if m and not line.startswith("."):            # a function's entry label (basic-block labels start with .LBB)
-                func, last = m.group(1), []
+                func, last, mfma_dst = m.group(1), [], {}
                 out["kernels"] += 1
             continue
         t = line.strip()
-        if not t.startswith("v_"):
+        if not t.startswith(_WRITES_VGPR):
             continue
         mn, _, rest = t.partition(" ")
         ops = _operands(rest.split(";")[0])
         dst = ops[0] if ops else ""
+        dregs = _vregs(dst)
+        if mn.startswith("v_mfma"):
+            out["mfma"][mn] = out["mfma"].get(mn, 0) + 1
+            srcc = _vregs(ops[3]) if len(ops) >= 4 else frozenset()
+            prev = mfma_dst.get(srcc)
+            if prev and prev[0] != mn:
+                out["mixed_mfma_chains"] += 1
+                out["violations"].append((func, no, [prev[1], t]))
+            for k in [k for k in mfma_dst if k & dregs]:
+                del mfma_dst[k]
+            if dregs:
+                mfma_dst[dregs] = (mn, t)
+        elif dregs and mfma_dst:
+            for k in [k for k in mfma_dst if k & dregs]:
+                del mfma_dst[k]
+        if not t.startswith("v_"):
+            continue
         if mn in _PK_F32:
             out[mn[2:-4]] += 1
             if dst in ops[1:]:
@@ -112,7 +150,7 @@ def check_isa_file(source_name, flags, headers, hipcc=None, listing=None):
         json.dump(res, fh, indent=1)
     if res["violations"]:
         f, no, chain = res["violations"][0]
-        raise RuntimeError("%s: %d in-place packed fp32 chains in the device code (first: %s, line %d: %s) -- see build.py ISA_CHECKED"
+        raise RuntimeError("%s: %d forbidden instruction chains in the device code (in-place packed fp32, or MFMAs of two shapes on one accumulator; first: %s, line %d: %s) -- see build.py ISA_CHECKED"
                            % (source_name, len(res["violations"]), f, no, " ; ".join(chain)))
     return res
 

@@ -106,7 +106,6 @@ __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], c
                                             int ntr, int it, int jt0) {
     const int lane = lane_now();
     const __bf16 one = (__bf16)1.0f;
-    const bf4 ones4 = (bf4){one, one, one, one};
     const bf8 ones8 = (bf8){one, one, one, one, one, one, one, one};
     auto cat = [](const bf4& x, const bf4& y) { return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7); };
 #pragma unroll
@@ -136,27 +135,32 @@ __device__ __forceinline__ void wgrad_accum(f32x4 (&acc)[2], f32x4 (&accb)[2], c
                 }
             }
         } else if (t < ntr) {
-            const bf4 ah = tr4(Ah, 16 * t, it, lane);
-            const bf4 al = SPLIT ? tr4(Al, 16 * t, it, lane) : ah;
-            bf4 gh[2], gl[2];
+            // an odd last tile: the SAME K = 32 instruction with zeros in k slots 4..7.  (It used to go through the K = 16 shape; in the plain-bf16
+            // build -- two products per pair instead of six -- that 4-pass product then read, as its SrcC, the accumulator of the 8-pass product
+            // issued just before it, and registers 0 / 1 of that accumulator came out wrong, run-dependent: tools/probes/bf16_w2_blocks.py,
+            // DESIGN.md section 4 "Round 5: a mixed-shape accumulate".  One shape along the whole chain is the form the hardware forwards.)
+            const bf4 z4 = (bf4){(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+            const bf8 ah = cat(tr4(Ah, 16 * t, it, lane), z4);
+            const bf8 al = SPLIT ? cat(tr4(Al, 16 * t, it, lane), z4) : ah;
+            bf8 gh[2], gl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                gh[j] = tr4(Gh, 16 * t, jt0 + j, lane);
-                gl[j] = SPLIT ? tr4(Gl, 16 * t, jt0 + j, lane) : gh[j];
+                gh[j] = cat(tr4(Gh, 16 * t, jt0 + j, lane), z4);
+                gl[j] = SPLIT ? cat(tr4(Gl, 16 * t, jt0 + j, lane), z4) : gh[j];
             }
             if (SPLIT) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, gh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh[j], acc[j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gl[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl[j], acc[j], 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, gh[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh[j], acc[j], 0, 0, 0);
             if (BIAS && it == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones4, gl[j], accb[j], 0, 0, 0);
-                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones4, gh[j], accb[j], 0, 0, 0);
+                    if (SPLIT) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, gl[j], accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, gh[j], accb[j], 0, 0, 0);
                 }
             }
         }

@@ -1,4 +1,5 @@
-"""The device code of the register-layout kernels holds no in-place packed fp32 chain (castrec_amd/build.py: ISA_CHECKED).
+"""The device code of the register-layout kernels holds no in-place packed fp32 chain and no accumulation chain of two MFMA shapes
+(castrec_amd/build.py: ISA_CHECKED).
 
 profiles/r04_flake/README.md pins round 3's wrong-dx episodes to ONE compiler-made form: v_pk_add_f32 t ; v_pk_fma_f32 t, a, b, t ;
 v_pk_mul_f32 out, c, t on one register pair (SLP vectorisation of the LayerNorm backward's last statement).  The source can no
@@ -45,6 +46,41 @@ def test_scanner_sees_the_failing_chain_and_nothing_else():
     assert good["violations"] == [] and good["pk_fma"] == 2 and good["in_place_any"] >= 2
 
 
+# round 5: the plain-bf16 block backward at the headline length (listing of k_stack_block_bwd<false, 50, 1> before the fix): the odd
+# seventh tile's K = 16 product accumulates onto the K = 32 product of tiles 4 / 5 -- registers 0 / 1 of that accumulator came out
+# wrong, run-dependent (tools/probes/bf16_w2_blocks.py)
+MIXED = """
+_Z17k_stack_block_bwdILb0ELi50ELi1EEv6B1Args:
+\tds_read_b64_tr_b16 v[104:105], v106 offset:22528
+\tds_read_b64_tr_b16 v[106:107], v106 offset:24576
+\tv_mfma_f32_16x16x32_bf16 v[104:107], v[100:103], v[104:107], v[116:119]
+\tv_mfma_f32_16x16x32_bf16 v[100:103], v[100:103], v[108:111], v[120:123]
+\ts_cmp_lt_i32 s87, 7
+.LBB5_253:
+\tv_lshl_add_u32 v92, v92, 1, 0
+\tds_read_b64_tr_b16 v[108:109], v94 offset:12288
+\tv_mfma_f32_16x16x16_bf16 v[104:107], v[108:109], v[94:95], v[104:107]
+\tv_mfma_f32_16x16x16_bf16 v[100:103], v[108:109], v[110:111], v[100:103]
+"""
+ONE_SHAPE = """
+_Z17k_stack_block_bwdILb0ELi50ELi1EEv6B1Args:
+\tv_mfma_f32_16x16x32_bf16 v[104:107], v[100:103], v[104:107], v[116:119]
+\tv_mfma_f32_16x16x32_bf16 v[104:107], v[108:111], v[92:95], v[104:107]
+\tv_mfma_f32_16x16x32_bf16 v[100:103], v[100:103], v[108:111], v[120:123]
+\tv_mov_b32_e32 v100, 0
+\tv_mfma_f32_16x16x16_bf16 v[100:103], v[108:109], v[110:111], v[100:103]
+"""
+
+
+def test_scanner_sees_an_accumulation_chain_of_two_mfma_shapes():
+    bad = B.scan_isa(MIXED)
+    assert bad["mixed_mfma_chains"] == 2 and len(bad["violations"]) == 2
+    assert bad["mfma"] == {"v_mfma_f32_16x16x32_bf16": 2, "v_mfma_f32_16x16x16_bf16": 2}
+    assert "16x16x32" in bad["violations"][0][2][0] and "16x16x16" in bad["violations"][0][2][1]
+    ok = B.scan_isa(ONE_SHAPE)           # one shape along a chain; a K = 16 product on registers a vector instruction rewrote is no chain
+    assert ok["violations"] == [] and ok["mixed_mfma_chains"] == 0
+
+
 def _headers():
     return B.HEADERS
 
@@ -58,7 +94,8 @@ def test_production_listing_is_clean(src):
         B.check_isa_file(src, flags, _headers())                                   # hipcc -S --cuda-device-only; raises on a violation
     with open(B.isa_summary_path(src)) as fh:
         d = json.load(fh)
-    assert d["violations"] == [] and d["kernels"] >= 1
+    assert d["violations"] == [] and d["kernels"] >= 1 and d["mixed_mfma_chains"] == 0
+    assert set(d["mfma"]) == {"v_mfma_f32_16x16x32_bf16"}          # the bf16 kernels hold ONE matrix instruction shape (round 5)
     assert ("-fno-slp-vectorize" in d["flags"]) == (src != "cr_attn_bf.hip")
     if src != "cr_attn_bf.hip":
         # without SLP every packed op comes from explicit two-element vector code (the hi / lo splits): adds and multiplies of

@@ -351,7 +351,8 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     batch size.  Same mathematics; the projections / feed-forward / weight gradients run on split bf16 products here and on
     fp32 MFMA there, so the two differ by the rounding of those products: 1e-4 of the tensor scale for the split form
     (measured 2e-5); plain bf16 rounds every operand to 8 bits, at different places on the two paths: 3e-2 on the
-    activations, 1e-1 on the gradients (ReLU gates of near-zero units flip; measured 4.5e-2)."""
+    activations; on the gradients 3e-2 with the same forward (measured 1e-2) and 1e-1 with another forward (measured 4.5e-2).  Until
+    round 5 the bound was 1e-1 throughout, which hid a defect: test_plain_bf16_weight_gradients_at_the_headline_length."""
     rs = np.random.RandomState(5)
     itemnum, max_bins = 45, 9
     hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=H, dropout_rate=0.2, max_bins=max_bins, seed=13)
@@ -379,7 +380,48 @@ def test_register_layout_kernels_equal_the_tile_kernels(monkeypatch, E, prec, en
     ga, gb = a.grads(), b.grads()
     gmax = max(float(v.abs().max()) for v in gb.values())
     for k in gb:
-        assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1) * gmax, k
+        # (plain bf16 with another FORWARD: the activations themselves differ at the 8-bit level and the backward inherits that, 4.5e-2
+        #  measured; with the same forward and another backward: 1e-2 measured)
+        assert float((ga[k] - gb[k]).abs().max()) <= (10 * tol if prec == "bf16x3" else 1e-1 if env == "CASTREC_NO_STACK_KERNEL" else 3e-2) * gmax, k
+
+
+def test_plain_bf16_weight_gradients_at_the_headline_length(monkeypatch, E):
+    """Round 5 found the plain-bf16 block backward's dW2 wrong by 20-50 % of its largest entry at T = 200 / D = 50, run-dependent, in
+    registers 0 / 1 of the out-column tiles 0 and 2, from the rows of tiles 4 / 5 only: the odd seventh tile of a round went through
+    v_mfma_f32_16x16x16_bf16 with, as SrcC, the result of the v_mfma_f32_16x16x32_bf16 of tiles 4 / 5 issued just before it (two
+    products per pair in the plain build, six in the split one, which never showed it).  A 1e-1 bound on plain bf16 hid it.  Now one
+    shape along the chain (cr_rbwd.hpp wgrad_accum; the build refuses listings with such a chain: tests/test_isa.py).  Here: every
+    weight gradient of the one-launch block backward against the tile kernels (fp32 MFMA on the same stored activations), relative
+    to the parameter's OWN largest entry, with all positions live and with only the rows of tiles 4 / 5 live, and the same bits twice."""
+    T, D, B = 200, 50, 3
+    hp = E.Hyper(maxlen=T, hidden_units=D, num_blocks=2, num_heads=1, dropout_rate=0.2, max_bins=9, seed=13)
+    a = E.Engine("sasrec", 9, 45, hp, B, training=True, n_slabs=7, attn_precision="bf16")
+    monkeypatch.setenv("CASTREC_NO_STACK_BWD", "1")
+    b = E.Engine("sasrec", 9, 45, hp, B, training=True, n_slabs=7, attn_precision="bf16")
+    monkeypatch.delenv("CASTREC_NO_STACK_BWD")
+    assert "cr_stack_block_bwd" in [n for n, _, _ in a.bwd] and "cr_stack_block_bwd" not in [n for n, _, _ in b.bwd]
+    a.P.add_(0.05 * torch.randn(a.P.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
+    b.P.copy_(a.P)
+    for lo, hi in ((0, T), (64, 96)):
+        rs = np.random.RandomState(5)
+        batch = [x.copy() for x in make_batch(rs, B, T, 45, 9)]
+        for x in batch[:3]:
+            x[:, :lo] = 0
+            x[:, hi:] = 0
+            x[:, lo:hi] = np.maximum(x[:, lo:hi], 1)
+        got = []
+        for e in (a, a, b):
+            e.set_batch(*batch)
+            e.set_step(1)
+            e.Gflat.zero_()
+            e.launch_step(apply=False)
+            torch.cuda.synchronize()
+            got.append({k: v.clone() for k, v in e.grads().items()})
+        for k in got[0]:
+            if k.endswith((".w1", ".w2", ".wq", ".wk", ".wv")):
+                assert torch.equal(got[0][k], got[1][k]), k
+                err = float((got[0][k] - got[2][k]).abs().max() / got[2][k].abs().max())
+                assert err < 3e-2, (lo, hi, k, err)               # (measured <= 1.1e-2; the defect: 0.2-0.86)
 
 
 @pytest.mark.parametrize("model", ["cast_1", "cast_3"])
