@@ -365,9 +365,15 @@ class EngineReplica:
 
     def snapshot(self):
         """Everything a step changes (parameters, Adam moments, the state block with the step counter and the loss sums, the
-        gradient bucket, row-sparse Adam's claim flags): capture_step's rehearsals are undone with restore()."""
+        gradient bucket, the static id buffers, row-sparse Adam's claim flags): capture_step's rehearsals are undone with restore()."""
         e = self.e
         snap = dict(P=e.P.clone(), Mom=e.Mom.clone(), Vel=e.Vel.clone(), state=e.state.clone(), Gflat=e.Gflat.clone())
+        if getattr(e, "batch_buf", None) is not None:
+            # (with the id ring a step ENDS by moving the next slot's ids into the static id buffers: a rehearsal step undone without
+            #  them would replay on the next batch -- bench.py's forced-collectives run fell back to three graphs that way, round 5)
+            snap["batch_buf"] = e.batch_buf.clone()       # (ids + the batch's occurrence index)
+        elif getattr(e, "ids_all", None) is not None:
+            snap["ids_all"] = e.ids_all.clone()
         if getattr(e, "lazy_flags", None) is not None:
             snap["lazy_flags"] = e.lazy_flags.clone()
         return snap

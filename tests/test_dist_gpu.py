@@ -273,3 +273,44 @@ def test_graph_resident_step_with_the_collectives_on_one_rank(sparse, one_graph)
     finally:
         dist.destroy_process_group()
 
+
+
+def test_whole_step_graph_over_the_id_ring_on_one_rank():
+    """bench.py's data-parallel form: the batches wait in the id ring (slot = ids + occurrence index), a step ends by moving the next
+    slot's ids into the static id buffers, and the whole step -- collectives included -- is ONE HIP graph that capture_step validates
+    by replaying one step against an eager step from a state snapshot.  Round 5: the snapshot did not hold the id buffers, the replay
+    ran on the NEXT batch, the validation refused the graph and bench.py's forced-collectives run silently measured the three-graph
+    form.  One rank over RCCL (force_collectives), the engine's own slab count (so the prediction head rides the last forward launch):
+    the graph must be accepted and three steps must equal the plain engine's on the same batches."""
+    import torch.distributed as dist
+    import castrec_amd  # noqa: F401
+    from castrec_amd import engine as E
+    from castrec_amd.dist import DataParallel, EngineReplica
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        items = 5000
+        a = E.Engine("cast_1", USERS, items, hyper(E), B, training=True)
+        b = E.Engine("cast_1", USERS, items, hyper(E), B, training=True)
+        perturb_start(a)
+        b.P.copy_(a.P)
+        batches = [make_batch(st, items) for st in range(4)]
+        staged = torch.from_numpy(np.stack([b.pack_slot(*bt) for bt in batches])).cuda()
+        b.use_id_ring(staged)
+        b.load_slot(staged[0])
+        dp = DataParallel(EngineReplica(b, use_graph=True), 0, 1, force_collectives=True)
+        assert dp.capture_step(), dp.step_form_why
+        assert dp.step_form == "one graph" and dp._replay_report["matches_eager"], (dp.step_form_why, dp._replay_report)
+        b.set_step(1); b.Mom.zero_(); b.Vel.zero_(); b.Gflat.zero_()
+        b.load_slot(staged[b.step_number() % len(batches)])
+        a.set_step(1); a.Mom.zero_(); a.Vel.zero_(); a.Gflat.zero_()
+        for st in range(3):
+            a.train_step(*batches[(st + 1) % len(batches)])              # (slot = step number mod slots; the first step is number 1)
+            dp.step_phases()
+        torch.cuda.synchronize()
+        pa, pb = a.get_params(), b.get_params()
+        for k in pa:
+            if not k.endswith(".bk"):
+                assert (pa[k] - pb[k]).abs().max().item() <= 1e-5, k
+    finally:
+        dist.destroy_process_group()
