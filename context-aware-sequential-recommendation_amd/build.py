@@ -37,7 +37,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.jo
 # pk_add -> pk_fma -> pk_mul chain on one pair that profiles/r04_flake/README.md pins the round-3 wrong-dx episodes to (47 of them
 # in an SLP build of cr_stack_bwd1.hip, none in production).  cr_common.hpp's cr_ln_bwd_tail keeps the source from forming it;
 # this keeps any other statement, flag or compiler version from forming it unseen.
-ISA_CHECKED = ["cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_attn_bf.hip"]
+ISA_CHECKED = ["cr_stack.hip", "cr_stack_bwd.hip", "cr_stack_bwd1.hip", "cr_wide.hip", "cr_attn_bf.hip",
+               # (round 5: every source with matrix instructions -- the two-shape rule; each holds ONE shape today)
+               "cr_block.hip", "cr_attn_fwd.hip", "cr_attn_bwd.hip", "cr_attn_bwd1.hip", "cr_gemm.hip", "cr_gemm_bf.hip"]
 SLP_PROTECTED = ("cr_stack", "cr_wide")          # file-name prefixes that may never be compiled with SLP vectorisation
 _PK_F32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
 _LABEL = re.compile(r"^([A-Za-z_$][\w$.]*):")

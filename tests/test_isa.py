@@ -95,7 +95,9 @@ def test_production_listing_is_clean(src):
     with open(B.isa_summary_path(src)) as fh:
         d = json.load(fh)
     assert d["violations"] == [] and d["kernels"] >= 1 and d["mixed_mfma_chains"] == 0
-    assert set(d["mfma"]) == {"v_mfma_f32_16x16x32_bf16"}          # the bf16 kernels hold ONE matrix instruction shape (round 5)
+    assert len(d["mfma"]) == 1, d["mfma"]                             # every source holds ONE matrix instruction shape (round 5)
+    if src.startswith(("cr_stack", "cr_wide", "cr_attn_bf", "cr_gemm_bf")):
+        assert set(d["mfma"]) == {"v_mfma_f32_16x16x32_bf16"}
     assert ("-fno-slp-vectorize" in d["flags"]) == (src != "cr_attn_bf.hip")
     if src != "cr_attn_bf.hip":
         # without SLP every packed op comes from explicit two-element vector code (the hi / lo splits): adds and multiplies of
