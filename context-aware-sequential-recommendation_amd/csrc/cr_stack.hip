@@ -31,6 +31,7 @@
 struct StackBlk { cr_block_desc bd; cr_attn_desc ad; };
 struct StackArgs {
     int nb, T16, nkt;
+    unsigned char ptile[2][8];    // PAIR mode: the query tile of wave w of workgroup y (255 = none): stack_deal_pair
     float isd_log2e, invT;
     const float* lnf_g; const float* lnf_b; float* out; int ld_out, col_out;
     unsigned long long* ts;       // debug: per-wave phase stamps [B][8 waves][64] (tools/stack_ts.py); NULL in production
@@ -126,12 +127,13 @@ __global__ __launch_bounds__(64 * NW) void k_stack_fwd(StackArgs a) {
     const int base_row = n * T;
     SK_TS(0); SK_TS(1);
     // tiles of this wave, heaviest first: ranks w and 2 W - 1 - w of the order "last tile first" (causal cost = tile + 1)
-    const int tile0 = a.nkt - 1 - (PAIR ? 2 * wave + (int)blockIdx.y : wave);
+    auto ptile = [&](int y) { const int t = a.ptile[y][wave]; return t == 255 ? -1 : t; };
+    const int tile0 = PAIR ? ptile((int)blockIdx.y) : a.nkt - 1 - wave;
     const int tile1 = PAIR ? -1 : a.nkt - 1 - (2 * NW - 1 - wave);
     const int nB = (tile0 >= 0 ? 1 : 0) + (tile1 >= 0 ? 1 : 0);              // phase B / C tiles (tile1 >= 0 implies tile0 >= 0)
     // phase A tiles: the wave's own B / C tile first, then (PAIR) the tile of the same rank pair that the OTHER workgroup
     // takes through B / C -- so a wave only ever re-reads rows of x / y that it wrote itself
-    const int tileP = PAIR ? a.nkt - 1 - (2 * wave + 1 - (int)blockIdx.y) : tile1;
+    const int tileP = PAIR ? ptile(1 - (int)blockIdx.y) : tile1;
     const int nA = (tile0 >= 0 ? 1 : 0) + (tileP >= 0 ? 1 : 0);
     auto tile_a = [&](int i) { return (i == 0 && tile0 >= 0) ? tile0 : tileP; };
     auto tile_b = [&](int i) { return i == 0 ? tile0 : tile1; };
@@ -739,6 +741,37 @@ extern "C" int cr_stack_fwd_head_supported(const cr_stack_desc* s, const cr_head
     return stack_head_unsupported(s, h, n) == nullptr;
 }
 
+// PAIR mode: which query tile wave w of workgroup y carries through the attention and feed-forward phases (each workgroup runs phase A on
+// its own tile and on the partner's tile of the same wave, so any deal covers every tile's K / V in both).  Until round 5: tile
+// nkt - 1 - (2 w + y) -- workgroup 0's SIMD 0 (waves 0 and 4) carried tiles 12 and 4, SIMD 3 tile 6 alone.  Now: tiles in descending
+// order go to the (workgroup, SIMD) with the smallest sum of (key tiles + ST_DEAL_FIXED) so far, upper wave (w + 4) first when free.
+#ifndef ST_DEAL_FIXED
+#define ST_DEAL_FIXED 6
+#endif
+static void stack_deal_pair(int nkt, unsigned char (&pt)[2][8]) {
+    for (int y = 0; y < 2; ++y) for (int w = 0; w < 8; ++w) pt[y][w] = 255;
+    if (nkt > 16) return;                                 // (PAIR mode takes at most 16 tiles: stack_pair_mode)
+    static const int fixed = getenv("CASTREC_FWD_DEAL_FIXED") ? atoi(getenv("CASTREC_FWD_DEAL_FIXED")) : ST_DEAL_FIXED;
+    if (fixed < 0) {                                      // the deal of rounds 2-4 (measurement switch)
+        for (int y = 0; y < 2; ++y) for (int w = 0; w < 8; ++w) { const int t = nkt - 1 - (2 * w + y); pt[y][w] = t >= 0 ? (unsigned char)t : 255; }
+        return;
+    }
+    int sum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int t = nkt - 1; t >= 0; --t) {
+        int by = -1, bs = -1;
+        for (int s4 = 0; s4 < 4; ++s4)
+            for (int y = 0; y < 2; ++y) {
+                if (cnt[y][s4] >= 2) continue;
+                if (by < 0 || sum[y][s4] < sum[by][bs]) { by = y; bs = s4; }
+            }
+        if (by < 0) return;
+        const int w = cnt[by][bs] == 0 ? bs : bs + 4;    // a SIMD's first (heavier) tile: the lower wave
+        pt[by][w] = (unsigned char)t;
+        ++cnt[by][bs];
+        sum[by][bs] += t + 1 + fixed;
+    }
+}
+
 static int stack_fwd_impl(const cr_stack_desc* s, const cr_head_desc* h, const cr_ln_bwd_desc* n, void* stream) {
     const char* why = h ? stack_head_unsupported(s, h, n) : stack_unsupported(s);
     CR_REQUIRE(why == nullptr, "%s: unsupported (%s)", h ? "cr_stack_fwd_head" : "cr_stack_fwd", why ? why : "");
@@ -748,6 +781,7 @@ static int stack_fwd_impl(const cr_stack_desc* s, const cr_head_desc* h, const c
     const cr_attn_desc& a0 = s->attn[0];
     a.T16 = (a0.T + 15) / 16 * 16;
     a.nkt = a.T16 / 16;
+    stack_deal_pair(a.nkt, a.ptile);
     a.isd_log2e = (float)(1.4426950408889634 / sqrt((double)a0.d));
     a.invT = 1.0f / (float)a0.T;
     a.ts = g_attn_ts_which == 7 ? g_attn_ts : nullptr;

@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
 
 #include "cr_rbwd.hpp"
 
@@ -1405,37 +1406,125 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
 // =====================================================================================================
 // host side
 // =====================================================================================================
-// Tiles of the attention passes' waves: at most two per wave (what a wave carries through registers), heaviest first to the
-// SIMD (waves w and w + 4 share one) with the fewest pair iterations so far, there to the wave with the fewer.  A query tile
-// qt meets key tiles 0..qt, a key tile kt query tiles kt..nkt-1, two per loop iteration.
-static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
-    int cost[16], order[16], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int w = 0; w < 8; ++w) pk[w] = 0x3FFu;                           // two "none" entries
-    for (int t = 0; t < nkt; ++t) {
-        // pair iterations + what a tile costs whatever its length (fragments from memory, the row chain behind the loop,
-        // stores: about two iterations' worth on the timeline, tools/b1_ts.py)
-        cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2 + 2;
-        order[t] = t;
-    }
+// Tiles of the attention passes' waves: at most two per wave (what a wave carries through registers).  A query tile qt meets key tiles
+// 0..qt, a key tile kt query tiles kt..nkt-1, two per loop iteration; a tile costs its pair iterations + 3 (fragments from memory, the
+// row chain behind the loop, stores: tools/b1_ts.py).  Waves w and w + 4 share a SIMD, and what the timeline shows is that the SIMD's SUM
+// sets the pace (the wave whose SIMD carried 20 units finished 3 us behind the ones at 18-19): so the deal minimises the largest SIMD sum
+// first (a small branch-and-bound over the 4^nkt assignments, heaviest tile first, equal partial SIMDs tried once), then the largest wave;
+// inside a SIMD the heavier wave takes the upper half (w + 4: raised priority in the loops, b1_q_side / b1_k_side), inside a wave the
+// heavier tile goes first.  Round 5: the greedy deal before this one (heaviest tile to the lightest SIMD) left SIMD sums of 19 / 18 / 18 / 20
+// at 13 tiles where 19 / 19 / 19 / 18 exists: 0.3163 -> 0.3125 ms per step (tools/probes/deal_ab.sh, three interleaved rounds).
+struct B1Deal { unsigned pk[8]; bool done; };
+static void b1_deal_search(int nkt, bool query_pass, unsigned (&pk)[8]) {
+    int cost[16], order[16];
+    for (int t = 0; t < nkt; ++t) { cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2 + 3; order[t] = t; }
     for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
         for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
-    {
-        for (int i = 0; i < nkt; ++i) {
-            const int t = order[i];
-            int best = -1;
-            for (int s4 = 0; s4 < 4; ++s4) {
-                if (cnt[s4] >= 2 && cnt[s4 + 4] >= 2) continue;
-                if (best < 0 || load[s4] + load[s4 + 4] < load[best] + load[best + 4]) best = s4;
-            }
-            int w = best;
-            if (cnt[w] >= 2 || (cnt[w + 4] < 2 && load[w + 4] < load[w])) w = best + 4;
-            pk[w] = (pk[w] & ~(31u << (5 * cnt[w]))) | ((unsigned)t << (5 * cnt[w]));
-            ++cnt[w];
-            load[w] += cost[t];
+    int simd_of[16], sums[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+    for (int t = 0; t < 16; ++t) simd_of[t] = -1;
+    long best_key[3] = {1L << 40, 1L << 40, 1L << 40};
+    int best_wave[16];                                                     // tile -> wave
+    bool have = false;
+    // the best split of one SIMD's tiles over its two waves (at most two each): returns the larger wave's load
+    auto split = [&](int s, int* wave_of) {
+        int ts[4], k = 0;
+        for (int t = 0; t < nkt; ++t) if (simd_of[t] == s) ts[k++] = t;
+        if (k == 1) { wave_of[ts[0]] = s; return cost[ts[0]]; }           // a lone tile: the lower wave, as ever
+        int best_m = 1 << 30, best_mask = 0;
+        for (int mask = 0; mask < (1 << k); ++mask) {
+            const int na = __builtin_popcount(mask);
+            if (na > 2 || k - na > 2) continue;
+            int la = 0, lb = 0;
+            for (int i = 0; i < k; ++i) ((mask >> i) & 1 ? la : lb) += cost[ts[i]];
+            if (la > lb) continue;                                         // the lighter wave is the lower one (ties: either)
+            if (lb < best_m) { best_m = lb; best_mask = mask; }
         }
+        if (best_m == (1 << 30)) return -1;
+        for (int i = 0; i < k; ++i) wave_of[ts[i]] = ((best_mask >> i) & 1) ? s : s + 4;
+        return best_m;
+    };
+    // iterative depth-first search
+    int choice[16];
+    int i = 0;
+    choice[0] = -1;
+    while (i >= 0) {
+        if (i == nkt) {
+            int wave_of[16], wmax = 0;
+            bool ok = true;
+            for (int s = 0; s < 4 && ok; ++s) {
+                if (cnt[s] == 0) continue;
+                const int m = split(s, wave_of);
+                if (m < 0) ok = false; else if (m > wmax) wmax = m;
+            }
+            if (ok) {
+                long smax = 0, sq = 0;
+                for (int s = 0; s < 4; ++s) { if (sums[s] > smax) smax = sums[s]; sq += (long)sums[s] * sums[s]; }
+                const long key[3] = {smax, wmax, sq};
+                if (!have || key[0] < best_key[0] || (key[0] == best_key[0] && (key[1] < best_key[1] || (key[1] == best_key[1] && key[2] < best_key[2])))) {
+                    have = true;
+                    for (int k = 0; k < 3; ++k) best_key[k] = key[k];
+                    for (int t = 0; t < nkt; ++t) best_wave[t] = wave_of[t];
+                }
+            }
+            --i;
+            continue;
+        }
+        const int t = order[i];
+        if (choice[i] >= 0) { const int s = choice[i]; --cnt[s]; sums[s] -= cost[t]; simd_of[t] = -1; }     // undo the last choice at this depth
+        int s = choice[i] + 1;
+        for (; s < 4; ++s) {
+            if (cnt[s] >= 4) continue;
+            bool dup = false;                                              // an equal partial SIMD was tried already at this depth
+            for (int p = 0; p < s; ++p) if (sums[p] == sums[s] && cnt[p] == cnt[s]) { dup = true; break; }
+            if (dup) continue;
+            if (have && sums[s] + cost[t] > best_key[0]) continue;
+            break;
+        }
+        if (s >= 4) { choice[i] = -1; --i; continue; }
+        choice[i] = s; ++cnt[s]; sums[s] += cost[t]; simd_of[t] = s;
+        ++i;
+        if (i < 16) choice[i] = -1;
     }
-    // (Tried, round 4: eight bins of at most two tiles dealt so that the four heaviest go to the waves that win their SIMD's
-    //  arbitration -- the first-dispatched half, or the half raised by s_setprio: within the run-to-run spread of the step, +-0.5 %.)
+    for (int w = 0; w < 8; ++w) pk[w] = 0x3FFu;                           // two "none" entries
+    int wc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < nkt; ++k) {                                        // heaviest first: a wave's heavier tile is its first
+        const int t = order[k], w = best_wave[t];
+        pk[w] = (pk[w] & ~(31u << (5 * wc[w]))) | ((unsigned)t << (5 * wc[w]));
+        ++wc[w];
+    }
+}
+static void b1_deal_tiles(int nkt, bool query_pass, unsigned (&pk)[8]) {
+    static B1Deal cache[2][16];
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        B1Deal& c = cache[query_pass ? 1 : 0][nkt & 15];
+        if (!c.done) { b1_deal_search(nkt, query_pass, c.pk); c.done = true; }
+        for (int w = 0; w < 8; ++w) pk[w] = c.pk[w];
+    }
+    // measurement override: CASTREC_B1_QPK / CASTREC_B1_KPK = eight entries "a" or "a:b" (tile numbers; "-" = none), comma separated, wave 0 first
+    if (const char* ov = getenv(query_pass ? "CASTREC_B1_QPK" : "CASTREC_B1_KPK")) {
+        unsigned t[8];
+        int w = 0;
+        const char* c = ov;
+        while (w < 8 && *c) {
+            unsigned a0 = 31, a1 = 31;
+            if (*c != '-') { a0 = (unsigned)strtol(c, const_cast<char**>(&c), 10); if (*c == ':') { ++c; a1 = (unsigned)strtol(c, const_cast<char**>(&c), 10); } }
+            else ++c;
+            t[w++] = (a0 & 31u) | ((a1 & 31u) << 5);
+            if (*c == ',') ++c;
+        }
+        if (w == 8) for (int i = 0; i < 8; ++i) pk[i] = t[i];
+    }
+}
+
+// (for tests: the deal of one pass -- pk[w] = two 5-bit tile numbers of wave w, 31 = none)
+extern "C" int cr_stack_block_bwd_deal(int nkt, int query_pass, uint32_t* pk) {
+    CR_REQUIRE(pk && nkt >= 1 && nkt <= 2 * SB_TPR, "cr_stack_block_bwd_deal: 1 <= tiles <= 14");
+    unsigned t[8];
+    b1_deal_tiles(nkt, query_pass != 0, t);
+    for (int w = 0; w < 8; ++w) pk[w] = t[w];
+    return CR_OK;
 }
 
 static const char* b1_unsupported(const cr_block_bwd_desc* bd, const cr_attn_desc* ad, int B, int T, int precision) {

@@ -176,6 +176,7 @@ _sig("cr_stack_ffn_bwd_heads", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(LnBwdDes
 _sig("cr_stack_qkv_bwd", c_i, [C.POINTER(BlockBwdDesc), c_i, c_i, c_i, c_p])
 _sig("cr_stack_qkv_bwd_scatter", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(EmbedBwdDesc), c_i, c_i, c_i, c_p])
 _sig("cr_stack_block_bwd_supported", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(AttnDesc), c_i, c_i, c_i])
+_sig("cr_stack_block_bwd_deal", c_i, [c_i, c_i, C.POINTER(C.c_uint32)])
 _sig("cr_stack_block_bwd", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(AttnDesc), C.POINTER(BlockBwd1Ext), C.POINTER(LnBwdDesc), C.POINTER(EmbedBwdDesc),
                                  c_i, c_i, c_i, c_p])
 _sig("cr_block_ln_qkv_bwd_scatter", c_i, [C.POINTER(BlockBwdDesc), C.POINTER(EmbedBwdDesc), c_p])
@@ -211,7 +212,7 @@ _sig("cr_table_grad", c_i, [C.POINTER(TgradDesc), c_p, c_p])
 
 EXPORTS = ["cr_version", "cr_last_error", "cr_step_begin", "cr_ids_ring_next", "cr_embed_fwd", "cr_embed_bwd", "cr_layernorm_fwd",
            "cr_layernorm_bwd", "cr_gemm_rows", "cr_gemm_wgrad", "cr_eltwise", "cr_attn_fwd", "cr_attn_bwd",
-           "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_rows_pack", "cr_rows_add", "cr_block_ln_qkv_bwd_scatter",
+           "cr_block_ln_qkv_fwd", "cr_block_ln_qkv_fwd_gather", "cr_block_ln_ffn_fwd", "cr_block_ln_ffn_fwd_tail", "cr_stack_fwd_supported", "cr_stack_fwd", "cr_block_ln_ffn_bwd", "cr_block_ln_qkv_bwd", "cr_stack_bwd_supported", "cr_stack_ffn_bwd", "cr_stack_ffn_bwd_ln", "cr_stack_ffn_bwd_heads", "cr_stack_qkv_bwd", "cr_stack_qkv_bwd_scatter", "cr_stack_block_bwd_supported", "cr_stack_block_bwd", "cr_stack_block_bwd_deal", "cr_rows_pack", "cr_rows_add", "cr_block_ln_qkv_bwd_scatter",
            "cr_wide_supported", "cr_wide_ln_qkv_fwd", "cr_wide_ln_ffn_fwd", "cr_wide_ln_ffn_fwd_tail", "cr_wide_ln_ffn_bwd", "cr_wide_ln_qkv_bwd",
            "cr_head_fwd_bwd", "cr_head_fwd_bwd_ln", "cr_stack_fwd_head_supported", "cr_stack_fwd_head", "cr_test_logits", "cr_adam_step", "cr_reduce_slabs", "cr_l2_penalty", "cr_graph_begin", "cr_graph_end", "cr_graph_launch",
            "cr_graph_destroy", "cr_sampler_create", "cr_sampler_next", "cr_sampler_destroy",

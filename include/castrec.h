@@ -364,6 +364,9 @@ typedef struct {
 int cr_stack_block_bwd_supported(const cr_block_bwd_desc* d, const cr_attn_desc* ad, int B, int T, int precision);   /* 1 / 0 */
 int cr_stack_block_bwd(const cr_block_bwd_desc* d, const cr_attn_desc* ad, const cr_block_bwd1_ext* x, const cr_ln_bwd_desc* lnf,
                        const cr_embed_bwd_desc* sc, int B, int T, int precision, void* stream);
+/* (tests) the deal of one attention pass of cr_stack_block_bwd at `tiles` 16-row tiles (1..14): pk[w] = the two tiles of wave w as
+ * 5-bit numbers (low bits first, 31 = none).  Host only, no GPU. */
+int cr_stack_block_bwd_deal(int tiles, int query_pass, uint32_t* pk);
 
 /* ---- the same four row phases for hidden sizes 128 / 192 / 256 (configs C4, C5) on the bf16 matrix pipe (cr_wide.hip):
  * one launch each where the unfused path runs cr_layernorm_* + cr_gemm_rows (+ cr_eltwise) chains -- modules.py:53-80
