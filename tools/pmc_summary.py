@@ -24,16 +24,22 @@ def short(name):
     return name.split("(")[0]
 
 
+def newest(files, window=600.0):
+    """gpurun merges every call's outputs into the same directory: only the files of the latest run of a pass count"""
+    files = sorted(files, key=os.path.getmtime)
+    return [f for f in files if os.path.getmtime(files[-1]) - os.path.getmtime(f) <= window] if files else []
+
+
 def agg(pattern, counter):
     d = collections.defaultdict(list)
-    for f in glob.glob(pattern):
+    for f in newest(glob.glob(pattern)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in d.items()}
 
 
-stats = glob.glob(os.path.join(src, "p_kt", "*", "*_kernel_stats.csv"))
+stats = newest(glob.glob(os.path.join(src, "p_kt", "*", "*_kernel_stats.csv")))[-1:]
 if stats:
     shutil.copy(stats[0], os.path.join(out, tag + "_kernel_stats.csv"))
 fe = agg(os.path.join(src, "p_fetch", "*", "*_counter_collection.csv"), "FETCH_SIZE")
