@@ -3,6 +3,7 @@
 // one-GPU step never materialises the table gradient: cr_adam_step sums each listed row and updates it in place (cr_adam.hip).
 #include <string.h>
 
+#include <stdlib.h>
 #include "cr_tgrad.hpp"
 
 template <int LPR, int VEC, int ENT>
@@ -22,7 +23,10 @@ extern "C" int cr_tgrad_geometry(int D, int* ng, int* ent) {
 }
 
 // unit workgroups of a launch: one wave of them where the chip holds it (a batch's plan: a few hundred at the headline shape)
-int tg_unit_grid(const cr_tgrad_desc* d) { return d->lay.cap_blocks < 384 ? d->lay.cap_blocks : 384; }
+int tg_unit_grid(const cr_tgrad_desc* d) {
+    static const int cap = getenv("CASTREC_TG_UNITS") ? atoi(getenv("CASTREC_TG_UNITS")) : 384;      // (measurement override)
+    return d->lay.cap_blocks < cap ? d->lay.cap_blocks : cap;
+}
 
 extern "C" int cr_table_grad(const cr_tgrad_desc* d, float* table_grad, void* stream) {
     const char* why = tg_unsupported(d);
