@@ -1416,79 +1416,12 @@ __global__ __launch_bounds__(SB_NT) void k_stack_block_bwd(B1Args a) {
 // at 13 tiles where 19 / 19 / 19 / 18 exists: 0.3163 -> 0.3125 ms per step (tools/probes/deal_ab.sh, three interleaved rounds).
 struct B1Deal { unsigned pk[8]; bool done; };
 static void b1_deal_search(int nkt, bool query_pass, unsigned (&pk)[8]) {
-    int cost[16], order[16];
-    for (int t = 0; t < nkt; ++t) { cost[t] = ((query_pass ? t + 1 : nkt - t) + 1) / 2 + 3; order[t] = t; }
-    for (int i = 1; i < nkt; ++i)                                          // heaviest first (stable insertion sort)
-        for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
-    int simd_of[16], sums[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
-    for (int t = 0; t < 16; ++t) simd_of[t] = -1;
-    long best_key[3] = {1L << 40, 1L << 40, 1L << 40};
-    int best_wave[16];                                                     // tile -> wave
-    bool have = false;
-    // the best split of one SIMD's tiles over its two waves (at most two each): returns the larger wave's load
-    auto split = [&](int s, int* wave_of) {
-        int ts[4], k = 0;
-        for (int t = 0; t < nkt; ++t) if (simd_of[t] == s) ts[k++] = t;
-        if (k == 1) { wave_of[ts[0]] = s; return cost[ts[0]]; }           // a lone tile: the lower wave, as ever
-        int best_m = 1 << 30, best_mask = 0;
-        for (int mask = 0; mask < (1 << k); ++mask) {
-            const int na = __builtin_popcount(mask);
-            if (na > 2 || k - na > 2) continue;
-            int la = 0, lb = 0;
-            for (int i = 0; i < k; ++i) ((mask >> i) & 1 ? la : lb) += cost[ts[i]];
-            if (la > lb) continue;                                         // the lighter wave is the lower one (ties: either)
-            if (lb < best_m) { best_m = lb; best_mask = mask; }
-        }
-        if (best_m == (1 << 30)) return -1;
-        for (int i = 0; i < k; ++i) wave_of[ts[i]] = ((best_mask >> i) & 1) ? s : s + 4;
-        return best_m;
-    };
-    // iterative depth-first search
-    int choice[16];
-    int i = 0;
-    choice[0] = -1;
-    while (i >= 0) {
-        if (i == nkt) {
-            int wave_of[16], wmax = 0;
-            bool ok = true;
-            for (int s = 0; s < 4 && ok; ++s) {
-                if (cnt[s] == 0) continue;
-                const int m = split(s, wave_of);
-                if (m < 0) ok = false; else if (m > wmax) wmax = m;
-            }
-            if (ok) {
-                long smax = 0, sq = 0;
-                for (int s = 0; s < 4; ++s) { if (sums[s] > smax) smax = sums[s]; sq += (long)sums[s] * sums[s]; }
-                const long key[3] = {smax, wmax, sq};
-                if (!have || key[0] < best_key[0] || (key[0] == best_key[0] && (key[1] < best_key[1] || (key[1] == best_key[1] && key[2] < best_key[2])))) {
-                    have = true;
-                    for (int k = 0; k < 3; ++k) best_key[k] = key[k];
-                    for (int t = 0; t < nkt; ++t) best_wave[t] = wave_of[t];
-                }
-            }
-            --i;
-            continue;
-        }
-        const int t = order[i];
-        if (choice[i] >= 0) { const int s = choice[i]; --cnt[s]; sums[s] -= cost[t]; simd_of[t] = -1; }     // undo the last choice at this depth
-        int s = choice[i] + 1;
-        for (; s < 4; ++s) {
-            if (cnt[s] >= 4) continue;
-            bool dup = false;                                              // an equal partial SIMD was tried already at this depth
-            for (int p = 0; p < s; ++p) if (sums[p] == sums[s] && cnt[p] == cnt[s]) { dup = true; break; }
-            if (dup) continue;
-            if (have && sums[s] + cost[t] > best_key[0]) continue;
-            break;
-        }
-        if (s >= 4) { choice[i] = -1; --i; continue; }
-        choice[i] = s; ++cnt[s]; sums[s] += cost[t]; simd_of[t] = s;
-        ++i;
-        if (i < 16) choice[i] = -1;
-    }
+    int wave_of[16], order[16];
+    cr_deal_search(nkt, query_pass, wave_of, order);
     for (int w = 0; w < 8; ++w) pk[w] = 0x3FFu;                           // two "none" entries
     int wc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < nkt; ++k) {                                        // heaviest first: a wave's heavier tile is its first
-        const int t = order[k], w = best_wave[t];
+        const int t = order[k], w = wave_of[t];
         pk[w] = (pk[w] & ~(31u << (5 * wc[w]))) | ((unsigned)t << (5 * wc[w]));
         ++wc[w];
     }
